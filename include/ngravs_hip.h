@@ -1,0 +1,204 @@
+/* ngravs_hip.h -- C ABI of libngravs_hip.so, the MI355X (gfx950) gravitational force engine for
+ * Gadget-2.0.7-ngravs.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference: everything under
+ * compute_accelerations() (accel.c:24-96) that computes gravity, i.e.
+ *     domain_Decomposition()  (domain.c:62)      -> ngravs_domain_decomposition()
+ *     force_treebuild()       (forcetree.c:61)   -> ngravs_force_treebuild()
+ *     gravity_tree()          (gravtree.c:27)    -> ngravs_gravity_tree()
+ *     pmforce_periodic()      (pm_periodic.c:204)-> ngravs_pmforce_periodic()
+ *     init_grav_maps()/wire_grav_maps() (ngravs_core.c:201, ngravs.c:64) -> ngravs_config_t.law_*
+ *     force_treeallocate() short-range tabulation (forcetree.c:3246-3403) -> ngravs_shortrange_table()
+ *     gravity_forcetest() direct sum (gravtree_forcetest.c:28, forcetree.c:3428) -> ngravs_direct_sum()
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types in any signature.  The reference keeps
+ * its state in globals (P[], All, TypeToGrav[], AccelFxns[][] ...); the glue a maintainer adds to
+ * the reference (gadget-2.0.7-ngravs_amd/host/gadget_glue.c) copies the fields
+ * listed in SURVEY.md 8(b) into ngravs_config_t / ngravs_particles_t and calls the functions below
+ * from the reference's own entry points, which keep their `void f(void)` signatures.
+ *
+ * Error convention: every call returns 0 on success or a negative ngravs_status; in addition a
+ * fatal condition invokes the registered on_fatal(code, msg) callback first (default: print
+ * "endrun called with an error level of C" in the reference's wording and return), mirroring
+ * endrun(code) (endrun.c:25-43).  Codes reuse the reference's numbers where one exists
+ * (1 = out of tree nodes, forcetree.c:247-253; 986/987 = massive empty node, forcetree.c:1482,1906).
+ *
+ * Threading: entry points are called serially from one host thread per process; one process per
+ * GPU (SURVEY.md 8(b) "Threading").
+ */
+#ifndef NGRAVS_HIP_H
+#define NGRAVS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGRAVS_ABI_VERSION 1
+#define NGRAVS_MAX_GRAVS 3      /* N_GRAVS upper bound compiled in (allvars.h:130-152)            */
+#define NGRAVS_NTYPES 6         /* Gadget particle types                                           */
+#define NGRAVS_NTAB 2048        /* NTAB: short-range table length (Makefile.reference, forcetree.c:33) */
+#define NGRAVS_ASMTH 1.25       /* allvars.h:83                                                     */
+#define NGRAVS_RCUT 4.5         /* allvars.h:87                                                     */
+#define NGRAVS_BITS_PER_DIMENSION 18 /* allvars.h:34: bits of the reference Peano-Hilbert key      */
+#define NGRAVS_TREE_BITS 21     /* bits/dim of the engine's internal tree key; key21>>9 == key18    */
+
+/* Force-law identifiers: the device cannot call through the reference's `gravity` function
+ * pointers (allvars.h:131-150), so each wired pointer is named by an id.  The same id selects the
+ * r-space law (AccelFxns), its k-space Green's function (GreensFxns) and the normalised Green's
+ * function (NormedGreensFxns) of that law. */
+typedef enum {
+  NGRAVS_LAW_NONE = 0,        /* none            ngravs.c:344                         */
+  NGRAVS_LAW_NEWTON = 1,      /* newtonian :351, pgdelta :390, normed_pgdelta :400    */
+  NGRAVS_LAW_NEG_NEWTON = 2,  /* neg_newtonian :357, neg_pgdelta :406                 */
+  NGRAVS_LAW_YUKAWA = 3,      /* yukawa :856, pgyukawa :869, normed_pgyukawa :880     */
+  NGRAVS_LAW_COLOYUK = 4,     /* coloyuk :826, pgcoloyuk :830, normed_pgcoloyuk :834  */
+  NGRAVS_LAW_COUNT
+} ngravs_law;
+
+typedef enum {
+  NGRAVS_SPLINE_NONE = 0,        /* none                 */
+  NGRAVS_SPLINE_PLUMMER = 1,     /* plummer      ngravs.c:420-434 */
+  NGRAVS_SPLINE_NEG_PLUMMER = 2, /* neg_plummer  ngravs.c:438-455 */
+  NGRAVS_SPLINE_COUNT
+} ngravs_spline;
+
+typedef enum {
+  NGRAVS_OK = 0,
+  NGRAVS_ERR_ARG = -1,        /* bad argument / unsupported configuration                 */
+  NGRAVS_ERR_NO_DEVICE = -2,  /* no HIP device or HIP runtime error                       */
+  NGRAVS_ERR_NOMEM = -3,      /* device allocation failed                                 */
+  NGRAVS_ERR_STATE = -4,      /* call order violated (e.g. walk before tree build)        */
+  NGRAVS_ERR_TREE = -5,       /* tree build failed (out of nodes: reference endrun(1))    */
+  NGRAVS_ERR_WIRING = -6      /* law table not wired / asymmetric (ngravs_core.c:321-424) */
+} ngravs_status;
+
+/* Walk variants (what gravity_tree() does per particle). */
+typedef enum {
+  NGRAVS_WALK_STRICT = 0, /* per-target opening decisions, exactly force_treeevaluate[_shortrange]
+                             (forcetree.c:1244-1610, 1623-2052): same interaction set and count     */
+  NGRAVS_WALK_GROUP = 1   /* wavefront-cooperative walk: 64 Peano-contiguous targets share one
+                             breadth-first traversal; a node is used only if EVERY target of the
+                             group would use it (conservative => at least the reference accuracy)   */
+} ngravs_walk_mode;
+
+/* The subset of `All`, TypeToGrav[] and the law tables the path reads. */
+typedef struct {
+  int32_t abi_version;        /* NGRAVS_ABI_VERSION                                            */
+  int32_t n_gravs;            /* N_GRAVS, 1..NGRAVS_MAX_GRAVS                                   */
+  int32_t periodic;           /* PERIODIC                                                       */
+  int32_t pmgrid;             /* PMGRID, 0 = tree-only                                          */
+  double box_size;            /* All.BoxSize                                                    */
+  double G;                   /* All.G                                                          */
+  double err_tol_theta;       /* All.ErrTolTheta (0 => relative criterion, gravtree.c:334-335)  */
+  double err_tol_force_acc;   /* All.ErrTolForceAcc                                             */
+  double force_softening[NGRAVS_NTYPES]; /* All.ForceSoftening[] = 2.8*SofteningTable (gravtree.c:514) */
+  int32_t type_to_grav[NGRAVS_NTYPES];   /* TypeToGrav[] (ngravs_core.c:201-260)                */
+  /* [TARGET][SOURCE] tables exactly as wire_grav_maps() fills them (ngravs.c:73-76) */
+  int32_t law_accel[NGRAVS_MAX_GRAVS][NGRAVS_MAX_GRAVS];    /* AccelFxns        -> ngravs_law    */
+  int32_t law_spline[NGRAVS_MAX_GRAVS][NGRAVS_MAX_GRAVS];   /* AccelSplines     -> ngravs_spline */
+  int32_t law_greens[NGRAVS_MAX_GRAVS][NGRAVS_MAX_GRAVS];   /* GreensFxns       -> ngravs_law    */
+  int32_t law_normed[NGRAVS_MAX_GRAVS][NGRAVS_MAX_GRAVS];   /* NormedGreensFxns -> ngravs_law    */
+  double yukawa_imass;        /* YUKAWA_IMASS (ngravs.c:41-43), default 60.0                     */
+  double asmth;               /* All.Asmth[0] = ASMTH*BoxSize/PMGRID (pm_periodic.c:59); 0 => derive */
+  double rcut;                /* All.Rcut[0]  = RCUT*Asmth (pm_periodic.c:60); 0 => derive       */
+  double tree_alloc_factor;   /* All.TreeAllocFactor (nodes per particle), 0 => 0.8              */
+  int32_t walk_mode;          /* ngravs_walk_mode                                                */
+  int32_t device;             /* HIP device ordinal                                              */
+  int32_t rank, world_size;   /* ThisTask, NTask: target shard = Peano segment `rank` of `world_size` */
+  int32_t reserved[8];
+} ngravs_config_t;
+
+/* Host- or device-resident particle columns (the fields of struct particle_data the path reads,
+ * allvars.h:546-581).  AoS callers pass strides in BYTES (e.g. stride 144 for P[] built with
+ * PMGRID), SoA callers pass sizeof(element).  `on_device` != 0 means the pointers are HIP device
+ * pointers (zero-copy hand-over; no PCIe traffic inside the call). */
+typedef struct {
+  int64_t n;                 /* NumPart                                               */
+  const double *pos;         /* Pos[3]          */  int64_t pos_stride;
+  const double *mass;        /* Mass            */  int64_t mass_stride;
+  const int32_t *type;       /* Type            */  int64_t type_stride;
+  const double *old_acc;     /* OldAcc (may be NULL => 0) */ int64_t old_acc_stride;
+  const uint8_t *active;     /* NULL => all active; else 1 where Ti_endstep==All.Ti_Current (gravtree.c:113) */
+  int64_t active_stride;
+  int32_t on_device;
+  int32_t reserved;
+} ngravs_particles_t;
+
+/* Per-call statistics, the numbers gravity_tree() logs to timings.txt/cpu.txt
+ * (gravtree.c:408-447, run.c:394-402). */
+typedef struct {
+  int64_t n_active;          /* Nf                                                       */
+  int64_t n_nodes;           /* Numnodestree                                             */
+  double interactions;       /* sum of ninteractions over active targets (ia/part * Nf)  */
+  double t_domain, t_peano, t_treebuild, t_treewalk, t_pm; /* seconds, device time       */
+  double walk_kernel_ms;     /* duration of the dominant walk kernel, HIP events          */
+  double reserved[7];
+} ngravs_stats_t;
+
+typedef struct ngravs_ctx ngravs_ctx;
+typedef void (*ngravs_fatal_fn)(int code, const char *msg);
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int ngravs_abi_version(void);
+const char *ngravs_build_info(void);                    /* arch, N_GRAVS instantiations, NTAB ... */
+void ngravs_config_default(ngravs_config_t *cfg);       /* N_GRAVS=1 Newton/plummer, tree-only    */
+/* init_grav_maps()+wire_grav_maps() checks (ngravs_core.c:321-424) happen here. */
+int ngravs_create(const ngravs_config_t *cfg, ngravs_ctx **out);
+void ngravs_destroy(ngravs_ctx *ctx);
+void ngravs_set_fatal_handler(ngravs_ctx *ctx, ngravs_fatal_fn fn);
+/* Change the walk parameters between calls (All.ErrTolTheta latch, gravtree.c:334-335). */
+int ngravs_set_opening(ngravs_ctx *ctx, double err_tol_theta, double err_tol_force_acc);
+int ngravs_set_walk_mode(ngravs_ctx *ctx, int walk_mode);
+
+/* ---- data hand-over ---------------------------------------------------------------------- */
+/* Replace the engine's particle set (the role of P[] + NumPart). */
+int ngravs_set_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
+/* Update OldAcc only (second pass of accel.c:48-52 without re-uploading positions). */
+int ngravs_set_old_acc(ngravs_ctx *ctx, const double *old_acc, int64_t stride, int on_device);
+
+/* ---- the path ---------------------------------------------------------------------------- */
+/* domain_findExtent + keys + Peano-Hilbert order (domain.c:882-944, peano.c:36-185).  Computes
+ * DomainCorner/Center/Len/Fac, the 18-bit reference keys and the device-side Peano order. */
+int ngravs_domain_decomposition(ngravs_ctx *ctx);
+/* force_treebuild(): returns the number of tree nodes (>0) or a negative status. */
+int64_t ngravs_force_treebuild(ngravs_ctx *ctx);
+/* gravity_tree(): walk for all active targets, OldAcc update, xG (gravtree.c:102-341). */
+int ngravs_gravity_tree(ngravs_ctx *ctx);
+/* pmforce_periodic(): GravPM for all particles (pm_periodic.c:204-790). */
+int ngravs_pmforce_periodic(ngravs_ctx *ctx);
+/* compute_accelerations(0) for gravity: [PM if pm_step] + domain + build + tree (accel.c:24-58). */
+int ngravs_compute_accelerations(ngravs_ctx *ctx, int pm_step);
+
+/* ---- results, in the caller's ORIGINAL particle order -------------------------------------- */
+/* Any pointer may be NULL.  stride in bytes as above.  grav_cost = ninteractions (gravtree.c) */
+int ngravs_get_accel(ngravs_ctx *ctx, double *grav_accel, int64_t accel_stride,
+                     double *grav_pm, int64_t pm_stride, double *old_acc, int64_t old_acc_stride,
+                     float *grav_cost, int64_t cost_stride, int on_device);
+int ngravs_get_stats(ngravs_ctx *ctx, ngravs_stats_t *out);
+/* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac (domain.c:916-923) -> out[8] */
+int ngravs_get_domain(ngravs_ctx *ctx, double out[8]);
+/* 18-bit reference Peano-Hilbert keys in original particle order (domain.c:938-944). */
+int ngravs_get_keys(ngravs_ctx *ctx, int64_t *keys, int on_device);
+/* Device-side Peano order: order[i] = original index of the i-th particle along the curve. */
+int ngravs_get_order(ngravs_ctx *ctx, int32_t *order, int on_device);
+
+/* ---- stand-alone pieces of the path ------------------------------------------------------- */
+/* peano_hilbert_key(x,y,z,bits) (peano.c:356-398), host. */
+int64_t ngravs_peano_hilbert_key(int x, int y, int z, int bits);
+/* Keys for n positions on the device given corner/fac (domain.c:938-944); host buffers. */
+int ngravs_peano_keys(ngravs_ctx *ctx, const double *pos, int64_t n, const double corner[3],
+                      double fac, int bits, int64_t *keys);
+/* shortrange_fourier_force[target][source][NTAB] (forcetree.c:3246-3403): out has
+ * n_gravs*n_gravs*NTAB doubles; pot_out (may be NULL) the matching shortrange_fourier_pot. */
+int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, double *pot_out);
+/* force_treeevaluate_direct for targets idx[0..nt) against all particles, non-periodic or
+ * nearest-image (no Ewald term); result xG into acc[3*nt] (forcetree.c:3428-3548). */
+int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *acc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NGRAVS_HIP_H */
