@@ -1,0 +1,257 @@
+"""gadget-2.0.7-ngravs_amd -- host-side mirror of the reference's gravity entry points over the
+C ABI of libngravs_hip.so (include/ngravs_hip.h).
+
+The directory name is not an importable identifier; load it with `__graft_entry__.load_package()`
+(importlib, alias `ngravs_amd`).  The names below follow the reference (proto.h): an `Engine`
+plays the role of the globals P[]/All/TypeToGrav[] for one MPI task and exposes
+domain_Decomposition(), force_treebuild(), gravity_tree(), pmforce_periodic(),
+compute_accelerations().  There is NO CPU fallback: if the HIP library or a GPU is missing every
+entry point raises (the oracle under oracle/ is test infrastructure and is never imported here).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi, ic  # noqa: F401
+from .abi import (Config, Particles, Stats, make_config, WALK_GROUP, WALK_STRICT,  # noqa: F401
+                  LAW_NONE, LAW_NEWTON, LAW_NEG_NEWTON, LAW_YUKAWA, LAW_COLOYUK)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libngravs_hip.so")
+_LIB = None
+
+# every symbol include/ngravs_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+EXPORTS = [
+    "ngravs_abi_version", "ngravs_build_info", "ngravs_config_default", "ngravs_create", "ngravs_destroy",
+    "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_particles",
+    "ngravs_set_old_acc", "ngravs_domain_decomposition", "ngravs_force_treebuild", "ngravs_gravity_tree",
+    "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
+    "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
+    "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
+]
+
+
+class NgravsError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into libngravs_hip.so (in-tree)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise NgravsError("libngravs_hip.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.ngravs_build_info.restype = C.c_char_p
+        L.ngravs_last_error.restype = C.c_char_p
+        L.ngravs_last_error.argtypes = [C.c_void_p]
+        L.ngravs_peano_hilbert_key.restype = C.c_int64
+        L.ngravs_peano_hilbert_key.argtypes = [C.c_int] * 4
+        L.ngravs_force_treebuild.restype = C.c_int64
+        L.ngravs_force_treebuild.argtypes = [C.c_void_p]
+        for name in ("ngravs_destroy", "ngravs_domain_decomposition", "ngravs_gravity_tree",
+                     "ngravs_pmforce_periodic"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.ngravs_compute_accelerations.argtypes = [C.c_void_p, C.c_int]
+        L.ngravs_set_opening.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ngravs_set_walk_mode.argtypes = [C.c_void_p, C.c_int]
+        L.ngravs_set_particles.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_set_old_acc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        L.ngravs_get_accel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int64, C.c_int]
+        L.ngravs_get_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_get_domain.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_get_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ngravs_get_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ngravs_get_shard.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngravs_peano_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.ngravs_shortrange_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngravs_direct_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def peano_hilbert_key(x, y, z, bits):
+    """peano_hilbert_key() (reference peano.c:356-398), host implementation of the library."""
+    return int(lib().ngravs_peano_hilbert_key(int(x), int(y), int(z), int(bits)))
+
+
+def shortrange_table(cfg):
+    """shortrange_fourier_force/pot[target][source][NTAB] (reference forcetree.c:3246-3403)."""
+    ng = cfg.n_gravs
+    force = np.zeros((ng, ng, abi.NTAB))
+    pot = np.zeros((ng, ng, abi.NTAB))
+    rc = lib().ngravs_shortrange_table(C.byref(cfg), force.ctypes.data, pot.ctypes.data)
+    if rc != 0:
+        raise NgravsError("ngravs_shortrange_table: %d" % rc)
+    return force, pot
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Engine:
+    """One task's gravity state: the replacement for the reference's globals on this path."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = lib().ngravs_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise NgravsError("ngravs_create failed with status %d (no HIP device or bad wiring)" % rc)
+        self._keep = []
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().ngravs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = lib().ngravs_last_error(self._h)
+            raise NgravsError("%s failed: status %d (%s)" % (what, rc, msg.decode() if msg else ""))
+
+    # -- P[] hand-over ------------------------------------------------------------------------
+    def set_particles(self, pos, mass, ptype, old_acc=None, active=None):
+        """numpy (host) columns; strides are taken from the arrays, so AoS views work."""
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        ptype = np.ascontiguousarray(ptype, dtype=np.int32)
+        p = Particles()
+        p.n = len(pos)
+        p.pos, p.pos_stride = pos.ctypes.data, 24
+        p.mass, p.mass_stride = mass.ctypes.data, 8
+        p.type, p.type_stride = ptype.ctypes.data, 4
+        keep = [pos, mass, ptype]
+        if old_acc is not None:
+            old_acc = np.ascontiguousarray(old_acc, dtype=np.float64)
+            p.old_acc, p.old_acc_stride = old_acc.ctypes.data, 8
+            keep.append(old_acc)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.uint8)
+            p.active, p.active_stride = active.ctypes.data, 1
+            keep.append(active)
+        p.on_device = 0
+        self._keep = keep
+        self.n = p.n
+        self._check(lib().ngravs_set_particles(self._h, C.byref(p)), "ngravs_set_particles")
+
+    def set_particles_device(self, n, pos_ptr, mass_ptr, type_ptr, old_acc_ptr=None, active_ptr=None):
+        """HIP device pointers (e.g. torch tensors' data_ptr()): zero-copy hand-over."""
+        p = Particles()
+        p.n = n
+        p.pos, p.pos_stride = pos_ptr, 24
+        p.mass, p.mass_stride = mass_ptr, 8
+        p.type, p.type_stride = type_ptr, 4
+        if old_acc_ptr:
+            p.old_acc, p.old_acc_stride = old_acc_ptr, 8
+        if active_ptr:
+            p.active, p.active_stride = active_ptr, 1
+        p.on_device = 1
+        self.n = n
+        self._check(lib().ngravs_set_particles(self._h, C.byref(p)), "ngravs_set_particles")
+
+    def set_old_acc(self, old_acc):
+        old_acc = np.ascontiguousarray(old_acc, dtype=np.float64)
+        self._check(lib().ngravs_set_old_acc(self._h, old_acc.ctypes.data, 8, 0), "ngravs_set_old_acc")
+
+    def set_opening(self, theta, err_tol_force_acc):
+        self._check(lib().ngravs_set_opening(self._h, theta, err_tol_force_acc), "ngravs_set_opening")
+        self.cfg.err_tol_theta = theta
+        self.cfg.err_tol_force_acc = err_tol_force_acc
+
+    def set_walk_mode(self, mode):
+        self._check(lib().ngravs_set_walk_mode(self._h, mode), "ngravs_set_walk_mode")
+
+    # -- the reference's entry points (proto.h names) ---------------------------------------------
+    def domain_Decomposition(self):
+        self._check(lib().ngravs_domain_decomposition(self._h), "domain_Decomposition")
+
+    def force_treebuild(self):
+        nn = lib().ngravs_force_treebuild(self._h)
+        if nn < 0:
+            self._check(int(nn), "force_treebuild")
+        return int(nn)
+
+    def gravity_tree(self):
+        self._check(lib().ngravs_gravity_tree(self._h), "gravity_tree")
+
+    def pmforce_periodic(self):
+        self._check(lib().ngravs_pmforce_periodic(self._h), "pmforce_periodic")
+
+    def compute_accelerations(self, pm_step=True):
+        self._check(lib().ngravs_compute_accelerations(self._h, 1 if pm_step else 0), "compute_accelerations")
+
+    # -- results -------------------------------------------------------------------------------------
+    def get_accel(self, want_pm=False):
+        """(GravAccel[N,3], OldAcc[N], GravCost[N]) [+ GravPM[N,3]] in the caller's particle order."""
+        n = self.n
+        acc = np.zeros((n, 3))
+        old = np.zeros(n)
+        cost = np.zeros(n, dtype=np.float32)
+        pm = np.zeros((n, 3)) if want_pm else None
+        self._check(lib().ngravs_get_accel(self._h, acc.ctypes.data, 24, _ptr(pm), 24, old.ctypes.data, 8,
+                                           cost.ctypes.data, 4, 0), "ngravs_get_accel")
+        return (acc, old, cost, pm) if want_pm else (acc, old, cost)
+
+    def get_pm(self):
+        pm = np.zeros((self.n, 3))
+        self._check(lib().ngravs_get_accel(self._h, None, 0, pm.ctypes.data, 24, None, 0, None, 0, 0), "ngravs_get_accel")
+        return pm
+
+    def stats(self):
+        s = Stats()
+        self._check(lib().ngravs_get_stats(self._h, C.byref(s)), "ngravs_get_stats")
+        return s
+
+    def domain(self):
+        d = np.zeros(8)
+        self._check(lib().ngravs_get_domain(self._h, d.ctypes.data), "ngravs_get_domain")
+        return d
+
+    def keys(self):
+        k = np.zeros(self.n, dtype=np.int64)
+        self._check(lib().ngravs_get_keys(self._h, k.ctypes.data, 0), "ngravs_get_keys")
+        return k
+
+    def order(self):
+        o = np.zeros(self.n, dtype=np.int32)
+        self._check(lib().ngravs_get_order(self._h, o.ctypes.data, 0), "ngravs_get_order")
+        return o
+
+    def shard(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(lib().ngravs_get_shard(self._h, C.byref(a), C.byref(b)), "ngravs_get_shard")
+        return int(a.value), int(b.value)
+
+    def peano_keys(self, pos, corner, fac, bits=18):
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        corner = np.ascontiguousarray(corner, dtype=np.float64)
+        out = np.zeros(len(pos), dtype=np.int64)
+        self._check(lib().ngravs_peano_keys(self._h, pos.ctypes.data, len(pos), corner.ctypes.data, float(fac), bits,
+                                            out.ctypes.data), "ngravs_peano_keys")
+        return out
+
+    def direct_sum(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.zeros((len(idx), 3))
+        self._check(lib().ngravs_direct_sum(self._h, idx.ctypes.data, len(idx), out.ctypes.data), "ngravs_direct_sum")
+        return out

@@ -1,0 +1,774 @@
+// capi.hip -- the C ABI of include/ngravs_hip.h: orchestration only, no arithmetic of the path.
+//
+// Mirrors the reference's drivers: gravity_tree (gravtree.c:27-460), long_range_force /
+// pmforce_periodic (longrange.c:56, pm_periodic.c:204), domain_Decomposition (domain.c:62-154),
+// compute_accelerations (accel.c:24-96), init_grav_maps (ngravs_core.c:201-425).
+#include "engine.hpp"
+#include "../../include/ngravs_peano.h"
+#include <chrono>
+#include <cmath>
+
+void ngravs_report(ngravs_ctx *ctx, int code, const std::string &msg)
+{
+  if(ctx)
+    ctx->last_error = msg;
+  if(ctx && ctx->on_fatal)
+    ctx->on_fatal(code, msg.c_str());
+  else
+    fprintf(stderr, "task %d: endrun called with an error level of %d (%s)\n", ctx ? ctx->cfg.rank : 0, code, msg.c_str());
+}
+
+// ---- small device helpers ---------------------------------------------------------------------
+__global__ void k_pack_strided_f64(const unsigned char *src, long long stride, int ncomp, long long n, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const double *s = reinterpret_cast<const double *>(src + i * stride);
+  for(int k = 0; k < ncomp; k++)
+    dst[i * ncomp + k] = s[k];
+}
+__global__ void k_pack_strided_i32(const unsigned char *src, long long stride, long long n, int *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = *reinterpret_cast<const int *>(src + i * stride);
+}
+__global__ void k_pack_strided_u8(const unsigned char *src, long long stride, long long n, unsigned char *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = src[i * stride];
+}
+__global__ void k_fill_f64(double *p, long long n, double v)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    p[i] = v;
+}
+__global__ void k_fill_u8(unsigned char *p, long long n, unsigned char v)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    p[i] = v;
+}
+// Peano order -> caller order
+__global__ void k_unpermute_f64(const unsigned int *idx, long long n, int ncomp, const double *src, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  long long j = idx[i];
+  for(int k = 0; k < ncomp; k++)
+    dst[j * ncomp + k] = src[i * ncomp + k];
+}
+__global__ void k_unpermute_i2f(const unsigned int *idx, long long n, const int *src, float *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[idx[i]] = (float)src[i];
+}
+__global__ void k_permute_f64(const unsigned int *idx, long long n, int ncomp, const double *src, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  long long j = idx[i];
+  for(int k = 0; k < ncomp; k++)
+    dst[i * ncomp + k] = src[j * ncomp + k];
+}
+__global__ void k_key18(const unsigned long long *k21, long long n, long long *out)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = (long long)(k21[i] >> (3 * (TREE_BITS - NGRAVS_BITS_PER_DIMENSION)));
+}
+__global__ void k_inverse_perm(const unsigned int *idx, long long n, int *inv)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    inv[idx[i]] = (int)i;
+}
+__global__ void k_map_idx(const int *inv, const int *in, long long n, int *out)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    out[i] = inv[in[i]];
+}
+__global__ void k_sum_active(const unsigned char *act, const int *nint, long long first, long long count, double *out)
+{
+  double s = 0, a = 0;
+  for(long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < count; k += (long long)gridDim.x * blockDim.x)
+    if(act[first + k])
+      {
+        s += nint[first + k];
+        a += 1;
+      }
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      s += __shfl_down(s, off);
+      a += __shfl_down(a, off);
+    }
+  if((threadIdx.x & 63) == 0)
+    {
+      atomicAdd(&out[0], s);
+      atomicAdd(&out[1], a);
+    }
+}
+
+#define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+// ---- lifecycle --------------------------------------------------------------------------------
+extern "C" int ngravs_abi_version(void) { return NGRAVS_ABI_VERSION; }
+
+extern "C" const char *ngravs_build_info(void)
+{
+  static char buf[512];
+  snprintf(buf, sizeof(buf),
+           "libngravs_hip abi=%d arch=gfx950 N_GRAVS<=%d NTAB=%d TREE_BITS=%d sizeof(config)=%zu sizeof(particles)=%zu "
+           "sizeof(stats)=%zu walks=strict,group laws=none,newtonian,neg_newtonian,yukawa,coloyuk",
+           NGRAVS_ABI_VERSION, NGRAVS_MAX_GRAVS, NGRAVS_NTAB, NGRAVS_TREE_BITS, sizeof(ngravs_config_t),
+           sizeof(ngravs_particles_t), sizeof(ngravs_stats_t));
+  return buf;
+}
+
+extern "C" void ngravs_config_default(ngravs_config_t *cfg)
+{
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->abi_version = NGRAVS_ABI_VERSION;
+  cfg->n_gravs = 1;
+  cfg->G = 1.0;
+  cfg->err_tol_theta = 0.5;
+  cfg->err_tol_force_acc = 0.005;
+  cfg->yukawa_imass = 60.0;
+  cfg->tree_alloc_factor = 0.8;
+  cfg->world_size = 1;
+  for(int i = 0; i < NGRAVS_MAX_GRAVS; i++)
+    for(int j = 0; j < NGRAVS_MAX_GRAVS; j++)
+      {
+        cfg->law_accel[i][j] = cfg->law_greens[i][j] = cfg->law_normed[i][j] = NGRAVS_LAW_NEWTON;
+        cfg->law_spline[i][j] = NGRAVS_SPLINE_PLUMMER;
+      }
+}
+
+// the sanity checks of init_grav_maps (ngravs_core.c:235-261, 321-424)
+static int check_config(const ngravs_config_t *cfg, std::string &why)
+{
+  if(cfg->abi_version != NGRAVS_ABI_VERSION)
+    {
+      why = "abi_version mismatch";
+      return NGRAVS_ERR_ARG;
+    }
+  if(cfg->n_gravs < 1 || cfg->n_gravs > NGRAVS_MAX_GRAVS)
+    {
+      why = "n_gravs out of range";
+      return NGRAVS_ERR_ARG;
+    }
+  if(cfg->pmgrid && !cfg->periodic)
+    {
+      why = "non-periodic PM is disabled by ngravs itself (ngravs_core.c:235-242)";
+      return NGRAVS_ERR_ARG;
+    }
+  if((cfg->periodic || cfg->pmgrid) && !(cfg->box_size > 0))
+    {
+      why = "box_size must be > 0";
+      return NGRAVS_ERR_ARG;
+    }
+  if(cfg->pmgrid && cfg->type_to_grav[0] != 0)
+    {
+      why = "gas must be gravitational species 0 with PMGRID (ngravs_core.c:255-261)";
+      return NGRAVS_ERR_WIRING;
+    }
+  if(cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size)
+    {
+      why = "rank/world_size";
+      return NGRAVS_ERR_ARG;
+    }
+  for(int t = 0; t < NGRAVS_NTYPES; t++)
+    if(cfg->type_to_grav[t] < 0 || cfg->type_to_grav[t] >= cfg->n_gravs)
+      {
+        why = "TypeToGrav entry outside [0,N_GRAVS)";
+        return NGRAVS_ERR_WIRING;
+      }
+  for(int i = 0; i < cfg->n_gravs; i++)
+    for(int j = 0; j < cfg->n_gravs; j++)
+      {
+        if(cfg->law_accel[i][j] < 0 || cfg->law_accel[i][j] >= NGRAVS_LAW_COUNT || cfg->law_spline[i][j] < 0 ||
+           cfg->law_spline[i][j] >= NGRAVS_SPLINE_COUNT || cfg->law_greens[i][j] < 0 ||
+           cfg->law_greens[i][j] >= NGRAVS_LAW_COUNT || cfg->law_normed[i][j] < 0 || cfg->law_normed[i][j] >= NGRAVS_LAW_COUNT)
+          {
+            why = "force-law table slot not wired (ngravs_core.c:321-360)";
+            return NGRAVS_ERR_WIRING;
+          }
+        // Newton's third law probe F[i][j](1,1,0.5,3,1) == F[j][i](...) (ngravs_core.c:371-403)
+        if(cfg->law_accel[i][j] != cfg->law_accel[j][i] || cfg->law_spline[i][j] != cfg->law_spline[j][i])
+          {
+            why = "force-law table violates Newton's third law (ngravs_core.c:371-403)";
+            return NGRAVS_ERR_WIRING;
+          }
+      }
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_create(const ngravs_config_t *cfg, ngravs_ctx **out)
+{
+  if(!cfg || !out)
+    return NGRAVS_ERR_ARG;
+  *out = nullptr;
+  std::string why;
+  int rc = check_config(cfg, why);
+  if(rc != NGRAVS_OK)
+    {
+      ngravs_report(nullptr, rc, why);
+      return rc;
+    }
+  int ndev = 0;
+  if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+      ngravs_report(nullptr, NGRAVS_ERR_NO_DEVICE, "no HIP device: libngravs_hip has no CPU fallback");
+      return NGRAVS_ERR_NO_DEVICE;
+    }
+  if(cfg->device < 0 || cfg->device >= ndev)
+    return NGRAVS_ERR_ARG;
+  ngravs_ctx *c = new ngravs_ctx;
+  c->cfg = *cfg;
+  memset(&c->stats, 0, sizeof(c->stats));
+  if(hipSetDevice(cfg->device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+     hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+     hipEventCreate(&c->evk0) != hipSuccess || hipEventCreate(&c->evk1) != hipSuccess)
+    {
+      delete c;
+      return NGRAVS_ERR_NO_DEVICE;
+    }
+  if(cfg->pmgrid)
+    {
+      c->asmth = cfg_asmth(cfg);
+      c->rcut = cfg_rcut(cfg);
+    }
+  *out = c;
+  return NGRAVS_OK;
+}
+
+extern "C" void ngravs_destroy(ngravs_ctx *c)
+{
+  if(!c)
+    return;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipStreamSynchronize(c->stream);
+  pm_release(c);
+  c->in_pos.release();
+  c->in_mass.release();
+  c->in_oldacc.release();
+  c->in_type.release();
+  c->in_active.release();
+  c->in_key.release();
+  c->s_pm.release();
+  c->s_type.release();
+  c->s_active.release();
+  c->s_oldacc.release();
+  c->s_key.release();
+  c->s_idx.release();
+  c->idx_iota.release();
+  c->sort_tmp.release();
+  c->red_tmp.release();
+  c->n_first.release();
+  c->n_count.release();
+  c->n_child.release();
+  c->n_flags.release();
+  c->n_nchild.release();
+  c->n_level.release();
+  c->n_geo.release();
+  c->n_mom.release();
+  c->scan_out.release();
+  c->scan_tmp.release();
+  c->d_counters.release();
+  c->table.release();
+  c->walk_stack.release();
+  c->r_acc.release();
+  c->r_pm.release();
+  c->r_oldacc.release();
+  c->r_nint.release();
+  c->pm_rho.release();
+  c->pm_phi.release();
+  c->pm_orig.release();
+  c->out_tmp.release();
+  c->out_tmpf.release();
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipEventDestroy(c->evk0);
+  (void)hipEventDestroy(c->evk1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" void ngravs_set_fatal_handler(ngravs_ctx *ctx, ngravs_fatal_fn fn)
+{
+  if(ctx)
+    ctx->on_fatal = fn;
+}
+
+extern "C" int ngravs_set_opening(ngravs_ctx *c, double theta, double errtol)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  c->cfg.err_tol_theta = theta;
+  c->cfg.err_tol_force_acc = errtol;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_set_walk_mode(ngravs_ctx *c, int mode)
+{
+  if(!c || (mode != NGRAVS_WALK_STRICT && mode != NGRAVS_WALK_GROUP))
+    return NGRAVS_ERR_ARG;
+  c->cfg.walk_mode = mode;
+  return NGRAVS_OK;
+}
+
+// ---- data hand-over -----------------------------------------------------------------------------
+static int upload_column_f64(ngravs_ctx *c, const void *src, int64_t stride, int ncomp, int64_t n, int on_device, double *dst)
+{
+  if(on_device)
+    {
+      if(stride == (int64_t)sizeof(double) * ncomp)
+        HIP_TRY(c, hipMemcpyAsync(dst, src, sizeof(double) * ncomp * n, hipMemcpyDeviceToDevice, c->stream));
+      else
+        hipLaunchKernelGGL(k_pack_strided_f64, GRID1(n), 0, c->stream, (const unsigned char *)src, (long long)stride, ncomp,
+                           (long long)n, dst);
+      return NGRAVS_OK;
+    }
+  if(stride == (int64_t)sizeof(double) * ncomp)
+    {
+      HIP_TRY(c, hipMemcpyAsync(dst, src, sizeof(double) * ncomp * n, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return NGRAVS_OK;
+    }
+  c->host_stage.resize(sizeof(double) * ncomp * (size_t)n);
+  double *h = reinterpret_cast<double *>(c->host_stage.data());
+  for(int64_t i = 0; i < n; i++)
+    memcpy(h + i * ncomp, (const unsigned char *)src + i * stride, sizeof(double) * ncomp);
+  HIP_TRY(c, hipMemcpyAsync(dst, h, sizeof(double) * ncomp * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p)
+{
+  if(!c || !p || p->n <= 0 || !p->pos || !p->mass || !p->type)
+    return NGRAVS_ERR_ARG;
+  if(p->n >= (1ll << 31) - 64)
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "int particle indices (reference All.MaxPart is int): n must be < 2^31");
+      return NGRAVS_ERR_ARG;
+    }
+  (void)hipSetDevice(c->cfg.device);
+  const int64_t n = p->n;
+  if(c->in_pos.ensure(3 * n) || c->in_mass.ensure(n) || c->in_oldacc.ensure(n) || c->in_type.ensure(n) || c->in_active.ensure(n))
+    {
+      ngravs_report(c, NGRAVS_ERR_NOMEM, "device allocation failed");
+      return NGRAVS_ERR_NOMEM;
+    }
+  c->n = n;
+  int rc;
+  if((rc = upload_column_f64(c, p->pos, p->pos_stride, 3, n, p->on_device, c->in_pos.p)))
+    return rc;
+  if((rc = upload_column_f64(c, p->mass, p->mass_stride, 1, n, p->on_device, c->in_mass.p)))
+    return rc;
+  if(p->old_acc)
+    {
+      if((rc = upload_column_f64(c, p->old_acc, p->old_acc_stride, 1, n, p->on_device, c->in_oldacc.p)))
+        return rc;
+    }
+  else
+    hipLaunchKernelGGL(k_fill_f64, GRID1(n), 0, c->stream, c->in_oldacc.p, (long long)n, 0.0);
+  // Type (int32)
+  if(p->on_device)
+    hipLaunchKernelGGL(k_pack_strided_i32, GRID1(n), 0, c->stream, (const unsigned char *)p->type, (long long)p->type_stride,
+                       (long long)n, c->in_type.p);
+  else
+    {
+      c->host_stage.resize(sizeof(int) * (size_t)n);
+      int *h = reinterpret_cast<int *>(c->host_stage.data());
+      for(int64_t i = 0; i < n; i++)
+        {
+          memcpy(h + i, (const unsigned char *)p->type + i * p->type_stride, sizeof(int));
+          if(h[i] < 0 || h[i] >= NGRAVS_NTYPES)
+            {
+              ngravs_report(c, NGRAVS_ERR_ARG, "particle Type outside 0..5");
+              return NGRAVS_ERR_ARG;
+            }
+        }
+      HIP_TRY(c, hipMemcpyAsync(c->in_type.p, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  if(p->active)
+    {
+      if(p->on_device)
+        hipLaunchKernelGGL(k_pack_strided_u8, GRID1(n), 0, c->stream, (const unsigned char *)p->active,
+                           (long long)p->active_stride, (long long)n, c->in_active.p);
+      else
+        {
+          c->host_stage.resize((size_t)n);
+          for(int64_t i = 0; i < n; i++)
+            c->host_stage[i] = ((const unsigned char *)p->active)[i * p->active_stride] ? 1 : 0;
+          HIP_TRY(c, hipMemcpyAsync(c->in_active.p, c->host_stage.data(), (size_t)n, hipMemcpyHostToDevice, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
+  else
+    hipLaunchKernelGGL(k_fill_u8, GRID1(n), 0, c->stream, c->in_active.p, (long long)n, (unsigned char)1);
+  HIP_TRY(c, hipGetLastError());
+  c->have_particles = true;
+  c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_set_old_acc(ngravs_ctx *c, const double *old_acc, int64_t stride, int on_device)
+{
+  if(!c || !c->have_particles || !old_acc)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = upload_column_f64(c, old_acc, stride, 1, c->n, on_device, c->in_oldacc.p);
+  if(rc)
+    return rc;
+  if(c->have_order)
+    hipLaunchKernelGGL(k_permute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 1, c->in_oldacc.p, c->s_oldacc.p);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+// ---- the path -------------------------------------------------------------------------------------
+static double ev_ms(ngravs_ctx *c)
+{
+  float ms = 0;
+  (void)hipEventSynchronize(c->ev1);
+  (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  return ms;
+}
+
+extern "C" int ngravs_domain_decomposition(ngravs_ctx *c)
+{
+  if(!c || !c->have_particles)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  int rc = dom_find_extent(c);
+  if(rc)
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_domain = ev_ms(c) * 1e-3;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  rc = dom_keys_and_sort(c);
+  if(rc)
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_peano = ev_ms(c) * 1e-3;
+  // target shard of this rank: a contiguous segment of the Peano order (domain.c:347-456 cuts the
+  // curve into NTask segments; here by particle count)
+  int64_t ws = c->cfg.world_size, r = c->cfg.rank;
+  int64_t lo = (c->n * r) / ws, hi = (c->n * (r + 1)) / ws;
+  lo = (lo / 64) * 64;                       // wave-aligned cuts keep groups identical across world sizes
+  hi = (r + 1 == ws) ? c->n : (hi / 64) * 64;
+  c->shard_first = lo;
+  c->shard_count = hi - lo;
+  c->have_order = true;
+  c->have_tree = false;   // TreeReconstructFlag = 1 (domain.c:84)
+  // P[].GravPM survives between PM steps (it is only rewritten by pmforce_periodic): carry it into the new order
+  if(c->have_pm)
+    {
+      if(c->r_pm.ensure(3 * c->n))
+        return NGRAVS_ERR_NOMEM;
+      hipLaunchKernelGGL(k_permute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->pm_orig.p, c->r_pm.p);
+      HIP_TRY(c, hipGetLastError());
+    }
+  return NGRAVS_OK;
+}
+
+extern "C" int64_t ngravs_force_treebuild(ngravs_ctx *c)
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  if(hipEventRecord(c->ev0, c->stream) != hipSuccess)
+    return NGRAVS_ERR_NO_DEVICE;
+  int rc = tree_build(c);
+  if(rc)
+    return rc;
+  if(hipEventRecord(c->ev1, c->stream) != hipSuccess)
+    return NGRAVS_ERR_NO_DEVICE;
+  c->stats.t_treebuild = ev_ms(c) * 1e-3;
+  c->have_tree = true;
+  return c->nnodes;
+}
+
+static int ensure_table(ngravs_ctx *c)
+{
+  if(!c->cfg.pmgrid || c->table_ready)
+    return NGRAVS_OK;
+  const int ng = c->cfg.n_gravs;
+  std::vector<double> h((size_t)ng * ng * NTAB);
+  host_shortrange_table(&c->cfg, h.data(), nullptr);
+  if(c->table.ensure(h.size()))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(c->table.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->table_ready = true;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  int rc;
+  if(!c->have_tree)   // gravtree.c:56-67
+    {
+      int64_t nn = ngravs_force_treebuild(c);
+      if(nn < 0)
+        return (int)nn;
+    }
+  if((rc = ensure_table(c)))
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  if((rc = walk_run(c)))
+    return rc;
+  if((rc = walk_finish(c)))
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_treewalk = ev_ms(c) * 1e-3;
+  float kms = 0;
+  (void)hipEventSynchronize(c->evk1);
+  (void)hipEventElapsedTime(&kms, c->evk0, c->evk1);
+  c->stats.walk_kernel_ms = kms;
+  // Nf and interaction sum (gravtree.c:74-78, 408-447)
+  if(c->red_tmp.ensure(2))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->red_tmp.p, 0, 2 * sizeof(double), c->stream));
+  hipLaunchKernelGGL(k_sum_active, dim3(512), dim3(256), 0, c->stream, c->s_active.p, c->r_nint.p, (long long)c->shard_first,
+                     (long long)c->shard_count, c->red_tmp.p);
+  double h[2] = {0, 0};
+  HIP_TRY(c, hipMemcpyAsync(h, c->red_tmp.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stats.interactions = h[0];
+  c->stats.n_active = (int64_t)h[1];
+  c->have_acc = true;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_pmforce_periodic(ngravs_ctx *c)
+{
+  if(!c || !c->have_particles)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  int rc;
+  if(!c->have_order && (rc = ngravs_domain_decomposition(c)))   // domain.c:66-73: PM steps always re-decompose
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  if((rc = pm_run(c)))
+    return rc;
+  if(c->pm_orig.ensure(3 * c->n))
+    return NGRAVS_ERR_NOMEM;
+  hipLaunchKernelGGL(k_unpermute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->r_pm.p, c->pm_orig.p);
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_pm = ev_ms(c) * 1e-3;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_compute_accelerations(ngravs_ctx *c, int pm_step)
+{
+  if(!c || !c->have_particles)
+    return NGRAVS_ERR_STATE;
+  int rc;
+  if((rc = ngravs_domain_decomposition(c)))
+    return rc;
+  if(pm_step && c->cfg.pmgrid && (rc = ngravs_pmforce_periodic(c)))   // accel.c:34-42
+    return rc;
+  return ngravs_gravity_tree(c);                                        // accel.c:46
+}
+
+// ---- results ----------------------------------------------------------------------------------------
+static int download_strided(ngravs_ctx *c, const void *dsrc, size_t elem, int ncomp, int64_t n, void *dst, int64_t stride,
+                            int on_device)
+{
+  const size_t row = elem * ncomp;
+  if(on_device)
+    {
+      if((size_t)stride != row)
+        {
+          ngravs_report(c, NGRAVS_ERR_ARG, "device outputs must be contiguous");
+          return NGRAVS_ERR_ARG;
+        }
+      HIP_TRY(c, hipMemcpyAsync(dst, dsrc, row * n, hipMemcpyDeviceToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return NGRAVS_OK;
+    }
+  if((size_t)stride == row)
+    {
+      HIP_TRY(c, hipMemcpyAsync(dst, dsrc, row * n, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return NGRAVS_OK;
+    }
+  c->host_stage.resize(row * (size_t)n);
+  HIP_TRY(c, hipMemcpyAsync(c->host_stage.data(), dsrc, row * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for(int64_t i = 0; i < n; i++)
+    memcpy((unsigned char *)dst + i * stride, c->host_stage.data() + i * row, row);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel_stride, double *grav_pm, int64_t pm_stride,
+                                double *old_acc, int64_t old_acc_stride, float *grav_cost, int64_t cost_stride, int on_device)
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  const int64_t n = c->n;
+  if(c->out_tmp.ensure(3 * n) || c->out_tmpf.ensure(n))
+    return NGRAVS_ERR_NOMEM;
+  int rc;
+  if(grav_accel)
+    {
+      if(!c->have_acc)
+        return NGRAVS_ERR_STATE;
+      HIP_TRY(c, hipMemsetAsync(c->out_tmp.p, 0, sizeof(double) * 3 * n, c->stream));
+      hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_acc.p, c->out_tmp.p);
+      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 3, n, grav_accel, accel_stride, on_device)))
+        return rc;
+    }
+  if(grav_pm)
+    {
+      if(!c->have_pm)
+        return NGRAVS_ERR_STATE;
+      hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_pm.p, c->out_tmp.p);
+      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 3, n, grav_pm, pm_stride, on_device)))
+        return rc;
+    }
+  if(old_acc)
+    {
+      if(!c->have_acc)
+        return NGRAVS_ERR_STATE;
+      HIP_TRY(c, hipMemsetAsync(c->out_tmp.p, 0, sizeof(double) * n, c->stream));
+      hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 1, c->r_oldacc.p, c->out_tmp.p);
+      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 1, n, old_acc, old_acc_stride, on_device)))
+        return rc;
+    }
+  if(grav_cost)
+    {
+      if(!c->have_acc)
+        return NGRAVS_ERR_STATE;
+      hipLaunchKernelGGL(k_unpermute_i2f, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, c->r_nint.p, c->out_tmpf.p);
+      if((rc = download_strided(c, c->out_tmpf.p, sizeof(float), 1, n, grav_cost, cost_stride, on_device)))
+        return rc;
+    }
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_get_stats(ngravs_ctx *c, ngravs_stats_t *out)
+{
+  if(!c || !out)
+    return NGRAVS_ERR_ARG;
+  *out = c->stats;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_get_domain(ngravs_ctx *c, double out[8])
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  memcpy(out, c->dom, sizeof(double) * 8);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_get_keys(ngravs_ctx *c, int64_t *keys, int on_device)
+{
+  if(!c || !c->have_order || !keys)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  const int64_t n = c->n;
+  if(c->out_tmp.ensure(3 * n))
+    return NGRAVS_ERR_NOMEM;
+  long long *tmp = reinterpret_cast<long long *>(c->out_tmp.p);
+  hipLaunchKernelGGL(k_key18, GRID1(n), 0, c->stream, c->in_key.p, (long long)n, tmp);
+  return download_strided(c, tmp, sizeof(long long), 1, n, keys, sizeof(long long), on_device);
+}
+
+extern "C" int ngravs_get_order(ngravs_ctx *c, int32_t *order, int on_device)
+{
+  if(!c || !c->have_order || !order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return download_strided(c, c->s_idx.p, sizeof(int), 1, c->n, order, sizeof(int), on_device);
+}
+
+extern "C" int ngravs_get_shard(ngravs_ctx *c, int64_t *first, int64_t *count)
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  if(first)
+    *first = c->shard_first;
+  if(count)
+    *count = c->shard_count;
+  return NGRAVS_OK;
+}
+
+extern "C" const char *ngravs_last_error(ngravs_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+// ---- stand-alone pieces -------------------------------------------------------------------------------
+extern "C" int64_t ngravs_peano_hilbert_key(int x, int y, int z, int bits) { return ngravs_ph_key(x, y, z, bits); }
+
+extern "C" int ngravs_peano_keys(ngravs_ctx *c, const double *pos, int64_t n, const double corner[3], double fac, int bits,
+                                 int64_t *keys)
+{
+  if(!c || !pos || !keys || n <= 0 || bits < 1 || bits > 21)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  DevBuf<double> dpos;
+  DevBuf<long long> dkeys;
+  if(dpos.ensure(3 * n) || dkeys.ensure(n))
+    return NGRAVS_ERR_NOMEM;
+  int rc = NGRAVS_OK;
+  if(hipMemcpyAsync(dpos.p, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  if(!rc)
+    rc = dom_keys_only(c, dpos.p, n, corner, fac, bits, dkeys.p);
+  if(!rc && hipMemcpyAsync(keys, dkeys.p, sizeof(long long) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  (void)hipStreamSynchronize(c->stream);
+  dpos.release();
+  dkeys.release();
+  return rc;
+}
+
+extern "C" int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, double *pot_out)
+{
+  if(!cfg || !force_out || cfg->n_gravs < 1 || cfg->n_gravs > NGRAVS_MAX_GRAVS)
+    return NGRAVS_ERR_ARG;
+  host_shortrange_table(cfg, force_out, pot_out);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_direct_sum(ngravs_ctx *c, const int32_t *idx, int64_t nt, double *acc)
+{
+  if(!c || !c->have_order || !idx || !acc || nt <= 0)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  DevBuf<int> inv, din, dout;
+  DevBuf<double> dacc;
+  if(inv.ensure(c->n) || din.ensure(nt) || dout.ensure(nt) || dacc.ensure(3 * nt))
+    return NGRAVS_ERR_NOMEM;
+  int rc = NGRAVS_OK;
+  hipLaunchKernelGGL(k_inverse_perm, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, inv.p);
+  if(hipMemcpyAsync(din.p, idx, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  hipLaunchKernelGGL(k_map_idx, GRID1(nt), 0, c->stream, inv.p, din.p, (long long)nt, dout.p);
+  if(!rc)
+    rc = direct_run(c, dout.p, nt, dacc.p);
+  if(!rc && hipMemcpyAsync(acc, dacc.p, sizeof(double) * 3 * nt, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  (void)hipStreamSynchronize(c->stream);
+  inv.release();
+  din.release();
+  dout.release();
+  dacc.release();
+  return rc;
+}

@@ -1,0 +1,164 @@
+// engine.hpp -- internal state of libngravs_hip.so (not part of the C ABI).
+//
+// Data layout in HBM (all SoA, fp64 as the reference's -DDOUBLEPRECISION build):
+//   input columns, caller's order : in_pos[3n] in_mass[n] in_type[n] in_oldacc[n] in_active[n]
+//   Peano-sorted particle columns : s_pm[n] = double4{x,y,z,mass}  s_type[n] u8  s_oldacc[n]
+//                                   s_active[n] u8  s_key[n] u64 (21 bits/dim)  s_idx[n] u32
+//   tree (breadth-first, level-contiguous): n_first/n_count (particle range), n_child[8*nodes]
+//       (>=0 node, -1 empty, <=-2 particle -2-p), n_geo = double4{cx,cy,cz,len},
+//       n_mom[nodes*NG] = double4{sx,sy,sz,mass}, n_flags (reference bitflags bits 2-5), n_level
+//   results, Peano order          : r_acc[3n] r_nint[n] r_pm[3n] r_oldacc[n]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/ngravs_hip.h"
+
+#define NG_MAX NGRAVS_MAX_GRAVS
+#define NTAB NGRAVS_NTAB
+#define TREE_BITS NGRAVS_TREE_BITS
+#define MAX_LEVELS (TREE_BITS + 1)
+
+struct ngravs_ctx;
+
+#define HIP_TRY(ctx, expr)                                                                        \
+  do                                                                                              \
+    {                                                                                             \
+      hipError_t e__ = (expr);                                                                    \
+      if(e__ != hipSuccess)                                                                       \
+        {                                                                                         \
+          ngravs_report(ctx, NGRAVS_ERR_NO_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+          return NGRAVS_ERR_NO_DEVICE;                                                            \
+        }                                                                                         \
+    }                                                                                             \
+  while(0)
+
+void ngravs_report(ngravs_ctx *ctx, int code, const std::string &msg);
+
+template <typename T> struct DevBuf
+{
+  T *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n)
+  {
+    if(n <= cap)
+      return 0;
+    if(p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 16 + 64;
+    if(hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess)
+      return -1;
+    cap = want;
+    return 0;
+  }
+  void release()
+  {
+    if(p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// constants every kernel needs, passed by value (fits kernarg / SGPRs)
+struct WalkParams
+{
+  int ng, periodic, pm, use_theta;
+  double box, boxhalf;
+  double theta2;            // ErrTolTheta^2
+  double errtol_acc;        // ErrTolForceAcc
+  double rcut, rcut2, asmthfac, utor2wpi, reach2;   // TreePM constants (forcetree.c:1708-1711)
+  double ym;                // YUKAWA_IMASS / BoxSize (ngravs.c:859)
+  double fsoft[NGRAVS_NTYPES];
+  int t2g[NGRAVS_NTYPES];
+  // law coefficients [target][source]: accel = m*(cN/r2 + cY*exp(-r ym)(ym/r + 1/r2)); spline = cS*plummer
+  double cN[NG_MAX][NG_MAX], cY[NG_MAX][NG_MAX], cS[NG_MAX][NG_MAX];
+};
+
+struct TreeView
+{
+  const int *first, *count, *child, *flags;
+  const double4 *geo, *mom;
+  int nnodes;
+};
+
+struct ngravs_ctx
+{
+  ngravs_config_t cfg;
+  ngravs_fatal_fn on_fatal = nullptr;
+  hipStream_t stream = nullptr;
+  double asmth = 0, rcut = 0;
+  int64_t n = 0;
+  bool have_particles = false, have_order = false, have_tree = false, have_pm = false, have_acc = false;
+  double dom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t shard_first = 0, shard_count = 0;
+
+  // inputs (caller order)
+  DevBuf<double> in_pos, in_mass, in_oldacc;
+  DevBuf<int> in_type;
+  DevBuf<unsigned char> in_active;
+  DevBuf<unsigned long long> in_key;
+  // sorted
+  DevBuf<double4> s_pm;
+  DevBuf<unsigned char> s_type, s_active;
+  DevBuf<double> s_oldacc;
+  DevBuf<unsigned long long> s_key;
+  DevBuf<unsigned int> s_idx, idx_iota;
+  DevBuf<unsigned char> sort_tmp;
+  DevBuf<double> red_tmp;
+  // tree
+  int64_t max_nodes = 0, nnodes = 0;
+  int nlevels = 0;
+  int64_t level_start[MAX_LEVELS + 2];
+  DevBuf<int> n_first, n_count, n_child, n_flags, n_nchild;
+  DevBuf<unsigned char> n_level;
+  DevBuf<double4> n_geo, n_mom;
+  DevBuf<int> scan_out;
+  DevBuf<unsigned char> scan_tmp;
+  DevBuf<int> d_counters;
+  // walk
+  DevBuf<double> table;       // [ng][ng][NTAB] shortrange_fourier_force
+  bool table_ready = false;
+  DevBuf<int> walk_stack;     // per-wave scratch
+  DevBuf<double> r_acc, r_pm, r_oldacc;
+  DevBuf<int> r_nint;
+  // pm
+  int pm_plan_n = 0;
+  void *fft_fwd = nullptr, *fft_inv = nullptr;   // hipfftHandle (int) boxed
+  DevBuf<double> pm_rho;      // [ng][N][N][N+2] real / complex in place
+  DevBuf<double> pm_phi;      // [ng][N][N][N+2]
+  DevBuf<double> pm_orig;     // GravPM in caller order (persists between PM steps)
+  // staging for results
+  DevBuf<double> out_tmp;
+  DevBuf<float> out_tmpf;
+  std::vector<unsigned char> host_stage;
+  ngravs_stats_t stats;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+  std::string last_error;
+};
+
+// ---- kernels_domain.hip
+int dom_find_extent(ngravs_ctx *c);
+int dom_keys_and_sort(ngravs_ctx *c);
+int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double corner[3], double fac, int bits,
+                  long long *d_keys);
+// ---- kernels_tree.hip
+int tree_build(ngravs_ctx *c);
+// ---- kernels_walk.hip
+void make_walk_params(const ngravs_ctx *c, WalkParams *wp);
+int walk_run(ngravs_ctx *c);
+int walk_finish(ngravs_ctx *c);
+int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc);
+// ---- kernels_pm.hip
+int pm_run(ngravs_ctx *c);
+void pm_release(ngravs_ctx *c);
+// ---- shortrange_table.cpp
+void host_shortrange_table(const ngravs_config_t *cfg, double *force, double *pot);
+double cfg_asmth(const ngravs_config_t *c);
+double cfg_rcut(const ngravs_config_t *c);

@@ -1,0 +1,259 @@
+// kernels_pm.hip -- long-range periodic particle-mesh force.
+//
+// Replaces (reference): pmforce_periodic (pm_periodic.c:204-790).  The reference runs, for every
+// (source, target) species pair, CIC deposit -> forward FFT -> Green multiply -> inverse FFT ->
+// three finite-difference sweeps -> CIC gather: 2*N_GRAVS^2 transforms and 3*N_GRAVS^2 mesh sweeps.
+// Here: deposit + forward rocFFT once per SOURCE species, one fused k-space kernel that forms, per
+// TARGET species b,  phi_b(k) = sum_a G_ab(k) rho_a(k) * (-exp(-k^2 asmth2)) / sinc^4  (linear, so
+// identical to summing the reference's per-pair potentials), inverse rocFFT once per target species,
+// and one fused kernel per target species that takes the 4-point gradient at the 8 CIC corners on
+// the fly and gathers GravPM: 2*N_GRAVS transforms, no force mesh at all.
+//
+// Mesh layout: real [N][N][N+2] fp64 (in-place r2c padding), complex [N][N][N/2+1].  rocFFT is an
+// unnormalised DFT with forward sign -1, like FFTW-2.
+#include "engine.hpp"
+#include <hipfft/hipfft.h>
+
+__device__ __forceinline__ int cell_of(double x, double to_slab, int N, double *frac)
+{
+  int s = (int)(to_slab * x);                                         // pm_periodic.c:299-301
+  if(s >= N)
+    s = N - 1;
+  *frac = to_slab * x - s;
+  return s;
+}
+
+__global__ void k_cic_deposit(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, long long n,
+                              double to_slab, int N, int ng, const int *__restrict__ t2g_tab, double *__restrict__ rho)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  double4 p = s_pm[i];
+  int g = t2g_tab[s_type[i]];
+  const long long NZ = N + 2;
+  double *grid = rho + (size_t)g * N * N * NZ;
+  double dx, dy, dz;
+  int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+  int sxx = sx + 1 == N ? 0 : sx + 1, syy = sy + 1 == N ? 0 : sy + 1, szz = sz + 1 == N ? 0 : sz + 1;
+  double m = p.w;
+  // pm_periodic.c:322-329 (same weights, same products)
+  atomicAdd(&grid[((long long)sx * N + sy) * NZ + sz], m * (1.0 - dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[((long long)sx * N + syy) * NZ + sz], m * (1.0 - dx) * dy * (1.0 - dz));
+  atomicAdd(&grid[((long long)sx * N + sy) * NZ + szz], m * (1.0 - dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[((long long)sx * N + syy) * NZ + szz], m * (1.0 - dx) * dy * dz);
+  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + sz], m * (dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + sz], m * (dx)*dy * (1.0 - dz));
+  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + szz], m * (dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + szz], m * (dx)*dy * dz);
+}
+
+struct GreenParams
+{
+  int ng, N;
+  double asmth2;       // (2 pi asmth / L)^2                                     pm_periodic.c:234-235
+  double ym2;          // (YUKAWA_IMASS / 2 pi)^2                                 ngravs.c:871
+  double yfac;         // exp(-ym^2 asmth2)                                       ngravs.c:877
+  double cN[NG_MAX][NG_MAX], cY[NG_MAX][NG_MAX];   // [source][target], as pm_periodic.c:490 indexes GreensFxns
+};
+
+// one thread per complex mode; rho[a] complex in, phi[b] complex out
+template <int NG>
+__global__ void k_green(const double2 *__restrict__ rho, double2 *__restrict__ phi, GreenParams gp)
+{
+  const int N = gp.N, NH = N / 2 + 1;
+  long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long total = (long long)N * N * NH;
+  if(idx >= total)
+    return;
+  int z = (int)(idx % NH);
+  int y = (int)((idx / NH) % N);
+  int x = (int)(idx / ((long long)NH * N));
+  double kx = x > N / 2 ? x - N : x, ky = y > N / 2 ? y - N : y, kz = z;   // pm_periodic.c:440-451
+  double k2 = kx * kx + ky * ky + kz * kz;
+  double2 out[NG];
+#pragma unroll
+  for(int b = 0; b < NG; b++)
+    out[b].x = out[b].y = 0;
+  if(k2 > 0)
+    {
+      double fx = 1, fy = 1, fz = 1;
+      if(kx != 0)
+        {
+          fx = (M_PI * kx) / N;
+          fx = sin(fx) / fx;
+        }
+      if(ky != 0)
+        {
+          fy = (M_PI * ky) / N;
+          fy = sin(fy) / fy;
+        }
+      if(kz != 0)
+        {
+          fz = (M_PI * kz) / N;
+          fz = sin(fz) / fz;
+        }
+      double ff = 1 / (fx * fy * fz);
+      double common = -exp(-k2 * gp.asmth2) * ff * ff * ff * ff;       // pm_periodic.c:491
+      double gN = 1.0 / k2, gY = 1.0 / (k2 + gp.ym2) * gp.yfac;         // pgdelta / pgyukawa
+#pragma unroll
+      for(int a = 0; a < NG; a++)
+        {
+          double2 r = rho[(size_t)a * total + idx];
+#pragma unroll
+          for(int b = 0; b < NG; b++)
+            {
+              double smth = (gp.cN[a][b] * gN + gp.cY[a][b] * gY) * common;
+              out[b].x += r.x * smth;
+              out[b].y += r.y * smth;
+            }
+        }
+    }
+#pragma unroll
+  for(int b = 0; b < NG; b++)
+    phi[(size_t)b * total + idx] = out[b];                             // k = 0 -> 0 (pm_periodic.c:519-520)
+}
+
+// fused 4-point gradient at the 8 CIC corners + CIC gather (pm_periodic.c:681-763)
+__global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                  long long n, double to_slab, int N, const int *__restrict__ t2g_tab,
+                                  const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  double4 p = s_pm[i];
+  int g = t2g_tab[s_type[i]];
+  const long long NZ = N + 2;
+  const double *grid = phi + (size_t)g * N * N * NZ;
+  double dx, dy, dz;
+  int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+  double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+  double acc[3] = {0, 0, 0};
+  auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
+  auto at = [&](int x, int y, int z) { return grid[((long long)x * N + y) * NZ + z]; };
+  // corner order of the reference's gather (x outer, then y/z as written at pm_periodic.c:749-757)
+  const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+  for(int c = 0; c < 8; c++)
+    {
+      int x = wrap(sx + ox[c]), y = wrap(sy + oy[c]), z = wrap(sz + oz[c]);
+      double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
+      double fxv = fac * ((4.0 / 3) * (at(wrap(x - 1), y, z) - at(wrap(x + 1), y, z)) -
+                          (1.0 / 6) * (at(wrap(x - 2), y, z) - at(wrap(x + 2), y, z)));
+      double fyv = fac * ((4.0 / 3) * (at(x, wrap(y - 1), z) - at(x, wrap(y + 1), z)) -
+                          (1.0 / 6) * (at(x, wrap(y - 2), z) - at(x, wrap(y + 2), z)));
+      double fzv = fac * ((4.0 / 3) * (at(x, y, wrap(z - 1)) - at(x, y, wrap(z + 1))) -
+                          (1.0 / 6) * (at(x, y, wrap(z - 2)) - at(x, y, wrap(z + 2))));
+      acc[0] += fxv * w;
+      acc[1] += fyv * w;
+      acc[2] += fzv * w;
+    }
+  r_pm[3 * i + 0] = acc[0];
+  r_pm[3 * i + 1] = acc[1];
+  r_pm[3 * i + 2] = acc[2];
+}
+
+void pm_release(ngravs_ctx *c)
+{
+  if(c->fft_fwd)
+    {
+      hipfftDestroy(*(hipfftHandle *)c->fft_fwd);
+      delete(hipfftHandle *)c->fft_fwd;
+      c->fft_fwd = nullptr;
+    }
+  if(c->fft_inv)
+    {
+      hipfftDestroy(*(hipfftHandle *)c->fft_inv);
+      delete(hipfftHandle *)c->fft_inv;
+      c->fft_inv = nullptr;
+    }
+  c->pm_plan_n = 0;
+}
+
+#define FFT_TRY(ctx, expr)                                                                  \
+  do                                                                                        \
+    {                                                                                       \
+      hipfftResult r__ = (expr);                                                            \
+      if(r__ != HIPFFT_SUCCESS)                                                             \
+        {                                                                                   \
+          ngravs_report(ctx, NGRAVS_ERR_NO_DEVICE, std::string(#expr) + ": hipfft error " + std::to_string((int)r__)); \
+          return NGRAVS_ERR_NO_DEVICE;                                                      \
+        }                                                                                   \
+    }                                                                                       \
+  while(0)
+
+int pm_run(ngravs_ctx *c)
+{
+  const int N = c->cfg.pmgrid, ng = c->cfg.n_gravs;
+  const long long n = c->n;
+  if(N <= 0 || !c->cfg.periodic)
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "pmforce_periodic needs PERIODIC and PMGRID");
+      return NGRAVS_ERR_ARG;
+    }
+  const size_t real_elems = (size_t)N * N * (N + 2);
+  if(c->pm_rho.ensure(real_elems * ng) || c->pm_phi.ensure(real_elems * ng) || c->r_pm.ensure(3 * n) || c->d_counters.ensure(16))
+    return NGRAVS_ERR_NOMEM;
+  if(c->pm_plan_n != N)
+    {
+      pm_release(c);
+      c->fft_fwd = new hipfftHandle;
+      c->fft_inv = new hipfftHandle;
+      FFT_TRY(c, hipfftPlan3d((hipfftHandle *)c->fft_fwd, N, N, N, HIPFFT_D2Z));
+      FFT_TRY(c, hipfftPlan3d((hipfftHandle *)c->fft_inv, N, N, N, HIPFFT_Z2D));
+      FFT_TRY(c, hipfftSetStream(*(hipfftHandle *)c->fft_fwd, c->stream));
+      FFT_TRY(c, hipfftSetStream(*(hipfftHandle *)c->fft_inv, c->stream));
+      c->pm_plan_n = N;
+    }
+  // type -> species table on the device (6 ints, lives in d_counters[8..13])
+  HIP_TRY(c, hipMemcpyAsync(c->d_counters.p + 8, c->cfg.type_to_grav, sizeof(int) * 6, hipMemcpyHostToDevice, c->stream));
+  const double L = c->cfg.box_size, to_slab = N / L;
+  HIP_TRY(c, hipMemsetAsync(c->pm_rho.p, 0, sizeof(double) * real_elems * ng, c->stream));
+  const int bs = 256;
+  unsigned nbp = (unsigned)((n + bs - 1) / bs);
+  hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N, ng,
+                     c->d_counters.p + 8, c->pm_rho.p);
+  for(int a = 0; a < ng; a++)
+    FFT_TRY(c, hipfftExecD2Z(*(hipfftHandle *)c->fft_fwd, c->pm_rho.p + real_elems * a,
+                             (hipfftDoubleComplex *)(c->pm_rho.p + real_elems * a)));
+  GreenParams gp;
+  memset(&gp, 0, sizeof(gp));
+  gp.ng = ng;
+  gp.N = N;
+  gp.asmth2 = (2 * M_PI) * c->asmth / L;
+  gp.asmth2 *= gp.asmth2;
+  double ym = c->cfg.yukawa_imass / (2 * M_PI);
+  gp.ym2 = ym * ym;
+  gp.yfac = exp(-ym * ym * gp.asmth2);
+  for(int a = 0; a < ng; a++)
+    for(int b = 0; b < ng; b++)
+      {
+        int law = c->cfg.law_greens[a][b];   // [source][target] (pm_periodic.c:490)
+        gp.cN[a][b] = law == NGRAVS_LAW_NEWTON || law == NGRAVS_LAW_COLOYUK ? 1.0 : (law == NGRAVS_LAW_NEG_NEWTON ? -1.0 : 0.0);
+        gp.cY[a][b] = law == NGRAVS_LAW_YUKAWA || law == NGRAVS_LAW_COLOYUK ? 1.0 : 0.0;
+      }
+  long long modes = (long long)N * N * (N / 2 + 1);
+  unsigned nbm = (unsigned)((modes + bs - 1) / bs);
+  switch(ng)
+    {
+    case 1:
+      hipLaunchKernelGGL(k_green<1>, dim3(nbm), dim3(bs), 0, c->stream, (const double2 *)c->pm_rho.p, (double2 *)c->pm_phi.p, gp);
+      break;
+    case 2:
+      hipLaunchKernelGGL(k_green<2>, dim3(nbm), dim3(bs), 0, c->stream, (const double2 *)c->pm_rho.p, (double2 *)c->pm_phi.p, gp);
+      break;
+    default:
+      hipLaunchKernelGGL(k_green<3>, dim3(nbm), dim3(bs), 0, c->stream, (const double2 *)c->pm_rho.p, (double2 *)c->pm_phi.p, gp);
+      break;
+    }
+  for(int b = 0; b < ng; b++)
+    FFT_TRY(c, hipfftExecZ2D(*(hipfftHandle *)c->fft_inv, (hipfftDoubleComplex *)(c->pm_phi.p + real_elems * b),
+                             c->pm_phi.p + real_elems * b));
+  double fac = c->cfg.G / (M_PI * L);      // pm_periodic.c:237-238
+  fac *= 1 / (2 * L / N);
+  hipLaunchKernelGGL(k_gradient_gather, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N,
+                     c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+  HIP_TRY(c, hipGetLastError());
+  c->have_pm = true;
+  return NGRAVS_OK;
+}

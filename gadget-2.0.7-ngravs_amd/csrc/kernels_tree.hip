@@ -1,0 +1,339 @@
+// kernels_tree.hip -- oct-tree construction and per-species monopole moments on the GPU.
+//
+// Replaces (reference): force_treebuild_single (forcetree.c:93-281: sequential insertion, one
+// particle per leaf) and force_update_node_recursive (forcetree.c:451-743: per-species mass and
+// centre of mass, softening bit-flags).
+//
+// MI355X design: the reference's root cube is the Peano key cube (forcetree.c:106-108 vs
+// domain.c:916-923), so an octree cell at depth d is exactly the set of particles sharing the top
+// 3d key bits, and in the key-sorted particle array every cell is one contiguous range.  The tree
+// is therefore built top-down, one level per launch, one thread per node: a node splits its range
+// at the 7 digit boundaries (linear scan for small ranges, binary search for large ones);
+// sub-ranges of >=2 particles become nodes of the next level (indices from a prefix sum, so the
+// node array is level-contiguous and deterministic), single particles become leaf children --
+// the same topology as the reference's insertion tree (one particle per leaf, chains included)
+// below its top-level domain grid.  Cell centres use the reference's own recurrence
+// (centre +- len/4 per level), so they are bit-identical.  Cells that are still shared at the
+// 21st level (below the reference's 18-bit key resolution) become bucket leaves.
+// Moments are accumulated bottom-up, one launch per level, fp64 accumulators as forcetree.c:470.
+#include "engine.hpp"
+#include <hipcub/hipcub.hpp>
+
+#define FLAG_BUCKET 64   // bit 6: node holds its particles directly (deepest level)
+
+__device__ __forceinline__ int key_digit(unsigned long long k, int level)   // digit deciding the child of a level-`level` node
+{
+  return (int)((k >> (3 * (TREE_BITS - 1 - level))) & 7ull);
+}
+
+// child[] encoding after this kernel: -1 empty, -2-p particle p, >=0 : start particle of a sub-range (fixed up in k_link)
+__global__ void k_split(const unsigned long long *__restrict__ key, const int *__restrict__ n_first,
+                        const int *__restrict__ n_count, int node0, int nnodes_level, int level,
+                        int *__restrict__ n_child, int *__restrict__ n_nchild)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  int node = node0 + t;
+  int f = n_first[node], cnt = n_count[node];
+  int b[9];
+  b[0] = f;
+  b[8] = f + cnt;
+  if(cnt <= 24)
+    {
+      int k = 1;
+      for(int i = f; i < f + cnt; i++)
+        {
+          int d = key_digit(key[i], level);
+          while(k <= d)
+            b[k++] = i;
+        }
+      while(k < 8)
+        b[k++] = f + cnt;
+    }
+  else
+    {
+      for(int k = 1; k < 8; k++)
+        {
+          int lo = b[k - 1], hi = f + cnt;   // first index with digit >= k
+          while(lo < hi)
+            {
+              int mid = (lo + hi) >> 1;
+              if(key_digit(key[mid], level) < k)
+                lo = mid + 1;
+              else
+                hi = mid;
+            }
+          b[k] = lo;
+        }
+    }
+  int nn = 0;
+  for(int k = 0; k < 8; k++)
+    {
+      int c = b[k + 1] - b[k], v;
+      if(c == 0)
+        v = -1;
+      else if(c == 1)
+        v = -2 - b[k];
+      else
+        {
+          v = b[k];
+          nn++;
+        }
+      n_child[8 * (long long)node + k] = v;
+    }
+  n_nchild[t] = nn;
+}
+
+// give the sub-ranges their node indices and initialise the nodes of the next level
+__global__ void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_first, int *__restrict__ n_count,
+                       int *__restrict__ n_child, double4 *__restrict__ n_geo, int *__restrict__ n_flags,
+                       const int *__restrict__ scan, int node0, int nnodes_level, int next0, int level,
+                       double cx, double cy, double cz, double fac21)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  int node = node0 + t;
+  int end = n_first[node] + n_count[node];
+  double4 g = n_geo[node];
+  int nxt = next0 + scan[t];
+  int starts[8], vals[8];
+  for(int k = 0; k < 8; k++)
+    {
+      int v = n_child[8 * (long long)node + k];
+      vals[k] = v;
+      starts[k] = v >= 0 ? v : (v <= -2 ? -2 - v : -1);
+    }
+  for(int k = 0; k < 8; k++)
+    {
+      if(vals[k] < 0)
+        continue;
+      int e = end;
+      for(int kk = k + 1; kk < 8; kk++)
+        if(starts[kk] >= 0)
+          {
+            e = starts[kk];
+            break;
+          }
+      int cn = nxt++;
+      n_child[8 * (long long)node + k] = cn;
+      n_first[cn] = starts[k];
+      n_count[cn] = e - starts[k];
+      // geometric octant of the child from its first particle's cell coordinates; centre recurrence
+      // of forcetree.c:190-206 (centre +- 0.25*len of the parent)
+      double4 p = s_pm[starts[k]];
+      int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
+      int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
+      int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
+      int sh = TREE_BITS - 1 - level;
+      double q = 0.25 * g.w;
+      double4 cg;
+      cg.x = ((ix >> sh) & 1) ? g.x + q : g.x - q;
+      cg.y = ((iy >> sh) & 1) ? g.y + q : g.y - q;
+      cg.z = ((iz >> sh) & 1) ? g.z + q : g.z - q;
+      cg.w = 0.5 * g.w;
+      n_geo[cn] = cg;
+      n_flags[cn] = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
+    }
+}
+
+struct SoftAcc
+{
+  int maxsofttype, diff;
+};
+__device__ __forceinline__ void soft_merge(SoftAcc &a, int t, int tdiff, const double *fsoft)
+{
+  // forcetree.c:571-596 / :640-658 (same rule for a child node's type and for a particle's type)
+  a.diff |= tdiff;
+  if(a.maxsofttype == 7)
+    a.maxsofttype = t;
+  else if(t != 7)
+    {
+      if(fsoft[t] > fsoft[a.maxsofttype])
+        {
+          a.maxsofttype = t;
+          a.diff = 1;
+        }
+      else if(fsoft[t] < fsoft[a.maxsofttype])
+        a.diff = 1;
+    }
+}
+
+template <int NG>
+__global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                          const int *__restrict__ n_first, const int *__restrict__ n_count,
+                          const int *__restrict__ n_child, const double4 *__restrict__ n_geo,
+                          double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level,
+                          WalkParams wp)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  int node = node0 + t;
+  double m[NG], sx[NG], sy[NG], sz[NG];
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    m[g] = sx[g] = sy[g] = sz[g] = 0;
+  SoftAcc sa;
+  sa.maxsofttype = 7;
+  sa.diff = 0;
+  int fl = n_flags[node];
+  auto add_particle = [&](int p) {
+    double4 v = s_pm[p];
+    int ty = s_type[p];
+    int gg = wp.t2g[ty];
+#pragma unroll
+    for(int g = 0; g < NG; g++)
+      if(g == gg)
+        {
+          m[g] += v.w;
+          sx[g] += v.w * v.x;
+          sy[g] += v.w * v.y;
+          sz[g] += v.w * v.z;
+        }
+    soft_merge(sa, ty, 0, wp.fsoft);
+  };
+  if(fl & FLAG_BUCKET)
+    {
+      int f = n_first[node], cnt = n_count[node];
+      for(int p = f; p < f + cnt; p++)
+        add_particle(p);
+    }
+  else
+    {
+      for(int k = 0; k < 8; k++)
+        {
+          int c = n_child[8 * (long long)node + k];
+          if(c == -1)
+            continue;
+          if(c <= -2)
+            add_particle(-2 - c);
+          else
+            {
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  double4 cm = n_mom[(long long)c * NG + g];
+                  m[g] += cm.w;
+                  sx[g] += cm.w * cm.x;
+                  sy[g] += cm.w * cm.y;
+                  sz[g] += cm.w * cm.z;
+                }
+              int cf = n_flags[c];
+              soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
+            }
+        }
+    }
+  double4 geo = n_geo[node];
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    {
+      double4 o;
+      if(m[g] > 0)
+        {
+          o.x = sx[g] / m[g];
+          o.y = sy[g] / m[g];
+          o.z = sz[g] / m[g];
+        }
+      else
+        {
+          o.x = geo.x;
+          o.y = geo.y;
+          o.z = geo.z;
+        }
+      o.w = m[g];
+      n_mom[(long long)node * NG + g] = o;
+    }
+  n_flags[node] = (fl & FLAG_BUCKET) | (4 * sa.maxsofttype + 32 * sa.diff);
+}
+
+int tree_build(ngravs_ctx *c)
+{
+  const long long n = c->n;
+  double taf = c->cfg.tree_alloc_factor > 0 ? c->cfg.tree_alloc_factor : 0.8;
+  long long maxn = (long long)(taf * (double)n) + 1024;
+  c->max_nodes = maxn;
+  const int ng = c->cfg.n_gravs;
+  if(c->n_first.ensure(maxn) || c->n_count.ensure(maxn) || c->n_child.ensure(8 * maxn) || c->n_flags.ensure(maxn) ||
+     c->n_geo.ensure(maxn) || c->n_mom.ensure(maxn * ng) || c->n_nchild.ensure(maxn) || c->scan_out.ensure(maxn) ||
+     c->d_counters.ensure(16))
+    return NGRAVS_ERR_NOMEM;
+  // root = the domain cube (forcetree.c:103-110)
+  int h_first = 0, h_count = (int)n, h_flags = 0;
+  double4 h_geo;
+  h_geo.x = c->dom[3];
+  h_geo.y = c->dom[4];
+  h_geo.z = c->dom[5];
+  h_geo.w = c->dom[6];
+  HIP_TRY(c, hipMemcpyAsync(c->n_first.p, &h_first, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->n_count.p, &h_count, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->n_geo.p, &h_geo, sizeof(double4), hipMemcpyHostToDevice, c->stream));
+  double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
+  size_t scan_bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c->n_nchild.p, c->scan_out.p, (int)maxn, c->stream);
+  if(c->scan_tmp.ensure(scan_bytes))
+    return NGRAVS_ERR_NOMEM;
+  long long node0 = 0, cnt = 1;
+  int level = 0;
+  c->level_start[0] = 0;
+  const int bs = 128;
+  while(cnt > 0 && level < TREE_BITS)
+    {
+      unsigned nb = (unsigned)((cnt + bs - 1) / bs);
+      hipLaunchKernelGGL(k_split, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->n_first.p, c->n_count.p, (int)node0,
+                         (int)cnt, level, c->n_child.p, c->n_nchild.p);
+      size_t sb = scan_bytes;
+      HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, sb, c->n_nchild.p, c->scan_out.p, (int)cnt, c->stream));
+      int last_scan = 0, last_n = 0;
+      HIP_TRY(c, hipMemcpyAsync(&last_scan, c->scan_out.p + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&last_n, c->n_nchild.p + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      long long next_cnt = (long long)last_scan + last_n;
+      long long next0 = node0 + cnt;
+      if(next0 + next_cnt > maxn)
+        {
+          ngravs_report(c, 1, "maximum number of tree-nodes reached (increase tree_alloc_factor)");   // endrun(1), forcetree.c:247
+          return NGRAVS_ERR_TREE;
+        }
+      hipLaunchKernelGGL(k_link, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->n_first.p, c->n_count.p, c->n_child.p,
+                         c->n_geo.p, c->n_flags.p, c->scan_out.p, (int)node0, (int)cnt, (int)next0, level, c->dom[0],
+                         c->dom[1], c->dom[2], fac21);
+      level++;
+      c->level_start[level] = next0;
+      node0 = next0;
+      cnt = next_cnt;
+    }
+  // cnt nodes of the last level (level == TREE_BITS, buckets) or 0
+  c->nlevels = level + (cnt > 0 ? 1 : 0);
+  c->nnodes = node0 + cnt;
+  c->level_start[c->nlevels] = c->nnodes;
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  for(int l = c->nlevels - 1; l >= 0; l--)
+    {
+      long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
+      if(lc <= 0)
+        continue;
+      unsigned nb = (unsigned)((lc + bs - 1) / bs);
+      switch(ng)
+        {
+        case 1:
+          hipLaunchKernelGGL(k_moments<1>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
+          break;
+        case 2:
+          hipLaunchKernelGGL(k_moments<2>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
+          break;
+        default:
+          hipLaunchKernelGGL(k_moments<3>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
+          break;
+        }
+    }
+  HIP_TRY(c, hipGetLastError());
+  c->stats.n_nodes = c->nnodes;
+  return NGRAVS_OK;
+}

@@ -1,0 +1,1008 @@
+// kernels_walk.hip -- the short-range / full tree walk, OldAcc + G post-processing, direct sum.
+//
+// Replaces (reference): force_treeevaluate (forcetree.c:1244-1610), force_treeevaluate_shortrange
+// (forcetree.c:1623-2052), the per-particle loop + post-processing of gravity_tree
+// (gravtree.c:112-149, 318-341) and force_treeevaluate_direct (forcetree.c:3428-3548).
+//
+// Two walk kernels over the same level-ordered tree, one wave64 per 64 Peano-contiguous targets:
+//
+//  k_walk_strict : the reference semantics per target.  The wave walks the tree depth-first in
+//      lock-step (control flow is wave-uniform: node indices live in SGPRs, node records are
+//      scalar loads); every lane takes its OWN prune / open / accept decision exactly as the
+//      reference does, and a lane that has used or pruned a node sleeps until the walk leaves
+//      that node's particle range (`resume_at`).  Interaction set, interaction count and
+//      summation order per target equal the reference's (children are visited in Peano instead
+//      of Morton order, which only reorders the fp64 sum).
+//
+//  k_walk_group : the MI355X production walk.  The 64 lanes traverse cooperatively: a LIFO of
+//      pending nodes is popped 64 at a time, each lane tests ONE node against the group's
+//      bounding box with the conservative form of every reference test (a node is used only if
+//      every target would use it, dropped only if every target would drop it), ballot +
+//      popcount prefix compact accepted monopoles / particle leaves into per-species interaction
+//      lists in LDS, and all 64 lanes then stream those lists (LDS broadcast reads) through the
+//      force law.  The TreePM short-range table (NTAB fp64 per species pair) is staged in LDS once
+//      per workgroup; workgroups are persistent and pull groups from an atomic counter.
+//
+// Force laws: the reference calls AccelFxns[tg][sg] through a pointer; here the wired table is
+// lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,
+// neg_newtonian, yukawa, coloyuk) and kernels are compiled per N_GRAVS and per "has Yukawa".
+#include "engine.hpp"
+
+#define FLAG_BUCKET 64
+#define WAVE 64
+
+__device__ __forceinline__ double nearest(double x, double box, double boxhalf)
+{
+  return (x > boxhalf) ? (x - box) : ((x < -boxhalf) ? (x + box) : x);   // NEAREST, forcetree.c:43
+}
+
+// ---------------------------------------------------------------------------------------------
+// force laws, reference formulation (strict walk, direct sum)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double law_accel_ref(int law, double m, double r2, double r, double ym)
+{
+  switch(law)
+    {
+    case NGRAVS_LAW_NEWTON:
+      return m / r2;                                                   // ngravs.c:351
+    case NGRAVS_LAW_NEG_NEWTON:
+      return -m / r2;                                                  // ngravs.c:357
+    case NGRAVS_LAW_YUKAWA:
+      return m * exp(-r * ym) * (ym / r + 1.0 / r2);                   // ngravs.c:856-861
+    case NGRAVS_LAW_COLOYUK:
+      return m * exp(-r * ym) * (ym / r + 1.0 / r2) + m / r2;          // ngravs.c:826
+    default:
+      return 0.0;
+    }
+}
+__device__ __forceinline__ double law_spline_ref(int id, double m, double h, double r)
+{
+  if(id == NGRAVS_SPLINE_NONE)
+    return 0.0;
+  double h_inv = 1 / h, v;                                             // ngravs.c:420-434, literal constants
+  r *= h_inv;
+  if(r < 0.5)
+    v = m * h_inv * h_inv * h_inv * (10.666666666667 + r * r * (32.0 * r - 38.4));
+  else
+    v = m * h_inv * h_inv * h_inv *
+        (21.333333333333 - 48.0 * r + 38.4 * r * r - 10.666666666667 * r * r * r - 0.066666666667 / (r * r * r));
+  return id == NGRAVS_SPLINE_NEG_PLUMMER ? -v : v;
+}
+
+struct LawIds
+{
+  int accel[NG_MAX][NG_MAX], spline[NG_MAX][NG_MAX];
+};
+
+// =============================================================================================
+//  strict walk
+// =============================================================================================
+#pragma clang fp contract(off)
+
+template <int NG, bool PM>
+__global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 *__restrict__ s_pm,
+                                                     const unsigned char *__restrict__ s_type,
+                                                     const double *__restrict__ s_oldacc,
+                                                     const unsigned char *__restrict__ s_active,
+                                                     const double *__restrict__ table, WalkParams wp, LawIds li,
+                                                     long long t_first, long long t_count,
+                                                     double *__restrict__ r_acc, int *__restrict__ r_nint)
+{
+  __shared__ int st_node[4][MAX_LEVELS + 2], st_slot[4][MAX_LEVELS + 2];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long grp = (long long)blockIdx.x * 4 + wave;
+  const long long ti = t_first + grp * WAVE + lane;
+  const bool valid = (grp * WAVE + lane) < t_count && s_active[ti < t_first + t_count ? ti : t_first] != 0;
+  if(grp * WAVE >= t_count)
+    return;
+  double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
+  int ptype = 0, tg = 0;
+  if(valid)
+    {
+      double4 p = s_pm[ti];
+      px = p.x;
+      py = p.y;
+      pz = p.z;
+      ptype = s_type[ti];
+      tg = wp.t2g[ptype];
+      hT = wp.fsoft[ptype];
+      aold = wp.errtol_acc * s_oldacc[ti];
+    }
+  double ax = 0, ay = 0, az = 0;
+  int nint = 0;
+  int resume_at = valid ? 0 : 0x7fffffff;
+  int *sn = st_node[wave], *ss = st_slot[wave];
+  int sp = -1;
+
+  // one source (particle or one species of a node): forcetree.c:1534-1583 / :1953-2032
+  auto interact = [&](int g, double dx, double dy, double dz, double r2, double m, double h) -> bool {
+    double r = sqrt(r2), fac;
+    if(PM)
+      {
+        int tab = (int)(wp.asmthfac * r);
+        if(tab >= NTAB)
+          return false;
+        if(r >= h)
+          {
+            fac = law_accel_ref(li.accel[tg][g], m, r2, r, wp.ym);
+            fac -= m * wp.utor2wpi * table[((size_t)tg * NG + g) * NTAB + tab];
+            fac /= r;
+          }
+        else
+          fac = law_spline_ref(li.spline[tg][g], m, h, r);
+      }
+    else
+      {
+        if(r >= h)
+          fac = law_accel_ref(li.accel[tg][g], m, r2, r, wp.ym) / r;
+        else
+          fac = law_spline_ref(li.spline[tg][g], m, h, r);
+      }
+    ax += dx * fac;
+    ay += dy * fac;
+    az += dz * fac;
+    return true;
+  };
+
+  auto do_particle = [&](int p) {
+    double4 q = s_pm[p];          // uniform address -> scalar load
+    int qt = s_type[p];
+    if(p >= resume_at)
+      {
+        int sg = wp.t2g[qt];
+        double dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+        if(wp.periodic)
+          {
+            dx = nearest(dx, wp.box, wp.boxhalf);
+            dy = nearest(dy, wp.box, wp.boxhalf);
+            dz = nearest(dz, wp.box, wp.boxhalf);
+          }
+        double r2 = dx * dx + dy * dy + dz * dz;
+        double h = hT;
+        if(h < wp.fsoft[qt])
+          h = wp.fsoft[qt];
+        bool added = interact(sg, dx, dy, dz, r2, q.w, h);
+        if(added || !PM)
+          nint++;
+      }
+  };
+
+  // returns true if some lane wants the node opened
+  auto visit = [&](int c) -> bool {
+    int first = tv.first[c], cnt = tv.count[c], fl = tv.flags[c];
+    double4 geo = tv.geo[c];
+    double4 mom[NG];
+#pragma unroll
+    for(int g = 0; g < NG; g++)
+      mom[g] = tv.mom[(long long)c * NG + g];
+    bool open = false;
+    if(first >= resume_at)
+      {
+        double dx[NG], dy[NG], dz[NG], r2[NG];
+        double r2min = INFINITY, r2max = -INFINITY, summass = 0;
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          {
+            summass += mom[g].w;
+            dx[g] = mom[g].x - px;
+            dy[g] = mom[g].y - py;
+            dz[g] = mom[g].z - pz;
+            if(wp.periodic)
+              {
+                dx[g] = nearest(dx[g], wp.box, wp.boxhalf);
+                dy[g] = nearest(dy[g], wp.box, wp.boxhalf);
+                dz[g] = nearest(dz[g], wp.box, wp.boxhalf);
+              }
+            r2[g] = dx[g] * dx[g] + dy[g] * dy[g] + dz[g] * dz[g];
+            if(r2[g] < r2min)
+              r2min = r2[g];
+            if(r2[g] > r2max)
+              r2max = r2[g];
+          }
+        const double len = geo.w;
+        bool done = false;   // pruned
+        if(PM && r2min > wp.rcut2)
+          {
+            double eff = wp.rcut + 0.5 * len;                           // forcetree.c:1828-1862
+            double d0 = geo.x - px, d1 = geo.y - py, d2 = geo.z - pz;
+            if(wp.periodic)
+              {
+                d0 = nearest(d0, wp.box, wp.boxhalf);
+                d1 = nearest(d1, wp.box, wp.boxhalf);
+                d2 = nearest(d2, wp.box, wp.boxhalf);
+              }
+            if(d0 < -eff || d0 > eff || d1 < -eff || d1 > eff || d2 < -eff || d2 > eff)
+              done = true;
+          }
+        if(!done)
+          {
+            if(wp.use_theta)
+              {
+                if(len * len > r2min * wp.theta2)                      // forcetree.c:1437-1445 (theta2 = ErrTolTheta^2)
+                  open = true;
+              }
+            else
+              {
+                if(summass * len * len > r2min * r2min * aold)         // forcetree.c:1454
+                  open = true;
+                else if(fabs(geo.x - px) < 0.60 * len && fabs(geo.y - py) < 0.60 * len &&
+                        fabs(geo.z - pz) < 0.60 * len)                 // forcetree.c:1462-1472 (no NEAREST)
+                  open = true;
+              }
+          }
+        if(!done && !open)
+          {
+            double h = hT;
+            int mst = (fl >> 2) & 7;
+            if(mst == 7)
+              open = true;                                             // empty node: nothing below, harmless
+            else
+              {
+                if(h < wp.fsoft[mst])
+                  {
+                    h = wp.fsoft[mst];
+                    if(r2max < h * h && ((fl >> 5) & 1))               // forcetree.c:1488-1499
+                      open = true;
+                  }
+                if(!open)
+                  {
+                    bool added = false;
+#pragma unroll
+                    for(int g = 0; g < NG; g++)
+                      if(mom[g].w != 0.0)
+                        added |= interact(g, dx[g], dy[g], dz[g], r2[g], mom[g].w, h);
+                    if(added || !PM)
+                      nint++;
+                  }
+              }
+          }
+        if(!open)
+          resume_at = first + cnt;
+      }
+    return __any(open ? 1 : 0) != 0;
+  };
+
+  if(visit(0))
+    {
+      sp = 0;
+      sn[0] = 0;
+      ss[0] = 0;
+    }
+  while(sp >= 0)
+    {
+      int node = __builtin_amdgcn_readfirstlane(sn[sp]);
+      int slot = __builtin_amdgcn_readfirstlane(ss[sp]);
+      int fl = tv.flags[node];
+      if(fl & FLAG_BUCKET)
+        {
+          int f = tv.first[node], cnt = tv.count[node];
+          if(slot >= cnt)
+            {
+              sp--;
+              continue;
+            }
+          ss[sp] = slot + 1;
+          do_particle(f + slot);
+          continue;
+        }
+      if(slot >= 8)
+        {
+          sp--;
+          continue;
+        }
+      ss[sp] = slot + 1;
+      int c = __builtin_amdgcn_readfirstlane(tv.child[8 * (long long)node + slot]);
+      if(c == -1)
+        continue;
+      if(c <= -2)
+        {
+          do_particle(-2 - c);
+          continue;
+        }
+      if(visit(c))
+        {
+          sp++;
+          sn[sp] = c;
+          ss[sp] = 0;
+        }
+    }
+  if(valid)
+    {
+      r_acc[3 * ti + 0] = ax;
+      r_acc[3 * ti + 1] = ay;
+      r_acc[3 * ti + 2] = az;
+      r_nint[ti] = nint;
+    }
+}
+
+#pragma clang fp contract(fast)
+
+// =============================================================================================
+//  group walk
+// =============================================================================================
+#define GW_WAVES 8
+#define GW_CAP 128          // interaction-list capacity per species per wave
+#define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
+
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ int lane_prefix(unsigned long long mask)   // # set bits below this lane
+{
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      double o = __shfl_xor(v, off);
+      v = o < v ? o : v;
+    }
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      double o = __shfl_xor(v, off);
+      v = o > v ? o : v;
+    }
+  return v;
+}
+
+template <int NG, bool PM, bool YUK, bool TAB_LDS>
+__global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
+    TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+    const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
+    const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
+    int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // layout: [table NG*NG*NTAB doubles (if TAB_LDS)] [per wave: NG*CAP double4 | NG*CAP double]
+  double *tab_s = reinterpret_cast<double *>(smem);
+  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double4 *lpos = reinterpret_cast<double4 *>(smem + tab_bytes) + (size_t)wave * NG * GW_CAP;
+  double *lh = reinterpret_cast<double *>(smem + tab_bytes + sizeof(double4) * GW_WAVES * NG * GW_CAP) +
+               (size_t)wave * NG * GW_CAP;
+  if(PM && TAB_LDS)
+    {
+      for(int t = threadIdx.x; t < NG * NG * NTAB; t += blockDim.x)
+        tab_s[t] = table[t];
+      __syncthreads();
+    }
+  const double *tabp = (PM && TAB_LDS) ? tab_s : table;
+  int *stack = stack_base + ((size_t)blockIdx.x * GW_WAVES + wave) * GW_STACK;
+  const long long ngroups = (t_count + WAVE - 1) / WAVE;
+
+  for(;;)
+    {
+      int grp = 0;
+      if(lane == 0)
+        grp = atomicAdd(counter, 1);
+      grp = __builtin_amdgcn_readfirstlane(grp);
+      if(grp >= ngroups)
+        break;
+      const long long ti = t_first + (long long)grp * WAVE + lane;
+      const bool valid = ((long long)grp * WAVE + lane) < t_count && s_active[ti] != 0;
+      if(!__any(valid ? 1 : 0))
+        continue;
+      double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
+      int tg = 0;
+      if(valid)
+        {
+          double4 p = s_pm[ti];
+          px = p.x;
+          py = p.y;
+          pz = p.z;
+          int ptype = s_type[ti];
+          tg = wp.t2g[ptype];
+          hT = wp.fsoft[ptype];
+          aold = wp.errtol_acc * s_oldacc[ti];
+        }
+      // per-lane law coefficients against each source species
+      double cN[NG], cY[NG], cS[NG];
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        {
+          cN[g] = wp.cN[tg][g];
+          cY[g] = wp.cY[tg][g];
+          cS[g] = wp.cS[tg][g];
+        }
+      // group bounding box and the conservative scalars
+      const double BIG = 1e300;
+      double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
+      double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
+      double loz = wave_min(valid ? pz : BIG), hiz = wave_max(valid ? pz : -BIG);
+      const double bcx = 0.5 * (lox + hix), bcy = 0.5 * (loy + hiy), bcz = 0.5 * (loz + hiz);
+      const double bhx = 0.5 * (hix - lox), bhy = 0.5 * (hiy - loy), bhz = 0.5 * (hiz - loz);
+      const double aold_min = wave_min(valid ? aold : BIG);
+      const double hT_min = wave_min(valid ? hT : BIG);
+      // may sources be wrapped once per group (relative to the box centre) instead of per pair?
+      const double bhmax = fmax(bhx, fmax(bhy, bhz));
+      const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
+                           (wp.boxhalf - bhmax) > 0;
+      const bool lanewrap = wp.periodic && !prewrap;
+
+      double ax = 0, ay = 0, az = 0;
+      int nint = 0;
+      int cnt[NG];
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        cnt[g] = 0;
+
+      // ---- stream the interaction lists through the force law --------------------------------
+      auto flush = [&]() {
+        wave_sync();
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          {
+            const double4 *lp = lpos + g * GW_CAP;
+            const double *hp = lh + g * GW_CAP;
+            const int n = cnt[g];
+            for(int j = 0; j < n; j++)
+              {
+                double4 e = lp[j];
+                double hs = hp[j];
+                double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
+                if(lanewrap)
+                  {
+                    dx = nearest(dx, wp.box, wp.boxhalf);
+                    dy = nearest(dy, wp.box, wp.boxhalf);
+                    dz = nearest(dz, wp.box, wp.boxhalf);
+                  }
+                double r2 = dx * dx + dy * dy + dz * dz;
+                if(PM && !(r2 < wp.reach2))
+                  continue;
+                double rinv = __builtin_amdgcn_rsq(r2);
+                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);
+                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);
+                double r = r2 * rinv;
+                if(!(r2 > 0))
+                  {
+                    r = 0;
+                    rinv = 0;
+                  }
+                double h = hT > hs ? hT : hs;
+                double fac;
+                int tab = 0;
+                if(PM)
+                  {
+                    tab = (int)(wp.asmthfac * r);
+                    if(tab >= NTAB)
+                      continue;
+                  }
+                if(r >= h)
+                  {
+                    double ri2 = rinv * rinv;
+                    fac = cN[g] * ri2;
+                    if(YUK)
+                      fac += cY[g] * exp(-r * wp.ym) * (wp.ym * rinv + ri2);
+                    if(PM)
+                      fac -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
+                    fac *= e.w * rinv;
+                  }
+                else
+                  {
+                    double h_inv = 1 / h, u = r * h_inv;
+                    double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
+                                         : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
+                                            0.066666666667 / (u * u * u));
+                    fac = cS[g] * e.w * h_inv * h_inv * h_inv * v;
+                  }
+                ax += dx * fac;
+                ay += dy * fac;
+                az += dz * fac;
+                nint++;
+              }
+            cnt[g] = 0;
+          }
+        wave_sync();
+      };
+      // append one entry per flagged lane to species list g (all lanes call this)
+      auto append = [&](int g, bool pred, double x, double y, double z, double m, double hs) {
+        unsigned long long mask = __ballot(pred ? 1 : 0);
+        if(mask == 0)
+          return;
+        if(pred)
+          {
+            if(prewrap)
+              {
+                x = bcx + nearest(x - bcx, wp.box, wp.boxhalf);
+                y = bcy + nearest(y - bcy, wp.box, wp.boxhalf);
+                z = bcz + nearest(z - bcz, wp.box, wp.boxhalf);
+              }
+            int o = cnt[g] + lane_prefix(mask);
+            double4 e;
+            e.x = x;
+            e.y = y;
+            e.z = z;
+            e.w = m;
+            lpos[g * GW_CAP + o] = e;
+            lh[g * GW_CAP + o] = hs;
+          }
+        cnt[g] += __popcll(mask);
+      };
+      auto room = [&]() {   // make sure every list can take 64 more entries
+        bool full = false;
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          full |= (cnt[g] + WAVE > GW_CAP);
+        if(full)
+          flush();
+      };
+      auto append_particle = [&](bool pred, int p) {
+        double4 q;
+        int qt = 0;
+        q.x = q.y = q.z = q.w = 0;
+        if(pred)
+          {
+            q = s_pm[p];
+            qt = s_type[p];
+          }
+        int sg = wp.t2g[qt];
+        double hs = wp.fsoft[qt];
+        room();
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          append(g, pred && sg == g, q.x, q.y, q.z, q.w, hs);
+      };
+
+      // ---- cooperative traversal ------------------------------------------------------------
+      int sp = 1;
+      if(lane == 0)
+        stack[0] = 0;
+      wave_sync();
+      bool overflow = false;
+      while(sp > 0)
+        {
+          const int nb = sp < WAVE ? sp : WAVE;
+          sp -= nb;
+          const int my = lane < nb ? stack[sp + lane] : -1;
+          wave_sync();
+          // decision: 0 drop, 1 accept, 2 open (children), 3 open bucket
+          int dec = 0;
+          double4 mom[NG];
+          double hs_node = 0;
+          int first = 0, count = 0;
+          if(my >= 0)
+            {
+              const double4 geo = tv.geo[my];
+              const int fl = tv.flags[my];
+              const double len = geo.w;
+              double r2min = BIG, summass = 0;
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  mom[g] = tv.mom[(long long)my * NG + g];
+                  summass += mom[g].w;
+                  double dx = mom[g].x - bcx, dy = mom[g].y - bcy, dz = mom[g].z - bcz;
+                  if(wp.periodic)
+                    {
+                      dx = nearest(dx, wp.box, wp.boxhalf);
+                      dy = nearest(dy, wp.box, wp.boxhalf);
+                      dz = nearest(dz, wp.box, wp.boxhalf);
+                    }
+                  double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
+                  double r2g = a0 * a0 + a1 * a1 + a2 * a2;
+                  r2min = r2g < r2min ? r2g : r2min;
+                }
+              double cx = geo.x - bcx, cy = geo.y - bcy, cz = geo.z - bcz;   // plain (inside-cell test has no NEAREST)
+              double wx = cx, wy = cy, wz = cz;
+              if(wp.periodic)
+                {
+                  wx = nearest(cx, wp.box, wp.boxhalf);
+                  wy = nearest(cy, wp.box, wp.boxhalf);
+                  wz = nearest(cz, wp.box, wp.boxhalf);
+                }
+              const int mst = (fl >> 2) & 7;
+              bool drop = (mst == 7);   // empty
+              if(PM && !drop)
+                {
+                  // (i) nothing inside the cell can be within the table's reach of any target
+                  double half = 0.5 * len;
+                  double q0 = fmax(0.0, fabs(wx) - bhx - half), q1 = fmax(0.0, fabs(wy) - bhy - half),
+                         q2 = fmax(0.0, fabs(wz) - bhz - half);
+                  if(q0 * q0 + q1 * q1 + q2 * q2 >= wp.reach2)
+                    drop = true;
+                  // (ii) the reference's own cut (forcetree.c:1828-1862) holds for every target
+                  if(!drop && r2min > wp.rcut2)
+                    {
+                      double eff = wp.rcut + half;
+                      if(fabs(wx) - bhx > eff || fabs(wy) - bhy > eff || fabs(wz) - bhz > eff)
+                        drop = true;
+                    }
+                }
+              if(!drop)
+                {
+                  bool open;
+                  if(wp.use_theta)
+                    open = len * len > r2min * wp.theta2;
+                  else
+                    {
+                      open = summass * len * len > r2min * r2min * aold_min;
+                      if(!open)
+                        open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
+                               (fabs(cz) - bhz < 0.60 * len);
+                    }
+                  hs_node = wp.fsoft[mst];
+                  if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
+                    open = true;
+                  if(open)
+                    {
+                      dec = (fl & FLAG_BUCKET) ? 3 : 2;
+                      first = tv.first[my];
+                      count = tv.count[my];
+                    }
+                  else
+                    dec = 1;
+                }
+            }
+          // accepted monopoles
+          if(__any(dec == 1))
+            {
+              room();
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                append(g, dec == 1 && mom[g].w != 0.0, mom[g].x, mom[g].y, mom[g].z, mom[g].w, hs_node);
+            }
+          // opened nodes: node children go back on the LIFO, particle children into the lists
+          if(__any(dec == 2))
+            {
+              for(int slot = 0; slot < 8; slot++)
+                {
+                  int ch = (dec == 2) ? tv.child[8 * (long long)my + slot] : -1;
+                  bool isnode = ch >= 0;
+                  unsigned long long mask = __ballot(isnode ? 1 : 0);
+                  if(mask)
+                    {
+                      int npush = __popcll(mask);
+                      if(sp + npush > GW_STACK)
+                        {
+                          overflow = true;
+                          break;
+                        }
+                      if(isnode)
+                        stack[sp + lane_prefix(mask)] = ch;
+                      sp += npush;
+                    }
+                  bool ispart = ch <= -2;
+                  if(__any(ispart ? 1 : 0))
+                    append_particle(ispart, -2 - ch);
+                }
+              if(overflow)
+                break;
+            }
+          // opened buckets (coincident keys at the deepest level): all their particles
+          if(__any(dec == 3))
+            {
+              int k = 0;
+              for(;;)
+                {
+                  bool more = (dec == 3) && k < count;
+                  if(!__any(more ? 1 : 0))
+                    break;
+                  append_particle(more, first + k);
+                  k++;
+                }
+            }
+          wave_sync();
+        }
+      if(overflow)
+        {
+          if(lane == 0)
+            atomicExch(err_flag, 1);
+          continue;
+        }
+      flush();
+      if(valid)
+        {
+          r_acc[3 * ti + 0] = ax;
+          r_acc[3 * ti + 1] = ay;
+          r_acc[3 * ti + 2] = az;
+          r_nint[ti] = nint;
+        }
+    }
+}
+
+// =============================================================================================
+//  post-processing (gravtree.c:318-341): OldAcc = |GravAccel + GravPM/G|, GravAccel *= G
+// =============================================================================================
+__global__ void k_finish(long long t_first, long long t_count, const unsigned char *__restrict__ s_active,
+                         double *__restrict__ r_acc, const double *__restrict__ r_pm, double *__restrict__ r_oldacc,
+                         double G, int have_pm)
+{
+  long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(k >= t_count)
+    return;
+  long long i = t_first + k;
+  if(!s_active[i])
+    return;
+  double ax = r_acc[3 * i], ay = r_acc[3 * i + 1], az = r_acc[3 * i + 2];
+  double bx = ax, by = ay, bz = az;
+  if(have_pm)
+    {
+      bx += r_pm[3 * i] / G;
+      by += r_pm[3 * i + 1] / G;
+      bz += r_pm[3 * i + 2] / G;
+    }
+  r_oldacc[i] = sqrt(bx * bx + by * by + bz * bz);
+  r_acc[3 * i] = ax * G;
+  r_acc[3 * i + 1] = ay * G;
+  r_acc[3 * i + 2] = az * G;
+}
+
+// =============================================================================================
+//  direct summation for a list of targets (forcetree.c:3428-3548, no Ewald term)
+// =============================================================================================
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_direct(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                                 long long n, const int *__restrict__ tidx, long long nt, WalkParams wp,
+                                                 LawIds li, double G, double *__restrict__ acc)
+{
+  // one block per target, threads stride over sources, fp64 block reduction
+  long long k = blockIdx.x;
+  if(k >= nt)
+    return;
+  int t = tidx[k];
+  double4 p = s_pm[t];
+  int ptype = s_type[t], tg = wp.t2g[ptype];
+  double ax = 0, ay = 0, az = 0;
+  for(long long i = threadIdx.x; i < n; i += blockDim.x)
+    {
+      double4 q = s_pm[i];
+      int qt = s_type[i], sg = wp.t2g[qt];
+      double h = wp.fsoft[qt] > wp.fsoft[ptype] ? wp.fsoft[qt] : wp.fsoft[ptype];
+      double dx = q.x - p.x, dy = q.y - p.y, dz = q.z - p.z;
+      if(wp.periodic)
+        {
+          dx = nearest(dx, wp.box, wp.boxhalf);
+          dy = nearest(dy, wp.box, wp.boxhalf);
+          dz = nearest(dz, wp.box, wp.boxhalf);
+        }
+      double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2), u = r * (1 / h), fac;
+      if(u >= 1)
+        fac = law_accel_ref(li.accel[tg][sg], q.w, r2, r, wp.ym) / r;
+      else
+        fac = law_spline_ref(li.spline[tg][sg], q.w, h, r);
+      ax += dx * fac;
+      ay += dy * fac;
+      az += dz * fac;
+    }
+  __shared__ double sh[3][4];
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      ax += __shfl_down(ax, off);
+      ay += __shfl_down(ay, off);
+      az += __shfl_down(az, off);
+    }
+  if((threadIdx.x & 63) == 0)
+    {
+      sh[0][threadIdx.x >> 6] = ax;
+      sh[1][threadIdx.x >> 6] = ay;
+      sh[2][threadIdx.x >> 6] = az;
+    }
+  __syncthreads();
+  if(threadIdx.x == 0)
+    {
+      acc[3 * k] = (sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3]) * G;
+      acc[3 * k + 1] = (sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]) * G;
+      acc[3 * k + 2] = (sh[2][0] + sh[2][1] + sh[2][2] + sh[2][3]) * G;
+    }
+}
+#pragma clang fp contract(fast)
+
+// =============================================================================================
+//  host side
+// =============================================================================================
+void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
+{
+  const ngravs_config_t &cfg = c->cfg;
+  memset(wp, 0, sizeof(*wp));
+  wp->ng = cfg.n_gravs;
+  wp->periodic = cfg.periodic;
+  wp->pm = cfg.pmgrid != 0;
+  wp->use_theta = cfg.err_tol_theta != 0;
+  wp->box = cfg.box_size;
+  wp->boxhalf = 0.5 * cfg.box_size;
+  wp->theta2 = cfg.err_tol_theta * cfg.err_tol_theta;
+  wp->errtol_acc = cfg.err_tol_force_acc;
+  if(cfg.pmgrid)
+    {
+      wp->rcut = c->rcut;
+      wp->rcut2 = c->rcut * c->rcut;
+      wp->asmthfac = 0.5 / c->asmth * (NTAB / 3.0);          // forcetree.c:1708
+      wp->utor2wpi = 1.0 / (M_PI * 4 * c->asmth * c->asmth);  // forcetree.c:1711
+      double reach = NTAB / wp->asmthfac;                    // tabindex < NTAB  <=>  r < 6*asmth
+      wp->reach2 = reach * reach;
+    }
+  wp->ym = cfg.box_size > 0 ? cfg.yukawa_imass / cfg.box_size : 0.0;
+  for(int t = 0; t < NGRAVS_NTYPES; t++)
+    {
+      wp->fsoft[t] = cfg.force_softening[t];
+      wp->t2g[t] = cfg.type_to_grav[t];
+    }
+  for(int i = 0; i < NG_MAX; i++)
+    for(int j = 0; j < NG_MAX; j++)
+      {
+        int law = (i < cfg.n_gravs && j < cfg.n_gravs) ? cfg.law_accel[i][j] : NGRAVS_LAW_NONE;
+        int spl = (i < cfg.n_gravs && j < cfg.n_gravs) ? cfg.law_spline[i][j] : NGRAVS_SPLINE_NONE;
+        wp->cN[i][j] = law == NGRAVS_LAW_NEWTON || law == NGRAVS_LAW_COLOYUK ? 1.0 : (law == NGRAVS_LAW_NEG_NEWTON ? -1.0 : 0.0);
+        wp->cY[i][j] = law == NGRAVS_LAW_YUKAWA || law == NGRAVS_LAW_COLOYUK ? 1.0 : 0.0;
+        wp->cS[i][j] = spl == NGRAVS_SPLINE_PLUMMER ? 1.0 : (spl == NGRAVS_SPLINE_NEG_PLUMMER ? -1.0 : 0.0);
+      }
+}
+
+static void make_law_ids(const ngravs_ctx *c, LawIds *li)
+{
+  memset(li, 0, sizeof(*li));
+  for(int i = 0; i < c->cfg.n_gravs; i++)
+    for(int j = 0; j < c->cfg.n_gravs; j++)
+      {
+        li->accel[i][j] = c->cfg.law_accel[i][j];
+        li->spline[i][j] = c->cfg.law_spline[i][j];
+      }
+}
+
+static bool has_yukawa(const ngravs_ctx *c)
+{
+  for(int i = 0; i < c->cfg.n_gravs; i++)
+    for(int j = 0; j < c->cfg.n_gravs; j++)
+      if(c->cfg.law_accel[i][j] == NGRAVS_LAW_YUKAWA || c->cfg.law_accel[i][j] == NGRAVS_LAW_COLOYUK)
+        return true;
+  return false;
+}
+
+static TreeView tree_view(ngravs_ctx *c)
+{
+  TreeView tv;
+  tv.first = c->n_first.p;
+  tv.count = c->n_count.p;
+  tv.child = c->n_child.p;
+  tv.flags = c->n_flags.p;
+  tv.geo = c->n_geo.p;
+  tv.mom = c->n_mom.p;
+  tv.nnodes = (int)c->nnodes;
+  return tv;
+}
+
+template <int NG, bool PM> static void launch_strict(ngravs_ctx *c, const WalkParams &wp, const LawIds &li)
+{
+  long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  unsigned nb = (unsigned)((ngroups + 3) / 4);
+  hipLaunchKernelGGL((k_walk_strict<NG, PM>), dim3(nb), dim3(256), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
+                     c->s_oldacc.p, c->s_active.p, c->table.p, wp, li, (long long)c->shard_first,
+                     (long long)c->shard_count, c->r_acc.p, c->r_nint.p);
+}
+
+template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngravs_ctx *c, const WalkParams &wp)
+{
+  int ncu = 256;
+  hipDeviceProp_t prop;
+  if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+    ncu = prop.multiProcessorCount;
+  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP;
+  int per_cu = (int)((160 * 1024) / lds);
+  if(per_cu < 1)
+    per_cu = 1;
+  if(per_cu > 4)
+    per_cu = 4;
+  long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  long long nblk = (long long)ncu * per_cu;
+  if(nblk > (ngroups + GW_WAVES - 1) / GW_WAVES)
+    nblk = (ngroups + GW_WAVES - 1) / GW_WAVES;
+  if(nblk < 1)
+    nblk = 1;
+  if(c->walk_stack.ensure((size_t)nblk * GW_WAVES * GW_STACK) || c->d_counters.ensure(16))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(int) * 16, c->stream));
+  auto kern = k_walk_group<NG, PM, YUK, TAB_LDS>;
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(GW_WAVES * 64), lds, c->stream, tree_view(c), c->s_pm.p,
+                     c->s_type.p, c->s_oldacc.p, c->s_active.p, c->table.p, wp, (long long)c->shard_first,
+                     (long long)c->shard_count, c->d_counters.p, c->walk_stack.p, c->d_counters.p + 1, c->r_acc.p,
+                     c->r_nint.p);
+  return NGRAVS_OK;
+}
+
+template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp)
+{
+  const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
+  constexpr bool TL = (NG <= 2);   // NG=3: 144 KB of tables do not fit beside the lists -> read through L1/L2
+  if(pm)
+    return yuk ? launch_group_t<NG, true, true, TL>(c, wp) : launch_group_t<NG, true, false, TL>(c, wp);
+  return yuk ? launch_group_t<NG, false, true, false>(c, wp) : launch_group_t<NG, false, false, false>(c, wp);
+}
+
+int walk_run(ngravs_ctx *c)
+{
+  const long long n = c->n;
+  if(c->r_acc.ensure(3 * n) || c->r_nint.ensure(n) || c->r_oldacc.ensure(n))
+    return NGRAVS_ERR_NOMEM;
+  if(c->cfg.periodic && !c->cfg.pmgrid)
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "PERIODIC without PMGRID (Ewald lattice correction, forcetree.c:2077) is not built yet");
+      return NGRAVS_ERR_ARG;
+    }
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  LawIds li;
+  make_law_ids(c, &li);
+  HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
+  const bool pm = c->cfg.pmgrid != 0;
+  HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
+  int rc = NGRAVS_OK;
+  if(c->cfg.walk_mode == NGRAVS_WALK_STRICT)
+    {
+      switch(c->cfg.n_gravs)
+        {
+        case 1:
+          pm ? launch_strict<1, true>(c, wp, li) : launch_strict<1, false>(c, wp, li);
+          break;
+        case 2:
+          pm ? launch_strict<2, true>(c, wp, li) : launch_strict<2, false>(c, wp, li);
+          break;
+        default:
+          pm ? launch_strict<3, true>(c, wp, li) : launch_strict<3, false>(c, wp, li);
+          break;
+        }
+    }
+  else
+    {
+      switch(c->cfg.n_gravs)
+        {
+        case 1:
+          rc = launch_group<1>(c, wp);
+          break;
+        case 2:
+          rc = launch_group<2>(c, wp);
+          break;
+        default:
+          rc = launch_group<3>(c, wp);
+          break;
+        }
+    }
+  if(rc != NGRAVS_OK)
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
+  HIP_TRY(c, hipGetLastError());
+  if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
+    {
+      int flag = 0;
+      HIP_TRY(c, hipMemcpyAsync(&flag, c->d_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if(flag)
+        {
+          ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");
+          return NGRAVS_ERR_TREE;
+        }
+    }
+  return NGRAVS_OK;
+}
+
+int walk_finish(ngravs_ctx *c)
+{
+  const int bs = 256;
+  unsigned nb = (unsigned)((c->shard_count + bs - 1) / bs);
+  if(nb == 0)
+    return NGRAVS_OK;
+  hipLaunchKernelGGL(k_finish, dim3(nb), dim3(bs), 0, c->stream, (long long)c->shard_first, (long long)c->shard_count,
+                     c->s_active.p, c->r_acc.p, c->r_pm.p, c->r_oldacc.p, c->cfg.G, (c->have_pm && c->cfg.pmgrid) ? 1 : 0);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc)
+{
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  LawIds li;
+  make_law_ids(c, &li);
+  hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, (long long)c->n, d_idx,
+                     (long long)nt, wp, li, c->cfg.G, d_acc);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}

@@ -184,6 +184,11 @@ int ngravs_get_domain(ngravs_ctx *ctx, double out[8]);
 int ngravs_get_keys(ngravs_ctx *ctx, int64_t *keys, int on_device);
 /* Device-side Peano order: order[i] = original index of the i-th particle along the curve. */
 int ngravs_get_order(ngravs_ctx *ctx, int32_t *order, int on_device);
+/* Target shard of this rank: positions [first, first+count) of the Peano order (the role of
+ * DomainMyStart/DomainMyLast, domain.c:347-456).  Results outside the shard are zero. */
+int ngravs_get_shard(ngravs_ctx *ctx, int64_t *first, int64_t *count);
+/* Text of the last error reported through the fatal handler. */
+const char *ngravs_last_error(ngravs_ctx *ctx);
 
 /* ---- stand-alone pieces of the path ------------------------------------------------------- */
 /* peano_hilbert_key(x,y,z,bits) (peano.c:356-398), host. */

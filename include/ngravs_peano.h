@@ -30,12 +30,10 @@ static inline NGRAVS_HD int64_t ngravs_ph_key_tab(const unsigned short (*step)[8
   return key;
 }
 
-#if !defined(__HIP_DEVICE_COMPILE__)
 static const unsigned short ngravs_ph_step_host[48][8] = NGRAVS_PH_STEP_INIT;
 static inline int64_t ngravs_ph_key(int x, int y, int z, int bits)
 {
   return ngravs_ph_key_tab(ngravs_ph_step_host, x, y, z, bits);
 }
-#endif
 
 #endif
