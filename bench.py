@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the gravity path (tree + PM) on MI355X.
+
+Workload at N=1 (BASELINE.json configs[3], the configuration the metric is quoted on): 2^26 = 64 M
+particles in a periodic box, N_GRAVS=2 (diagonal Newton, off-diagonal Newton+Yukawa "coloyuk",
+YUKAWA_IMASS=60; SURVEY.md 8(d) wiring for C4), TreePM with PMGRID=512, ASMTH=1.25, RCUT=4.5,
+NTAB=2048, softening eps = L/(40 N^(1/3)), ErrTolForceAcc=0.005 with the relative opening criterion
+(the steady-state second pass of accel.c:48-52; OldAcc comes from an untimed theta=0.5 pass).
+
+A "step" is one compute_accelerations(): domain extent + Peano keys + sort (domain_Decomposition),
+pmforce_periodic, force_treebuild, gravity_tree (walk + OldAcc/G post-processing) for ALL particles,
+inputs already resident in HBM.  value = particles * steps / wall time (max over ranks).
+
+  --gpus N : one process per GPU (torch.distributed / RCCL only for the barrier and the max-reduce).
+             Every rank holds the full particle set; the tree walk -- >= 90 % of the step -- is sharded
+             into N contiguous Peano segments (strong scaling, no data-path collective);
+             decomposition, tree build and PM are still replicated this round (DESIGN.md "Multi-GPU").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK = 8.0e12     # B/s, MI355X_MICROARCH.md
+
+
+def walk_alg_bytes(n_gravs):
+    # target 44 + result 28 + every source record once 36 + 0.5*(48+32g)
+    return 108 + 0.5 * (48 + 32 * n_gravs)
+
+
+def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
+    g = n_gravs
+    b = 96 + (36 + 0.5 * (48 + 32 * g)) + walk_alg_bytes(g)
+    if pm:
+        b += 88 + 64 * g * cells_per_particle
+    return b
+
+
+def make_box(pkg, n, L, n_gravs, seed):
+    rng = np.random.default_rng(seed)
+    chunk = 1 << 22
+    pos = np.empty((n, 3), dtype=np.float64)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        p = rng.uniform(0.0, L, (e - s, 3)).astype(np.float32)
+        p[p >= L] = np.nextafter(np.float32(L), np.float32(0))
+        pos[s:e] = p
+    mass = np.full(n, 1.0 / n)
+    ptype = (1 + (np.arange(n) % n_gravs)).astype(np.int32)
+    return pos, mass, ptype
+
+
+def host_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(float(q) / float(p) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / p + 0.5)))
+        except Exception:
+            pass
+    if "NGRAVS_CPU_CORES" in os.environ:
+        n = int(os.environ["NGRAVS_CPU_CORES"])
+    return n
+
+
+def cpu_baseline(pkg, n_gravs, wiring, cells_per_particle):
+    """The oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload:
+    same density per PM cell, same wiring, same criterion; all host cores for the walk and PM (OpenMP),
+    serial insertion tree build as in the reference."""
+    O = ge.load_oracle()
+    n, pmgrid, L = 1 << 19, 64, 1.0
+    while (pmgrid * 2) ** 3 <= n * cells_per_particle:
+        pmgrid *= 2
+    ncores = host_cores()
+    pos, mass, ptype = make_box(pkg, n, L, n_gravs, 4242)
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=n_gravs, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(n_gravs), wiring=wiring)
+    tab, _ = O.shortrange_table(cfg)
+    # untimed first pass (theta) to obtain OldAcc
+    dom = O.domain_extent(pos)
+    T = O.Tree(cfg, pos, mass, ptype, dom)
+    pm = O.pm_periodic(cfg, pos, mass, ptype)
+    a, _ = T.walk(table=tab, nthreads=ncores)
+    _, old = O.finish(cfg, a, pm)
+    T.close()
+    cfg.err_tol_theta = 0.0
+    # timed steady-state step: decomposition + order, PM, tree build, walk
+    t0 = time.time()
+    dom = O.domain_extent(pos)
+    key = O.keys(pos, dom)
+    order = O.peano_order(cfg, key, ptype)
+    p2, m2, t2, o2 = pos[order], mass[order], ptype[order], old[order]
+    t1 = time.time()
+    pm = O.pm_periodic(cfg, p2, m2, t2)
+    t2_ = time.time()
+    T = O.Tree(cfg, p2, m2, t2, dom)
+    t3 = time.time()
+    a, nint = T.walk(old_acc=o2, table=tab, nthreads=ncores)
+    O.finish(cfg, a, pm)
+    t4 = time.time()
+    T.close()
+    total = t4 - t0
+    return {
+        "value": n / total, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
+        "sample": "2^19 particles, PMGRID=%d (same %g cells/particle, wiring, eps/spacing, relative criterion); "
+                  "phases s: domain+order %.2f pm %.2f build %.2f walk %.2f; ia/part %.1f; walk %.3g interactions/s/core"
+                  % (pmgrid, cells_per_particle, t1 - t0, t2_ - t1, t3 - t2_, t4 - t3, float(nint.mean()),
+                     float(nint.sum()) / (t4 - t3) / ncores),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2n", type=int, default=26, help="log2 of the particle number (26 = the 64M headline)")
+    ap.add_argument("--pmgrid", type=int, default=0, help="0 = 2 cells per particle (512 at 64M)")
+    ap.add_argument("--ngravs", type=int, default=2)
+    ap.add_argument("--wiring", default="c4")
+    ap.add_argument("--walk", default="group", choices=["group", "strict"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    if not os.path.exists(pkg.LIB_PATH):
+        if rank == 0:
+            ge.build()
+        if world > 1:
+            dist.barrier()
+
+    n = 1 << args.log2n
+    L = 1.0
+    pmgrid = args.pmgrid
+    if pmgrid == 0:
+        pmgrid = 16
+        while (pmgrid * 2) ** 3 <= 2 * n:      # largest power of two with <= 2 cells per particle (512 at 2^26)
+            pmgrid *= 2
+    cells_per_particle = pmgrid ** 3 / n
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=args.ngravs, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5,
+                          err_tol_force_acc=0.005, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(args.ngravs), wiring=args.wiring,
+                          walk_mode=pkg.WALK_GROUP if args.walk == "group" else pkg.WALK_STRICT,
+                          device=local_rank, rank=rank, world_size=world)
+    pos, mass, ptype = make_box(pkg, n, L, args.ngravs, 12345)
+    dev = torch.device("cuda", local_rank)
+    d_pos = torch.from_numpy(pos).to(dev)
+    d_mass = torch.from_numpy(mass).to(dev)
+    d_type = torch.from_numpy(ptype).to(dev)
+    d_old = torch.zeros(n, dtype=torch.float64, device=dev)
+    del pos, mass, ptype
+    eng = pkg.Engine(cfg)
+    eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_type.data_ptr())
+    torch.cuda.synchronize()
+
+    # pass 1 (untimed): Barnes-Hut theta=0.5 with OldAcc=0, as the reference's first force computation
+    eng.compute_accelerations(pm_step=True)
+    if world > 1:
+        # every rank needs OldAcc of all particles only for ITS targets; its own shard is what it has
+        pass
+    eng.get_old_acc_device(d_old.data_ptr())
+    eng.set_old_acc_device(d_old.data_ptr())
+    eng.set_opening(0.0, 0.005)     # All.ErrTolTheta = 0 latch (gravtree.c:334-335)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.compute_accelerations(pm_step=True)
+    walk_ms, phases = [], []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.compute_accelerations(pm_step=True)
+        st = eng.stats()
+        walk_ms.append(st.walk_kernel_ms)
+        phases.append((st.t_domain + st.t_peano, st.t_pm, st.t_treebuild, st.t_treewalk))
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+    shard_first, shard_count = eng.shard()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = n * args.steps / dt
+        k_ms = float(np.mean(walk_ms))
+        alg = walk_alg_bytes(args.ngravs) * shard_count
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        ph = np.mean(np.array(phases), axis=0)
+        out = {
+            "metric": "particle-steps/s (tree+PM)", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C4: %d-particle uniform periodic box, N_GRAVS=%d (%s wiring: Newton + Yukawa), TreePM "
+                                   "PMGRID=%d, relative criterion ErrTolForceAcc=0.005, %s walk" %
+                                   (n, args.ngravs, args.wiring, pmgrid, args.walk),
+                       "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
+                       "parallelism": "walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world,
+                       "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
+                                     "treewalk": ph[3] * 1e3},
+                       "ia_per_particle": st.interactions / max(1, st.n_active), "tree_nodes": st.n_nodes,
+                       "step_algorithmic_bytes_per_particle": step_alg_bytes(args.ngravs, cells_per_particle),
+                       "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle) / HBM_PEAK},
+            "roofline": {"bound": "hbm", "kernel": "k_walk_group" if args.walk == "group" else "k_walk_strict",
+                         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, args.ngravs, args.wiring, cells_per_particle)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,6 +173,18 @@ class Engine:
         old_acc = np.ascontiguousarray(old_acc, dtype=np.float64)
         self._check(lib().ngravs_set_old_acc(self._h, old_acc.ctypes.data, 8, 0), "ngravs_set_old_acc")
 
+    def set_old_acc_device(self, ptr):
+        """OldAcc from a HIP device pointer (N contiguous doubles, caller order)"""
+        self._check(lib().ngravs_set_old_acc(self._h, ptr, 8, 1), "ngravs_set_old_acc")
+
+    def get_old_acc_device(self, ptr):
+        """write OldAcc (caller order) to a HIP device pointer"""
+        self._check(lib().ngravs_get_accel(self._h, None, 0, None, 0, ptr, 8, None, 0, 1), "ngravs_get_accel")
+
+    def get_accel_device(self, acc_ptr=None, pm_ptr=None, old_ptr=None, cost_ptr=None):
+        self._check(lib().ngravs_get_accel(self._h, acc_ptr, 24, pm_ptr, 24, old_ptr, 8, cost_ptr, 4, 1),
+                    "ngravs_get_accel")
+
     def set_opening(self, theta, err_tol_force_acc):
         self._check(lib().ngravs_set_opening(self._h, theta, err_tol_force_acc), "ngravs_set_opening")
         self.cfg.err_tol_theta = theta
