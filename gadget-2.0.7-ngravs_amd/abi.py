@@ -32,7 +32,7 @@ class Config(C.Structure):
         ("force_softening", C.c_double * NTYPES), ("type_to_grav", C.c_int32 * NTYPES),
         ("law_accel", _G3), ("law_spline", _G3), ("law_greens", _G3), ("law_normed", _G3),
         ("yukawa_imass", C.c_double), ("asmth", C.c_double), ("rcut", C.c_double),
-        ("tree_alloc_factor", C.c_double),
+        ("tree_alloc_factor", C.c_double), ("group_reach", C.c_double),
         ("walk_mode", C.c_int32), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
         ("reserved", C.c_int32 * 8),
     ]
@@ -61,7 +61,7 @@ class Stats(C.Structure):
 
 def make_config(n_gravs=1, periodic=0, pmgrid=0, box_size=0.0, G=1.0, theta=0.5, err_tol_force_acc=0.005,
                 softening=None, type_to_grav=None, wiring="newton", yukawa_imass=60.0, walk_mode=WALK_STRICT,
-                tree_alloc_factor=0.0, device=0, rank=0, world_size=1):
+                tree_alloc_factor=0.0, device=0, rank=0, world_size=1, group_reach=0.0):
     """Build a Config the way init_grav_maps()+wire_grav_maps() would (ngravs_core.c:201, ngravs.c:64).
 
     softening: Plummer-equivalent eps per type (SofteningTable); ForceSoftening = 2.8*eps (gravtree.c:514).
@@ -103,6 +103,7 @@ def make_config(n_gravs=1, periodic=0, pmgrid=0, box_size=0.0, G=1.0, theta=0.5,
             cfg.law_normed[i][j] = law
     cfg.yukawa_imass = float(yukawa_imass)
     cfg.tree_alloc_factor = float(tree_alloc_factor)
+    cfg.group_reach = float(group_reach)
     cfg.walk_mode = int(walk_mode)
     cfg.device = int(device)
     cfg.rank = int(rank)

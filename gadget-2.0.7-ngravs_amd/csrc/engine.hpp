@@ -70,6 +70,7 @@ template <typename T> struct DevBuf
 struct WalkParams
 {
   int ng, periodic, pm, use_theta;
+  int dbg;                  // NGRAVS_DEBUG bits: 1 = skip list evaluation (traversal-only timing)
   double box, boxhalf;
   double theta2;            // ErrTolTheta^2
   double errtol_acc;        // ErrTolForceAcc

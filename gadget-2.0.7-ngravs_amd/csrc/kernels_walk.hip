@@ -323,6 +323,30 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_WAVES 8
 #define GW_CAP 128          // interaction-list capacity per species per wave
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
+#define GW_PQ 128           // pending particle-leaf queue per wave (LDS)
+#define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
+
+// exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
+// (32-entry table in LDS: one 256-byte bank row, so distinct entries never conflict).  ~1 ulp.
+__device__ __forceinline__ double exp_neg_fast(double x, const double *__restrict__ T)
+{
+  const double inv = 46.16624130844683;                                   // 32/ln2
+  const double hi = 0.02166084938653512, lo = 5.9631716539705866e-12;      // ln2/32 = hi + lo, hi has 21 trailing zero bits
+  double m = __builtin_rint(x * inv);
+  double f = __builtin_fma(-m, hi, x);                                     // exact for m < 2^21
+  f = __builtin_fma(-m, lo, f);
+  int mi = (int)m;
+  double t = T[mi & 31];
+  double y = -f;                                                           // |y| <= ln2/64
+  double pz = 1.0 / 720.0;
+  pz = __builtin_fma(pz, y, 1.0 / 120.0);
+  pz = __builtin_fma(pz, y, 1.0 / 24.0);
+  pz = __builtin_fma(pz, y, 1.0 / 6.0);
+  pz = __builtin_fma(pz, y, 0.5);
+  pz = __builtin_fma(pz, y, 1.0);
+  pz = __builtin_fma(pz, y, 1.0);
+  return ldexp(t * pz, -(mi >> 5));
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -367,6 +391,12 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
   double4 *lpos = reinterpret_cast<double4 *>(smem + tab_bytes) + (size_t)wave * NG * GW_CAP;
   double *lh = reinterpret_cast<double *>(smem + tab_bytes + sizeof(double4) * GW_WAVES * NG * GW_CAP) +
                (size_t)wave * NG * GW_CAP;
+  double *expT = reinterpret_cast<double *>(smem + tab_bytes + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP);
+  int *pq = reinterpret_cast<int *>(expT + 32) + wave * GW_PQ;
+  if(threadIdx.x < 32)
+    expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
+  if(!(PM && TAB_LDS))
+    __syncthreads();
   if(PM && TAB_LDS)
     {
       for(int t = threadIdx.x; t < NG * NG * NTAB; t += blockDim.x)
@@ -432,6 +462,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
 #pragma unroll
       for(int g = 0; g < NG; g++)
         cnt[g] = 0;
+      int st_entries = 0, st_nodes = 0, st_batches = 0;   // walk statistics (per group, wave-uniform)
 
       // ---- stream the interaction lists through the force law --------------------------------
       auto flush = [&]() {
@@ -441,7 +472,8 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
           {
             const double4 *lp = lpos + g * GW_CAP;
             const double *hp = lh + g * GW_CAP;
-            const int n = cnt[g];
+            const int n = (wp.dbg & 1) ? 0 : cnt[g];
+            st_entries += cnt[g];
             for(int j = 0; j < n; j++)
               {
                 double4 e = lp[j];
@@ -456,30 +488,25 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                 double r2 = dx * dx + dy * dy + dz * dz;
                 if(PM && !(r2 < wp.reach2))
                   continue;
+                r2 = fmax(r2, 1e-290);                          // self / coincident pairs: finite, and d = 0 kills them
                 double rinv = __builtin_amdgcn_rsq(r2);
-                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);
-                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);
+                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);   // one Newton step: ~2^-51
                 double r = r2 * rinv;
-                if(!(r2 > 0))
-                  {
-                    r = 0;
-                    rinv = 0;
-                  }
+                r = __builtin_fma(0.5 * rinv, __builtin_fma(-r, r, r2), r);   // r = sqrt(r2) to ~1 ulp
                 double h = hT > hs ? hT : hs;
                 double fac;
                 int tab = 0;
                 if(PM)
                   {
                     tab = (int)(wp.asmthfac * r);
-                    if(tab >= NTAB)
-                      continue;
+                    tab = tab < NTAB - 1 ? tab : NTAB - 1;      // r < reach <= 6 asmth: only rounding can hit NTAB
                   }
                 if(r >= h)
                   {
                     double ri2 = rinv * rinv;
                     fac = cN[g] * ri2;
                     if(YUK)
-                      fac += cY[g] * exp(-r * wp.ym) * (wp.ym * rinv + ri2);
+                      fac += cY[g] * exp_neg_fast(r * wp.ym, expT) * (wp.ym * rinv + ri2);
                     if(PM)
                       fac -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
                     fac *= e.w * rinv;
@@ -551,6 +578,25 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
       };
 
       // ---- cooperative traversal ------------------------------------------------------------
+      // particle leaves are queued (indices) and fetched 64 at a time, so their loads are in flight together
+      int qn = 0;
+      auto drain = [&](int take) {
+        wave_sync();
+        bool pred = lane < take;
+        int p = pred ? pq[qn - take + lane] : 0;
+        qn -= take;
+        append_particle(pred, p);
+      };
+      auto enqueue = [&](bool pred, int p) {
+        unsigned long long mask = __ballot(pred ? 1 : 0);
+        if(mask == 0)
+          return;
+        if(qn + WAVE > GW_PQ)
+          drain(WAVE);
+        if(pred)
+          pq[qn + lane_prefix(mask)] = p;
+        qn += __popcll(mask);
+      };
       int sp = 1;
       if(lane == 0)
         stack[0] = 0;
@@ -560,13 +606,16 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
         {
           const int nb = sp < WAVE ? sp : WAVE;
           sp -= nb;
+          st_nodes += nb;
+          st_batches++;
           const int my = lane < nb ? stack[sp + lane] : -1;
           wave_sync();
-          // decision: 0 drop, 1 accept, 2 open (children), 3 open bucket
+          // decision: 0 drop, 1 accept, 2 open (children), 3 open as a leaf (all particles of the range)
           int dec = 0;
           double4 mom[NG];
           double hs_node = 0;
           int first = 0, count = 0;
+          int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
           if(my >= 0)
             {
               const double4 geo = tv.geo[my];
@@ -632,9 +681,17 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                     open = true;
                   if(open)
                     {
-                      dec = (fl & FLAG_BUCKET) ? 3 : 2;
                       first = tv.first[my];
                       count = tv.count[my];
+                      if((fl & FLAG_BUCKET) || count <= GW_NLEAF)
+                        dec = 3;
+                      else
+                        {
+                          dec = 2;
+                          const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
+                          ch_lo = cp[0];
+                          ch_hi = cp[1];
+                        }
                     }
                   else
                     dec = 1;
@@ -648,48 +705,50 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
               for(int g = 0; g < NG; g++)
                 append(g, dec == 1 && mom[g].w != 0.0, mom[g].x, mom[g].y, mom[g].z, mom[g].w, hs_node);
             }
-          // opened nodes: node children go back on the LIFO, particle children into the lists
+          // opened nodes: node children go back on the LIFO, particle children into the leaf queue
           if(__any(dec == 2))
             {
+              const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
+#pragma unroll
               for(int slot = 0; slot < 8; slot++)
                 {
-                  int ch = (dec == 2) ? tv.child[8 * (long long)my + slot] : -1;
-                  bool isnode = ch >= 0;
+                  const int ch = chv[slot];
+                  const bool isnode = ch >= 0;
                   unsigned long long mask = __ballot(isnode ? 1 : 0);
                   if(mask)
                     {
                       int npush = __popcll(mask);
                       if(sp + npush > GW_STACK)
+                        overflow = true;
+                      else
                         {
-                          overflow = true;
-                          break;
+                          if(isnode)
+                            stack[sp + lane_prefix(mask)] = ch;
+                          sp += npush;
                         }
-                      if(isnode)
-                        stack[sp + lane_prefix(mask)] = ch;
-                      sp += npush;
                     }
-                  bool ispart = ch <= -2;
-                  if(__any(ispart ? 1 : 0))
-                    append_particle(ispart, -2 - ch);
+                  enqueue(ch <= -2, -2 - ch);
                 }
               if(overflow)
                 break;
             }
-          // opened buckets (coincident keys at the deepest level): all their particles
+          // small or coincident-key nodes: all particles of the contiguous range
           if(__any(dec == 3))
             {
-              int k = 0;
-              for(;;)
+              for(int k = 0;; k++)
                 {
                   bool more = (dec == 3) && k < count;
                   if(!__any(more ? 1 : 0))
                     break;
-                  append_particle(more, first + k);
-                  k++;
+                  enqueue(more, first + k);
                 }
             }
+          while(qn >= WAVE)
+            drain(WAVE);
           wave_sync();
         }
+      if(!overflow && qn > 0)
+        drain(qn);
       if(overflow)
         {
           if(lane == 0)
@@ -697,6 +756,12 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
           continue;
         }
       flush();
+      if(lane == 0)
+        {
+          atomicAdd(&err_flag[1], st_entries);   // d_counters[2..4]: list entries, nodes tested, batches
+          atomicAdd(&err_flag[2], st_nodes);
+          atomicAdd(&err_flag[3], st_batches);
+        }
       if(valid)
         {
           r_acc[3 * ti + 0] = ax;
@@ -805,6 +870,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
   wp->periodic = cfg.periodic;
   wp->pm = cfg.pmgrid != 0;
   wp->use_theta = cfg.err_tol_theta != 0;
+  wp->dbg = getenv("NGRAVS_DEBUG") ? atoi(getenv("NGRAVS_DEBUG")) : 0;
   wp->box = cfg.box_size;
   wp->boxhalf = 0.5 * cfg.box_size;
   wp->theta2 = cfg.err_tol_theta * cfg.err_tol_theta;
@@ -816,6 +882,14 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
       wp->asmthfac = 0.5 / c->asmth * (NTAB / 3.0);          // forcetree.c:1708
       wp->utor2wpi = 1.0 / (M_PI * 4 * c->asmth * c->asmth);  // forcetree.c:1711
       double reach = NTAB / wp->asmthfac;                    // tabindex < NTAB  <=>  r < 6*asmth
+      if(cfg.walk_mode == NGRAVS_WALK_GROUP)
+        {
+          double ru = cfg.group_reach > 0 ? cfg.group_reach : NGRAVS_GROUP_REACH;
+          if(getenv("NGRAVS_GROUP_REACH"))
+            ru = atof(getenv("NGRAVS_GROUP_REACH"));
+          if(ru < 6.0)
+            reach = ru * c->asmth;
+        }
       wp->reach2 = reach * reach;
     }
   wp->ym = cfg.box_size > 0 ? cfg.yukawa_imass / cfg.box_size : 0.0;
@@ -883,7 +957,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngr
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP;
+  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP +
+               32 * sizeof(double) + sizeof(int) * GW_WAVES * GW_PQ;
   int per_cu = (int)((160 * 1024) / lds);
   if(per_cu < 1)
     per_cu = 1;
@@ -971,9 +1046,14 @@ int walk_run(ngravs_ctx *c)
   HIP_TRY(c, hipGetLastError());
   if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
     {
-      int flag = 0;
-      HIP_TRY(c, hipMemcpyAsync(&flag, c->d_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      unsigned int flags[4] = {0, 0, 0, 0};
+      HIP_TRY(c, hipMemcpyAsync(flags, c->d_counters.p + 1, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      int flag = (int)flags[0];
+      double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
+      c->stats.reserved[0] = flags[1] / ngroups;   // interaction-list entries per group (mod 2^32 wrap at huge N: diagnostic)
+      c->stats.reserved[1] = flags[2] / ngroups;   // nodes tested per group
+      c->stats.reserved[2] = flags[3] / ngroups;   // traversal batches per group
       if(flag)
         {
           ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");

@@ -43,6 +43,7 @@ extern "C" {
 #define NGRAVS_ASMTH 1.25       /* allvars.h:83                                                     */
 #define NGRAVS_RCUT 4.5         /* allvars.h:87                                                     */
 #define NGRAVS_BITS_PER_DIMENSION 18 /* allvars.h:34: bits of the reference Peano-Hilbert key      */
+#define NGRAVS_GROUP_REACH 4.5  /* default ngravs_config_t.group_reach = RCUT (DESIGN.md "Group walk cut")  */
 #define NGRAVS_TREE_BITS 21     /* bits/dim of the engine's internal tree key; key21>>9 == key18    */
 
 /* Force-law identifiers: the device cannot call through the reference's `gravity` function
@@ -105,6 +106,10 @@ typedef struct {
   double asmth;               /* All.Asmth[0] = ASMTH*BoxSize/PMGRID (pm_periodic.c:59); 0 => derive */
   double rcut;                /* All.Rcut[0]  = RCUT*Asmth (pm_periodic.c:60); 0 => derive       */
   double tree_alloc_factor;   /* All.TreeAllocFactor (nodes per particle), 0 => 0.8              */
+  double group_reach;         /* group walk only: radius, in units of Asmth, out to which short-range
+                                 forces are evaluated.  0 => NGRAVS_GROUP_REACH.  RCUT (4.5) is the
+                                 reference's nominal cut (allvars.h:87), 6.0 the end of its table
+                                 (tabindex < NTAB, forcetree.c:1962-1967).  The strict walk ignores it. */
   int32_t walk_mode;          /* ngravs_walk_mode                                                */
   int32_t device;             /* HIP device ordinal                                              */
   int32_t rank, world_size;   /* ThisTask, NTask: target shard = Peano segment `rank` of `world_size` */

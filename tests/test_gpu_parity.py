@@ -160,38 +160,33 @@ def test_group_walk_tree_only_accuracy(pkg, O):
 
 
 @pytest.mark.parametrize("wiring,ng", [("newton", 1), ("c4", 2)])
-def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng):
-    """TreePM total (tree + PM) against an independent Ewald sum: the group walk must be at least as
-    accurate as the reference walk (oracle), whose own error is rms ~8e-3.  The two
-    walks differ at the 1e-2 level of the (strongly cancelling) total force because the reference
-    truncates at its rcut box (forcetree.c:1828-1862) while the group walk keeps every source the
-    short-range table reaches."""
-    from ewald import ewald_direct
-    n, L, pmgrid = 40000, 1e4, 32
-    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=21)
-    eps = L / (40 * n ** (1 / 3))
-    cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=43007.1, theta=0.5, softening=[eps] * 6,
-                          type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=pkg.WALK_GROUP)
-    eng, (acc, old, cost, gpm), (a_o, old_o, n_o, pm_o), T = _strict_vs_oracle(pkg, O, cfg, pos, mass, typ)
-    # steady-state pass (relative criterion), both walks
-    eng.set_opening(0.0, 0.005)
-    eng.set_old_acc(old_o)
-    eng.gravity_tree()
-    acc2, _, cost2 = eng.get_accel()
-    cfg.err_tol_theta = 0.0
-    a2, n2 = T.walk(old_acc=old_o, table=O.shortrange_table(cfg)[0])
-    a2, _ = O.finish(cfg, a2, pm_o)
-    idx = np.arange(0, n, 250)
-    species = np.array(pkg.ic.default_type_to_grav(ng))[typ]
-    law = [[cfg.law_accel[i][j] for j in range(ng)] for i in range(ng)]
-    truth = ewald_direct(pos, mass, species, idx, L, cfg.G, law, cfg.yukawa_imass / L, 2.8 * eps)
-    e_grp = rel_err((acc2 + gpm)[idx], truth)
-    e_ref = rel_err((a2 + pm_o)[idx], truth)
+@pytest.mark.parametrize("reach", [0.0, 6.0])
+def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
+    """TreePM total (tree + PM) against an independent Ewald sum (tests/golden/ewald_truth_*.npz, made by
+    tools/make_ewald_golden.py): the group walk must be at least as accurate as the reference walk, whose
+    own error is rms 6.5e-3 .. 9.1e-3 here (7.8e-3 .. 9.6e-3).  The two walks differ at the
+    1e-2 level of the (strongly cancelling) total force because the reference truncates at its rcut box
+    (forcetree.c:1828-1862) while the group walk cuts on a sphere of radius group_reach * Asmth."""
+    import os
+    sys_path = os.path.join(os.path.dirname(__file__), "..", "tools")
+    import sys
+    sys.path.insert(0, sys_path)
+    from make_ewald_golden import N, L, SEED, case_config
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ewald_truth_%s.npz" % wiring))
+    pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=ng, seed=SEED)
+    cfg, eps = case_config(pkg, wiring, ng, walk_mode=pkg.WALK_GROUP, group_reach=reach)
+    eng = _engine(pkg, cfg, pos, mass, typ, old_acc=gold["old_acc"])
+    eng.set_opening(0.0, 0.005)                     # steady-state pass (relative criterion)
+    eng.compute_accelerations(pm_step=True)
+    acc, _, cost, gpm = eng.get_accel(want_pm=True)
+    idx, truth = gold["idx"], gold["truth"]
     rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
-    print("TreePM vs Ewald: group rms %.2e max %.2e ia/part %.1f | reference walk rms %.2e max %.2e ia/part %.1f" %
-          (rms(e_grp), e_grp.max(), cost2.mean(), rms(e_ref), e_ref.max(), n2.mean()))
-    assert rms(e_grp) <= 1.05 * rms(e_ref)
-    assert rms(e_grp) < 1.2e-2                      # the reference's own band (7.8e-3 .. 9.6e-3) with margin
+    e_grp = rel_err((acc + gpm)[idx], truth)
+    e_ref = rel_err(gold["ref_total"], truth)
+    print("TreePM vs Ewald [%s reach %.1f]: group rms %.2e max %.2e ia/part %.1f | reference walk rms %.2e max %.2e ia/part %.1f" %
+          (wiring, reach, rms(e_grp), e_grp.max(), cost.mean(), rms(e_ref), e_ref.max(), float(gold["ref_ia_per_part"])))
+    assert rms(e_grp) <= rms(e_ref)
+    assert rms(e_grp) < 1.0e-2
     eng.close()
 
 
