@@ -321,9 +321,9 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 //  group walk
 // =============================================================================================
 #define GW_WAVES 8
-#define GW_CAP 128          // interaction-list capacity per species per wave
+#define GW_CAP 96           // interaction-list capacity per species per wave (flushed when < 64 free)
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
-#define GW_PQ 128           // pending particle-leaf queue per wave (LDS)
+#define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x 8 items
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
     int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // layout: [table NG*NG*NTAB doubles (if TAB_LDS)] [per wave: NG*CAP double4 | NG*CAP double]
+  // LDS: [table NG*NG*NTAB doubles (if TAB_LDS)] [lists: per wave NG*CAP double4 | NG*CAP double] [exp table 32]
+  //      [item queue: per wave GW_PQ ints]
   double *tab_s = reinterpret_cast<double *>(smem);
   const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -395,17 +396,14 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
   int *pq = reinterpret_cast<int *>(expT + 32) + wave * GW_PQ;
   if(threadIdx.x < 32)
     expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
-  if(!(PM && TAB_LDS))
-    __syncthreads();
   if(PM && TAB_LDS)
-    {
-      for(int t = threadIdx.x; t < NG * NG * NTAB; t += blockDim.x)
-        tab_s[t] = table[t];
-      __syncthreads();
-    }
+    for(int t = threadIdx.x; t < NG * NG * NTAB; t += blockDim.x)
+      tab_s[t] = table[t];
+  __syncthreads();
   const double *tabp = (PM && TAB_LDS) ? tab_s : table;
   int *stack = stack_base + ((size_t)blockIdx.x * GW_WAVES + wave) * GW_STACK;
   const long long ngroups = (t_count + WAVE - 1) / WAVE;
+  const double BIG = 1e300;
 
   for(;;)
     {
@@ -442,7 +440,6 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
           cS[g] = wp.cS[tg][g];
         }
       // group bounding box and the conservative scalars
-      const double BIG = 1e300;
       double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
       double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
       double loz = wave_min(valid ? pz : BIG), hiz = wave_max(valid ? pz : -BIG);
@@ -464,157 +461,177 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
         cnt[g] = 0;
       int st_entries = 0, st_nodes = 0, st_batches = 0;   // walk statistics (per group, wave-uniform)
 
-      // ---- stream the interaction lists through the force law --------------------------------
-      auto flush = [&]() {
-        wave_sync();
-#pragma unroll
-        for(int g = 0; g < NG; g++)
+      // one list entry against this lane's target; branch-free on the common path so that two entries
+      // can be interleaved by the scheduler (only 2 waves per SIMD fit beside the LDS tables)
+      auto eval_one = [&](const int g, const double4 e, const double hs) {
+        double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
+        if(lanewrap)
           {
-            const double4 *lp = lpos + g * GW_CAP;
-            const double *hp = lh + g * GW_CAP;
-            const int n = (wp.dbg & 1) ? 0 : cnt[g];
-            st_entries += cnt[g];
-            for(int j = 0; j < n; j++)
-              {
-                double4 e = lp[j];
-                double hs = hp[j];
-                double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
-                if(lanewrap)
-                  {
-                    dx = nearest(dx, wp.box, wp.boxhalf);
-                    dy = nearest(dy, wp.box, wp.boxhalf);
-                    dz = nearest(dz, wp.box, wp.boxhalf);
-                  }
-                double r2 = dx * dx + dy * dy + dz * dz;
-                if(PM && !(r2 < wp.reach2))
-                  continue;
-                r2 = fmax(r2, 1e-290);                          // self / coincident pairs: finite, and d = 0 kills them
-                double rinv = __builtin_amdgcn_rsq(r2);
-                rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);   // one Newton step: ~2^-51
-                double r = r2 * rinv;
-                r = __builtin_fma(0.5 * rinv, __builtin_fma(-r, r, r2), r);   // r = sqrt(r2) to ~1 ulp
-                double h = hT > hs ? hT : hs;
-                double fac;
-                int tab = 0;
-                if(PM)
-                  {
-                    tab = (int)(wp.asmthfac * r);
-                    tab = tab < NTAB - 1 ? tab : NTAB - 1;      // r < reach <= 6 asmth: only rounding can hit NTAB
-                  }
-                if(r >= h)
-                  {
-                    double ri2 = rinv * rinv;
-                    fac = cN[g] * ri2;
-                    if(YUK)
-                      fac += cY[g] * exp_neg_fast(r * wp.ym, expT) * (wp.ym * rinv + ri2);
-                    if(PM)
-                      fac -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
-                    fac *= e.w * rinv;
-                  }
-                else
-                  {
-                    double h_inv = 1 / h, u = r * h_inv;
-                    double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
-                                         : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
-                                            0.066666666667 / (u * u * u));
-                    fac = cS[g] * e.w * h_inv * h_inv * h_inv * v;
-                  }
-                ax += dx * fac;
-                ay += dy * fac;
-                az += dz * fac;
-                nint++;
-              }
-            cnt[g] = 0;
+            dx = nearest(dx, wp.box, wp.boxhalf);
+            dy = nearest(dy, wp.box, wp.boxhalf);
+            dz = nearest(dz, wp.box, wp.boxhalf);
           }
-        wave_sync();
-      };
-      // append one entry per flagged lane to species list g (all lanes call this)
-      auto append = [&](int g, bool pred, double x, double y, double z, double m, double hs) {
-        unsigned long long mask = __ballot(pred ? 1 : 0);
-        if(mask == 0)
-          return;
-        if(pred)
+        double r2 = dx * dx + dy * dy + dz * dz;
+        const bool in = PM ? (r2 < wp.reach2) : true;
+        if(PM && !__any(in ? 1 : 0))
+          return;                                                       // no target of the group is in range
+        // self / coincident pairs stay finite (d = 0 kills them); masked lanes stay inside the table
+        r2 = fmax(r2, 1e-290);
+        if(PM)
+          r2 = fmin(r2, wp.reach2);
+        double rinv = __builtin_amdgcn_rsq(r2);
+        rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);                 // one Newton step: ~2^-51
+        double r = r2 * rinv;
+        r = __builtin_fma(0.5 * rinv, __builtin_fma(-r, r, r2), r);     // r = sqrt(r2) to ~1 ulp
+        const double ri2 = rinv * rinv;
+        double fac = cN[g] * ri2;
+        if(YUK)
+          fac += cY[g] * exp_neg_fast(r * wp.ym, expT) * (wp.ym * rinv + ri2);
+        if(PM)
           {
-            if(prewrap)
-              {
-                x = bcx + nearest(x - bcx, wp.box, wp.boxhalf);
-                y = bcy + nearest(y - bcy, wp.box, wp.boxhalf);
-                z = bcz + nearest(z - bcz, wp.box, wp.boxhalf);
-              }
-            int o = cnt[g] + lane_prefix(mask);
-            double4 e;
-            e.x = x;
-            e.y = y;
-            e.z = z;
-            e.w = m;
-            lpos[g * GW_CAP + o] = e;
-            lh[g * GW_CAP + o] = hs;
+            int tab = (int)(wp.asmthfac * r);
+            tab = tab < NTAB - 1 ? tab : NTAB - 1;                      // r <= cut <= 6 asmth: only rounding can hit NTAB
+            fac -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
           }
-        cnt[g] += __popcll(mask);
-      };
-      auto room = [&]() {   // make sure every list can take 64 more entries
-        bool full = false;
-#pragma unroll
-        for(int g = 0; g < NG; g++)
-          full |= (cnt[g] + WAVE > GW_CAP);
-        if(full)
-          flush();
-      };
-      auto append_particle = [&](bool pred, int p) {
-        double4 q;
-        int qt = 0;
-        q.x = q.y = q.z = q.w = 0;
-        if(pred)
+        fac *= e.w * rinv;
+        const double h = hT > hs ? hT : hs;
+        const bool soft = r < h;
+        if(__any((soft && in) ? 1 : 0))                                 // rare: inside the softening radius
           {
-            q = s_pm[p];
-            qt = s_type[p];
+            double h_inv = 1 / h, u = r * h_inv;
+            double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
+                                 : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
+                                    0.066666666667 / (u * u * u));
+            double fs = cS[g] * e.w * h_inv * h_inv * h_inv * v;
+            fac = soft ? fs : fac;
           }
-        int sg = wp.t2g[qt];
-        double hs = wp.fsoft[qt];
-        room();
-#pragma unroll
-        for(int g = 0; g < NG; g++)
-          append(g, pred && sg == g, q.x, q.y, q.z, q.w, hs);
+        fac = in ? fac : 0.0;
+        ax = __builtin_fma(dx, fac, ax);
+        ay = __builtin_fma(dy, fac, ay);
+        az = __builtin_fma(dz, fac, az);
+        nint += in ? 1 : 0;
       };
 
-      // ---- cooperative traversal ------------------------------------------------------------
-      // particle leaves are queued (indices) and fetched 64 at a time, so their loads are in flight together
-      int qn = 0;
-      auto drain = [&](int take) {
-        wave_sync();
-        bool pred = lane < take;
-        int p = pred ? pq[qn - take + lane] : 0;
-        qn -= take;
-        append_particle(pred, p);
-      };
-      auto enqueue = [&](bool pred, int p) {
-        unsigned long long mask = __ballot(pred ? 1 : 0);
-        if(mask == 0)
-          return;
-        if(qn + WAVE > GW_PQ)
-          drain(WAVE);
-        if(pred)
-          pq[qn + lane_prefix(mask)] = p;
-        qn += __popcll(mask);
-      };
-      int sp = 1;
+      // ---- state machine: ONE flush site, ONE materialise site, ONE node-test site -------------------
+      //   items (LDS queue): p >= 0 particle p;  -1-(node*NG+g) monopole of species g of a node
+      int qn = 0, sp = 1;
       if(lane == 0)
         stack[0] = 0;
       wave_sync();
-      bool overflow = false;
-      while(sp > 0)
+      bool overflow = false, done = false;
+      while(!done)
         {
+          const bool want_mat = (qn >= WAVE) || (sp == 0 && qn > 0);
+          const bool finished = (sp == 0 && qn == 0);
+          bool full = false;
+#pragma unroll
+          for(int g = 0; g < NG; g++)
+            full |= (cnt[g] + WAVE > GW_CAP);
+          if(finished || (want_mat && full))
+            {
+              // ---------------- flush: stream the lists through the force law ----------------
+              wave_sync();
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  const double4 *lp = lpos + g * GW_CAP;
+                  const double *hp = lh + g * GW_CAP;
+                  const int n = (wp.dbg & 1) ? 0 : cnt[g];
+                  st_entries += cnt[g];
+                  int j = 0;
+                  for(; j + 1 < n; j += 2)
+                    {
+                      const double4 e0 = lp[j], e1 = lp[j + 1];
+                      const double h0 = hp[j], h1 = hp[j + 1];
+                      eval_one(g, e0, h0);
+                      eval_one(g, e1, h1);
+                    }
+                  if(j < n)
+                    eval_one(g, lp[j], hp[j]);
+                  cnt[g] = 0;
+                }
+              wave_sync();
+              if(finished)
+                done = true;
+              continue;
+            }
+          if(want_mat)
+            {
+              // ---------------- materialise up to 64 queued items into the lists ----------------
+              wave_sync();
+              const int take = qn < WAVE ? qn : WAVE;
+              const bool have = lane < take;
+              const int item = have ? pq[qn - take + lane] : 0;
+              qn -= take;
+              double4 q;
+              q.x = q.y = q.z = q.w = 0;
+              int sg = 0;
+              double hs = 0;
+              if(have)
+                {
+                  if(item >= 0)
+                    {
+                      q = s_pm[item];
+                      int qt = s_type[item];
+                      sg = wp.t2g[qt];
+                      hs = wp.fsoft[qt];
+                    }
+                  else
+                    {
+                      int k = -1 - item;
+                      q = tv.mom[k];
+                      int nd = k / NG;
+                      sg = k - nd * NG;
+                      hs = wp.fsoft[(tv.flags[nd] >> 2) & 7];
+                    }
+                }
+              bool pred = have && q.w != 0.0;
+              double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
+              if(wp.periodic)
+                {
+                  ex = nearest(ex, wp.box, wp.boxhalf);
+                  ey = nearest(ey, wp.box, wp.boxhalf);
+                  ez = nearest(ez, wp.box, wp.boxhalf);
+                }
+              if(PM)
+                {
+                  // a source farther than the cut from the whole bounding box contributes to no target
+                  double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
+                  pred = pred && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+                }
+              if(prewrap)
+                {
+                  q.x = bcx + ex;
+                  q.y = bcy + ey;
+                  q.z = bcz + ez;
+                }
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  const bool pg = pred && sg == g;
+                  unsigned long long mask = __ballot(pg ? 1 : 0);
+                  if(pg)
+                    {
+                      int o = cnt[g] + lane_prefix(mask);
+                      lpos[g * GW_CAP + o] = q;
+                      lh[g * GW_CAP + o] = hs;
+                    }
+                  cnt[g] += __popcll(mask);
+                }
+              wave_sync();
+              continue;
+            }
+          // ---------------- test up to 64 pending nodes against the group's bounding box ----------------
           const int nb = sp < WAVE ? sp : WAVE;
           sp -= nb;
           st_nodes += nb;
           st_batches++;
           const int my = lane < nb ? stack[sp + lane] : -1;
           wave_sync();
-          // decision: 0 drop, 1 accept, 2 open (children), 3 open as a leaf (all particles of the range)
+          // decision: 0 drop, 1 accept (monopoles), 2 open (children), 3 open as a leaf (all particles of the range)
           int dec = 0;
-          double4 mom[NG];
-          double hs_node = 0;
           int first = 0, count = 0;
+          unsigned massmask = 0;
           int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
           if(my >= 0)
             {
@@ -625,9 +642,10 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
 #pragma unroll
               for(int g = 0; g < NG; g++)
                 {
-                  mom[g] = tv.mom[(long long)my * NG + g];
-                  summass += mom[g].w;
-                  double dx = mom[g].x - bcx, dy = mom[g].y - bcy, dz = mom[g].z - bcz;
+                  const double4 mom = tv.mom[(long long)my * NG + g];
+                  summass += mom.w;
+                  massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
+                  double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
                   if(wp.periodic)
                     {
                       dx = nearest(dx, wp.box, wp.boxhalf);
@@ -650,7 +668,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
               bool drop = (mst == 7);   // empty
               if(PM && !drop)
                 {
-                  // (i) nothing inside the cell can be within the table's reach of any target
+                  // (i) nothing inside the cell can be within the cut of any target
                   double half = 0.5 * len;
                   double q0 = fmax(0.0, fabs(wx) - bhx - half), q1 = fmax(0.0, fabs(wy) - bhy - half),
                          q2 = fmax(0.0, fabs(wz) - bhz - half);
@@ -676,7 +694,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                         open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
                                (fabs(cz) - bhz < 0.60 * len);
                     }
-                  hs_node = wp.fsoft[mst];
+                  const double hs_node = wp.fsoft[mst];
                   if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
                     open = true;
                   if(open)
@@ -697,15 +715,18 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                     dec = 1;
                 }
             }
-          // accepted monopoles
-          if(__any(dec == 1))
-            {
-              room();
+          // every tested node queues at most 8 items, and qn < 64 here: qn + 8*64 <= GW_PQ always holds
+          // accepted nodes: one monopole item per species with mass
 #pragma unroll
-              for(int g = 0; g < NG; g++)
-                append(g, dec == 1 && mom[g].w != 0.0, mom[g].x, mom[g].y, mom[g].z, mom[g].w, hs_node);
+          for(int g = 0; g < NG; g++)
+            {
+              const bool pg = dec == 1 && ((massmask >> g) & 1u);
+              unsigned long long mask = __ballot(pg ? 1 : 0);
+              if(pg)
+                pq[qn + lane_prefix(mask)] = -1 - (my * NG + g);
+              qn += __popcll(mask);
             }
-          // opened nodes: node children go back on the LIFO, particle children into the leaf queue
+          // opened nodes: node children back on the LIFO, particle children into the queue
           if(__any(dec == 2))
             {
               const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
@@ -727,40 +748,66 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                           sp += npush;
                         }
                     }
-                  enqueue(ch <= -2, -2 - ch);
+                  const bool ispart = ch <= -2;
+                  unsigned long long pmask = __ballot(ispart ? 1 : 0);
+                  if(ispart)
+                    pq[qn + lane_prefix(pmask)] = -2 - ch;
+                  qn += __popcll(pmask);
                 }
-              if(overflow)
-                break;
             }
-          // small or coincident-key nodes: all particles of the contiguous range
+          // small or coincident-key nodes: all particles of the contiguous range (first GW_NLEAF here, buckets below)
           if(__any(dec == 3))
             {
-              for(int k = 0;; k++)
+#pragma unroll
+              for(int k = 0; k < GW_NLEAF; k++)
                 {
-                  bool more = (dec == 3) && k < count;
-                  if(!__any(more ? 1 : 0))
-                    break;
-                  enqueue(more, first + k);
+                  const bool more = (dec == 3) && k < count;
+                  unsigned long long pmask = __ballot(more ? 1 : 0);
+                  if(more)
+                    pq[qn + lane_prefix(pmask)] = first + k;
+                  qn += __popcll(pmask);
+                }
+              // a bucket (coincident keys at the deepest level) may hold more than NLEAF particles: re-queue
+              // the remainder as a node test of its own is impossible, so feed it through the LIFO as
+              // (negative) range markers -- rare path, handled one wave-step at a time
+              bool big = (dec == 3) && count > GW_NLEAF;
+              while(__any(big ? 1 : 0))
+                {
+                  // serialise: the first such lane streams its remaining particles 64 at a time via the queue
+                  int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(big ? 1 : 0)));
+                  int bf = __shfl(first, src), bc = __shfl(count, src);
+                  for(int k0 = GW_NLEAF; k0 < bc; k0 += WAVE)
+                    {
+                      if(qn + WAVE > GW_PQ)
+                        {
+                          overflow = true;   // cannot happen for sane inputs (needs > GW_PQ coincident particles)
+                          break;
+                        }
+                      bool m2 = k0 + lane < bc;
+                      unsigned long long pm2 = __ballot(m2 ? 1 : 0);
+                      if(m2)
+                        pq[qn + lane_prefix(pm2)] = bf + k0 + lane;
+                      qn += __popcll(pm2);
+                    }
+                  if(lane == src)
+                    big = false;
                 }
             }
-          while(qn >= WAVE)
-            drain(WAVE);
+          if(overflow)
+            break;
           wave_sync();
         }
-      if(!overflow && qn > 0)
-        drain(qn);
-      if(overflow)
-        {
-          if(lane == 0)
-            atomicExch(err_flag, 1);
-          continue;
-        }
-      flush();
       if(lane == 0)
         {
           atomicAdd(&err_flag[1], st_entries);   // d_counters[2..4]: list entries, nodes tested, batches
           atomicAdd(&err_flag[2], st_nodes);
           atomicAdd(&err_flag[3], st_batches);
+        }
+      if(overflow)
+        {
+          if(lane == 0)
+            atomicExch(err_flag, 1);
+          continue;
         }
       if(valid)
         {
