@@ -81,6 +81,17 @@ def lib():
     return _LIB
 
 
+def shard_range(n, rank, world_size):
+    """Target shard of `rank`: positions [first, first+count) of the Peano order, cut on wave (64) boundaries so
+    that target groups are identical for every world size (mirrors ngravs_domain_decomposition in capi.hip; the
+    role of DomainMyStart/DomainMyLast after domain_findSplit, reference domain.c:347-456)."""
+    lo = (n * rank) // world_size
+    hi = (n * (rank + 1)) // world_size
+    lo = (lo // 64) * 64
+    hi = n if rank + 1 == world_size else (hi // 64) * 64
+    return lo, hi - lo
+
+
 def peano_hilbert_key(x, y, z, bits):
     """peano_hilbert_key() (reference peano.c:356-398), host implementation of the library."""
     return int(lib().ngravs_peano_hilbert_key(int(x), int(y), int(z), int(bits)))

@@ -278,6 +278,7 @@ def test_pm_persists_between_pm_steps_and_multi_shard(pkg, O):
         e.compute_accelerations(pm_step=True)
         a, _, c = e.get_accel()
         first, count = e.shard()
+        assert (first, count) == pkg.shard_range(n, r, 2)
         o = e.order()[first:first + count]
         parts.append((o, a))
         assert np.all(np.delete(a, o, axis=0) == 0)
