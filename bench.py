@@ -240,7 +240,7 @@ def main():
                                      "treewalk": ph[3] * 1e3},
                        "ia_per_particle": st.interactions / max(1, st.n_active), "tree_nodes": st.n_nodes,
                        "walk_list_entries_per_group": st.reserved[0], "walk_nodes_tested_per_group": st.reserved[1],
-                       "walk_batches_per_group": st.reserved[2],
+                       "walk_batches_per_group": st.reserved[2], "walk_force_iters_per_group": st.reserved[3],
                        "step_algorithmic_bytes_per_particle": step_alg_bytes(args.ngravs, cells_per_particle),
                        "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": "k_walk_group" if args.walk == "group" else "k_walk_strict",

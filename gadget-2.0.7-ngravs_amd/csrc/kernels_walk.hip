@@ -27,6 +27,7 @@
 // lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,
 // neg_newtonian, yukawa, coloyuk) and kernels are compiled per N_GRAVS and per "has Yukawa".
 #include "engine.hpp"
+#include <type_traits>
 
 #define FLAG_BUCKET 64
 #define WAVE 64
@@ -321,9 +322,11 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 //  group walk
 // =============================================================================================
 #define GW_WAVES 8
-#define GW_CAP 96           // interaction-list capacity per species per wave (flushed when < 64 free)
+#define GW_POOL 128         // interaction pool per wave: entries shared by the 8 sub-group lists (flushed when < 64 free)
+#define GW_SUBS 8           // sub-groups of 8 consecutive targets, each with its own (index) list into the pool
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
 #define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x 8 items
+#define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -389,11 +392,14 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
   double *tab_s = reinterpret_cast<double *>(smem);
   const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double4 *lpos = reinterpret_cast<double4 *>(smem + tab_bytes) + (size_t)wave * NG * GW_CAP;
-  double *lh = reinterpret_cast<double *>(smem + tab_bytes + sizeof(double4) * GW_WAVES * NG * GW_CAP) +
-               (size_t)wave * NG * GW_CAP;
-  double *expT = reinterpret_cast<double *>(smem + tab_bytes + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP);
-  int *pq = reinterpret_cast<int *>(expT + 32) + wave * GW_PQ;
+  // per wave: pool (positions+mass, source softening), sub-group bounding boxes, index lists, item queue
+  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW_WAVE_LDS(NG);
+  double *expT = reinterpret_cast<double *>(smem + tab_bytes);
+  double4 *lpos = reinterpret_cast<double4 *>(wbase);
+  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * GW_POOL);
+  double *sbb = lh + GW_POOL;                                        // [GW_SUBS][6]: centre xyz, half-width xyz
+  int *pq = reinterpret_cast<int *>(sbb + GW_SUBS * 6);
+  unsigned char *sl = reinterpret_cast<unsigned char *>(pq + GW_PQ);   // [NG][GW_SUBS][GW_POOL] pool indices
   if(threadIdx.x < 32)
     expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
   if(PM && TAB_LDS)
@@ -455,61 +461,116 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
 
       double ax = 0, ay = 0, az = 0;
       int nint = 0;
-      int cnt[NG];
+      int cnt[NG][GW_SUBS];   // wave-uniform lengths of the sub-group lists
 #pragma unroll
       for(int g = 0; g < NG; g++)
-        cnt[g] = 0;
-      int st_entries = 0, st_nodes = 0, st_batches = 0;   // walk statistics (per group, wave-uniform)
+#pragma unroll
+        for(int u = 0; u < GW_SUBS; u++)
+          cnt[g][u] = 0;
+      int npool = 0;
+      const int mysub = lane >> 3;
+      // bounding boxes of the 8 sub-groups (8 consecutive Peano targets each): what each list is culled against
+      {
+        double slx = valid ? px : BIG, shx = valid ? px : -BIG, sly = valid ? py : BIG, shy = valid ? py : -BIG,
+               slz = valid ? pz : BIG, shz = valid ? pz : -BIG;
+        for(int off = 4; off > 0; off >>= 1)
+          {
+            slx = fmin(slx, __shfl_xor(slx, off));
+            shx = fmax(shx, __shfl_xor(shx, off));
+            sly = fmin(sly, __shfl_xor(sly, off));
+            shy = fmax(shy, __shfl_xor(shy, off));
+            slz = fmin(slz, __shfl_xor(slz, off));
+            shz = fmax(shz, __shfl_xor(shz, off));
+          }
+        if((lane & 7) == 0)
+          {
+            const bool any = shx >= slx;                               // sub-group with no active target: unreachable box
+            sbb[mysub * 6 + 0] = any ? 0.5 * (slx + shx) : bcx;
+            sbb[mysub * 6 + 1] = any ? 0.5 * (sly + shy) : bcy;
+            sbb[mysub * 6 + 2] = any ? 0.5 * (slz + shz) : bcz;
+            sbb[mysub * 6 + 3] = any ? 0.5 * (shx - slx) : -BIG;
+            sbb[mysub * 6 + 4] = any ? 0.5 * (shy - sly) : -BIG;
+            sbb[mysub * 6 + 5] = any ? 0.5 * (shz - slz) : -BIG;
+          }
+      }
+      int st_entries = 0, st_nodes = 0, st_batches = 0, st_iters = 0;   // walk statistics (per group, wave-uniform)
 
-      // one list entry against this lane's target; branch-free on the common path so that two entries
-      // can be interleaved by the scheduler (only 2 waves per SIMD fit beside the LDS tables)
-      auto eval_one = [&](const int g, const double4 e, const double hs) {
-        double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
-        if(lanewrap)
+      // FOUR list entries against this lane's target, written as four independent straight-line streams
+      // (no branch on the common path) so that the scheduler overlaps their v_rsq / LDS-table latencies:
+      // only 2 waves per SIMD fit beside the LDS tables, the ILP has to come from here.
+      auto eval4 = [&](auto lw_tag, const int g, const double4 (&e)[4], const double (&hs)[4], const bool (&act)[4]) {
+        constexpr bool LW = decltype(lw_tag)::value;
+        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4];
+        bool in[4];
+        bool anyin = false;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
           {
-            dx = nearest(dx, wp.box, wp.boxhalf);
-            dy = nearest(dy, wp.box, wp.boxhalf);
-            dz = nearest(dz, wp.box, wp.boxhalf);
+            dx[k] = e[k].x - px;
+            dy[k] = e[k].y - py;
+            dz[k] = e[k].z - pz;
+            if(LW)
+              {
+                dx[k] = nearest(dx[k], wp.box, wp.boxhalf);
+                dy[k] = nearest(dy[k], wp.box, wp.boxhalf);
+                dz[k] = nearest(dz[k], wp.box, wp.boxhalf);
+              }
+            r2[k] = dx[k] * dx[k] + dy[k] * dy[k] + dz[k] * dz[k];
+            in[k] = act[k] && (PM ? (r2[k] < wp.reach2) : true);
+            anyin |= in[k];
           }
-        double r2 = dx * dx + dy * dy + dz * dz;
-        const bool in = PM ? (r2 < wp.reach2) : true;
-        if(PM && !__any(in ? 1 : 0))
-          return;                                                       // no target of the group is in range
-        // self / coincident pairs stay finite (d = 0 kills them); masked lanes stay inside the table
-        r2 = fmax(r2, 1e-290);
-        if(PM)
-          r2 = fmin(r2, wp.reach2);
-        double rinv = __builtin_amdgcn_rsq(r2);
-        rinv = rinv * (1.5 - 0.5 * r2 * rinv * rinv);                 // one Newton step: ~2^-51
-        double r = r2 * rinv;
-        r = __builtin_fma(0.5 * rinv, __builtin_fma(-r, r, r2), r);     // r = sqrt(r2) to ~1 ulp
-        const double ri2 = rinv * rinv;
-        double fac = cN[g] * ri2;
-        if(YUK)
-          fac += cY[g] * exp_neg_fast(r * wp.ym, expT) * (wp.ym * rinv + ri2);
-        if(PM)
+        if(!__any(anyin ? 1 : 0))
+          return;                                                       // none of the four reaches any target
+        bool anysoft = false;
+        bool soft[4];
+        double h[4];
+#pragma unroll
+        for(int k = 0; k < 4; k++)
           {
-            int tab = (int)(wp.asmthfac * r);
-            tab = tab < NTAB - 1 ? tab : NTAB - 1;                      // r <= cut <= 6 asmth: only rounding can hit NTAB
-            fac -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
+            // self / coincident pairs stay finite (d = 0 kills them); masked lanes are clamped at the table index
+            const double q2 = r2[k] + 1e-290;
+            double ri = __builtin_amdgcn_rsq(q2);
+            ri = ri * (1.5 - 0.5 * q2 * ri * ri);                         // one Newton step: ~2^-51
+            const double rr = q2 * ri;                                    // sqrt(r2) to ~2^-51
+            rinv[k] = ri;
+            r[k] = rr;
+            const double ri2 = ri * ri;
+            double f = cN[g] * ri2;
+            if(YUK)
+              f += cY[g] * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
+            if(PM)
+              {
+                int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
+                tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
+                f -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
+              }
+            fac[k] = f * e[k].w * ri;
+            h[k] = hT > hs[k] ? hT : hs[k];
+            soft[k] = in[k] && rr < h[k];
+            anysoft |= soft[k];
           }
-        fac *= e.w * rinv;
-        const double h = hT > hs ? hT : hs;
-        const bool soft = r < h;
-        if(__any((soft && in) ? 1 : 0))                                 // rare: inside the softening radius
+        if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
           {
-            double h_inv = 1 / h, u = r * h_inv;
-            double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
-                                 : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
-                                    0.066666666667 / (u * u * u));
-            double fs = cS[g] * e.w * h_inv * h_inv * h_inv * v;
-            fac = soft ? fs : fac;
+#pragma unroll
+            for(int k = 0; k < 4; k++)
+              {
+                double h_inv = 1 / h[k], u = r[k] * h_inv;
+                double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
+                                     : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
+                                        0.066666666667 / (u * u * u));
+                double fs = cS[g] * e[k].w * h_inv * h_inv * h_inv * v;
+                fac[k] = soft[k] ? fs : fac[k];
+              }
           }
-        fac = in ? fac : 0.0;
-        ax = __builtin_fma(dx, fac, ax);
-        ay = __builtin_fma(dy, fac, ay);
-        az = __builtin_fma(dz, fac, az);
-        nint += in ? 1 : 0;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+          {
+            const double f = in[k] ? fac[k] : 0.0;
+            ax = __builtin_fma(dx[k], f, ax);
+            ay = __builtin_fma(dy[k], f, ay);
+            az = __builtin_fma(dz[k], f, az);
+            nint += in[k] ? 1 : 0;
+          }
       };
 
       // ---- state machine: ONE flush site, ONE materialise site, ONE node-test site -------------------
@@ -523,33 +584,47 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
         {
           const bool want_mat = (qn >= WAVE) || (sp == 0 && qn > 0);
           const bool finished = (sp == 0 && qn == 0);
-          bool full = false;
-#pragma unroll
-          for(int g = 0; g < NG; g++)
-            full |= (cnt[g] + WAVE > GW_CAP);
+          const bool full = npool + WAVE > GW_POOL;
           if(finished || (want_mat && full))
             {
-              // ---------------- flush: stream the lists through the force law ----------------
+              // ---------------- flush: every sub-group streams ITS list through the force law ----------------
               wave_sync();
+              st_entries += npool;
 #pragma unroll
               for(int g = 0; g < NG; g++)
                 {
-                  const double4 *lp = lpos + g * GW_CAP;
-                  const double *hp = lh + g * GW_CAP;
-                  const int n = (wp.dbg & 1) ? 0 : cnt[g];
-                  st_entries += cnt[g];
-                  int j = 0;
-                  for(; j + 1 < n; j += 2)
+                  int mycnt = 0, n = 0;
+#pragma unroll
+                  for(int u = 0; u < GW_SUBS; u++)
                     {
-                      const double4 e0 = lp[j], e1 = lp[j + 1];
-                      const double h0 = hp[j], h1 = hp[j + 1];
-                      eval_one(g, e0, h0);
-                      eval_one(g, e1, h1);
+                      mycnt = (mysub == u) ? cnt[g][u] : mycnt;
+                      n = cnt[g][u] > n ? cnt[g][u] : n;
                     }
-                  if(j < n)
-                    eval_one(g, lp[j], hp[j]);
-                  cnt[g] = 0;
+                  if(wp.dbg & 1)
+                    n = 0;
+                  st_iters += n;
+                  const unsigned char *myl = sl + ((size_t)g * GW_SUBS + mysub) * GW_POOL;
+                  // four entries per trip: one 32-bit read brings four pool indices, the four entries are
+                  // fetched together, then evaluated -- the LDS latency of trip j+1 hides under trip j's math
+                  const unsigned int *myl4 = reinterpret_cast<const unsigned int *>(myl);
+                  for(int j = 0; j < n; j += 4)
+                    {
+                      const unsigned int w = (j < mycnt) ? myl4[j >> 2] : 0u;
+                      const bool act[4] = {j < mycnt, j + 1 < mycnt, j + 2 < mycnt, j + 3 < mycnt};
+                      const int i0 = act[0] ? (int)(w & 255u) : 0, i1 = act[1] ? (int)((w >> 8) & 255u) : 0,
+                                i2 = act[2] ? (int)((w >> 16) & 255u) : 0, i3 = act[3] ? (int)(w >> 24) : 0;
+                      const double4 e[4] = {lpos[i0], lpos[i1], lpos[i2], lpos[i3]};
+                      const double hh[4] = {lh[i0], lh[i1], lh[i2], lh[i3]};
+                      if(lanewrap)
+                        eval4(std::true_type{}, g, e, hh, act);
+                      else
+                        eval4(std::false_type{}, g, e, hh, act);
+                    }
+#pragma unroll
+                  for(int u = 0; u < GW_SUBS; u++)
+                    cnt[g][u] = 0;
                 }
+              npool = 0;
               wave_sync();
               if(finished)
                 done = true;
@@ -557,7 +632,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
             }
           if(want_mat)
             {
-              // ---------------- materialise up to 64 queued items into the lists ----------------
+              // ---------------- materialise up to 64 queued items into the pool + sub-group lists ----------------
               wave_sync();
               const int take = qn < WAVE ? qn : WAVE;
               const bool have = lane < take;
@@ -585,7 +660,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                       hs = wp.fsoft[(tv.flags[nd] >> 2) & 7];
                     }
                 }
-              bool pred = have && q.w != 0.0;
+              const bool live = have && q.w != 0.0;
               double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
               if(wp.periodic)
                 {
@@ -593,31 +668,48 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                   ey = nearest(ey, wp.box, wp.boxhalf);
                   ez = nearest(ez, wp.box, wp.boxhalf);
                 }
-              if(PM)
+              // which sub-groups can this source reach?  (tree-only: all of them)
+              unsigned hits = 0;
+#pragma unroll
+              for(int u = 0; u < GW_SUBS; u++)
                 {
-                  // a source farther than the cut from the whole bounding box contributes to no target
-                  double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
-                  pred = pred && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+                  bool hit = live;
+                  if(PM)
+                    {
+                      // offset from the sub-box centre = offset from the group centre - (sub centre - group centre)
+                      double b0 = fmax(0.0, fabs(ex - (sbb[u * 6 + 0] - bcx)) - sbb[u * 6 + 3]);
+                      double b1 = fmax(0.0, fabs(ey - (sbb[u * 6 + 1] - bcy)) - sbb[u * 6 + 4]);
+                      double b2 = fmax(0.0, fabs(ez - (sbb[u * 6 + 2] - bcz)) - sbb[u * 6 + 5]);
+                      hit = hit && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+                    }
+                  hits |= hit ? (1u << u) : 0u;
                 }
-              if(prewrap)
+              const bool pred = hits != 0;
+              const unsigned long long amask = __ballot(pred ? 1 : 0);
+              const int slot = npool + lane_prefix(amask);
+              if(pred)
                 {
-                  q.x = bcx + ex;
-                  q.y = bcy + ey;
-                  q.z = bcz + ez;
+                  if(prewrap)
+                    {
+                      q.x = bcx + ex;
+                      q.y = bcy + ey;
+                      q.z = bcz + ez;
+                    }
+                  lpos[slot] = q;
+                  lh[slot] = hs;
                 }
+              npool += __popcll(amask);
 #pragma unroll
               for(int g = 0; g < NG; g++)
-                {
-                  const bool pg = pred && sg == g;
-                  unsigned long long mask = __ballot(pg ? 1 : 0);
-                  if(pg)
-                    {
-                      int o = cnt[g] + lane_prefix(mask);
-                      lpos[g * GW_CAP + o] = q;
-                      lh[g * GW_CAP + o] = hs;
-                    }
-                  cnt[g] += __popcll(mask);
-                }
+#pragma unroll
+                for(int u = 0; u < GW_SUBS; u++)
+                  {
+                    const bool pg = ((hits >> u) & 1u) && sg == g;
+                    const unsigned long long mask = __ballot(pg ? 1 : 0);
+                    if(pg)
+                      sl[((size_t)g * GW_SUBS + u) * GW_POOL + cnt[g][u] + lane_prefix(mask)] = (unsigned char)slot;
+                    cnt[g][u] += __popcll(mask);
+                  }
               wave_sync();
               continue;
             }
@@ -802,6 +894,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
           atomicAdd(&err_flag[1], st_entries);   // d_counters[2..4]: list entries, nodes tested, batches
           atomicAdd(&err_flag[2], st_nodes);
           atomicAdd(&err_flag[3], st_batches);
+          atomicAdd(&err_flag[4], st_iters);
         }
       if(overflow)
         {
@@ -1004,8 +1097,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngr
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + (sizeof(double4) + sizeof(double)) * GW_WAVES * NG * GW_CAP +
-               32 * sizeof(double) + sizeof(int) * GW_WAVES * GW_PQ;
+  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + 32 * sizeof(double) + GW_WAVES * GW_WAVE_LDS(NG);
   int per_cu = (int)((160 * 1024) / lds);
   if(per_cu < 1)
     per_cu = 1;
@@ -1093,14 +1185,15 @@ int walk_run(ngravs_ctx *c)
   HIP_TRY(c, hipGetLastError());
   if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
     {
-      unsigned int flags[4] = {0, 0, 0, 0};
-      HIP_TRY(c, hipMemcpyAsync(flags, c->d_counters.p + 1, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      unsigned int flags[5] = {0, 0, 0, 0, 0};
+      HIP_TRY(c, hipMemcpyAsync(flags, c->d_counters.p + 1, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       int flag = (int)flags[0];
       double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
       c->stats.reserved[0] = flags[1] / ngroups;   // interaction-list entries per group (mod 2^32 wrap at huge N: diagnostic)
       c->stats.reserved[1] = flags[2] / ngroups;   // nodes tested per group
       c->stats.reserved[2] = flags[3] / ngroups;   // traversal batches per group
+      c->stats.reserved[3] = flags[4] / ngroups;   // force-loop iterations per group (max sub-group list length, summed)
       if(flag)
         {
           ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");

