@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_POOL 128         // interaction pool per wave: entries shared by the 8 sub-group lists (flushed when < 64 free)
 #define GW_SUBS 8           // sub-groups of 8 consecutive targets, each with its own (index) list into the pool
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
-#define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x 8 items
+#define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x NLEAF items
 #define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
@@ -729,6 +729,14 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
             {
               const double4 geo = tv.geo[my];
               const int fl = tv.flags[my];
+              // fetched with the record, not after the decision: one dependent memory round trip less per batch
+              first = tv.first[my];
+              count = tv.count[my];
+              {
+                const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
+                ch_lo = cp[0];
+                ch_hi = cp[1];
+              }
               const double len = geo.w;
               double r2min = BIG, summass = 0;
 #pragma unroll
@@ -790,19 +798,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
                   if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
                     open = true;
                   if(open)
-                    {
-                      first = tv.first[my];
-                      count = tv.count[my];
-                      if((fl & FLAG_BUCKET) || count <= GW_NLEAF)
-                        dec = 3;
-                      else
-                        {
-                          dec = 2;
-                          const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
-                          ch_lo = cp[0];
-                          ch_hi = cp[1];
-                        }
-                    }
+                    dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
                   else
                     dec = 1;
                 }
@@ -825,7 +821,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
 #pragma unroll
               for(int slot = 0; slot < 8; slot++)
                 {
-                  const int ch = chv[slot];
+                  const int ch = (dec == 2) ? chv[slot] : -1;
                   const bool isnode = ch >= 0;
                   unsigned long long mask = __ballot(isnode ? 1 : 0);
                   if(mask)
