@@ -201,7 +201,8 @@ static int check_config(const ngravs_config_t *cfg, std::string &why)
             return NGRAVS_ERR_WIRING;
           }
         // Newton's third law probe F[i][j](1,1,0.5,3,1) == F[j][i](...) (ngravs_core.c:371-403)
-        if(cfg->law_accel[i][j] != cfg->law_accel[j][i] || cfg->law_spline[i][j] != cfg->law_spline[j][i])
+        if(cfg->law_accel[i][j] != cfg->law_accel[j][i] || cfg->law_spline[i][j] != cfg->law_spline[j][i] ||
+           cfg->law_normed[i][j] != cfg->law_normed[j][i] || cfg->law_greens[i][j] != cfg->law_greens[j][i])
           {
             why = "force-law table violates Newton's third law (ngravs_core.c:371-403)";
             return NGRAVS_ERR_WIRING;

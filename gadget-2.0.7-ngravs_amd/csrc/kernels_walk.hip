@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 // =============================================================================================
 //  group walk
 // =============================================================================================
-#define GW_WAVES 8
+#define GW_MAXWAVES 12      // waves per persistent workgroup: as many as fit beside the LDS tables (launch_group_t)
 #define GW_POOL 128         // interaction pool per wave: entries shared by the 8 sub-group lists (flushed when < 64 free)
 #define GW_SUBS 8           // sub-groups of 8 consecutive targets, each with its own (index) list into the pool
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
@@ -380,7 +380,7 @@ __device__ __forceinline__ double wave_max(double v)
 }
 
 template <int NG, bool PM, bool YUK, bool TAB_LDS>
-__global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
+__global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
     TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
     const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
@@ -390,7 +390,9 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
   // LDS: [table NG*NG*NTAB doubles (if TAB_LDS)] [lists: per wave NG*CAP double4 | NG*CAP double] [exp table 32]
   //      [item queue: per wave GW_PQ ints]
   double *tab_s = reinterpret_cast<double *>(smem);
-  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0;
+  // symmetric wiring (Newton's third law, checked by ngravs_create): NG(NG+1)/2 distinct tables are staged
+  constexpr int NTABS = NG * (NG + 1) / 2;
+  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   // per wave: pool (positions+mass, source softening), sub-group bounding boxes, index lists, item queue
   unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW_WAVE_LDS(NG);
@@ -403,11 +405,20 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
   if(threadIdx.x < 32)
     expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
   if(PM && TAB_LDS)
-    for(int t = threadIdx.x; t < NG * NG * NTAB; t += blockDim.x)
-      tab_s[t] = table[t];
+    for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
+      {
+        // unique pair index u -> (a <= b):  u = a*NG - a(a-1)/2 + (b-a)
+        int u = t / NTAB, a = 0;
+        while(u >= NG - a)
+          {
+            u -= NG - a;
+            a++;
+          }
+        tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
+      }
   __syncthreads();
   const double *tabp = (PM && TAB_LDS) ? tab_s : table;
-  int *stack = stack_base + ((size_t)blockIdx.x * GW_WAVES + wave) * GW_STACK;
+  int *stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * GW_STACK;
   const long long ngroups = (t_count + WAVE - 1) / WAVE;
   const double BIG = 1e300;
 
@@ -444,6 +455,19 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
           cN[g] = wp.cN[tg][g];
           cY[g] = wp.cY[tg][g];
           cS[g] = wp.cS[tg][g];
+        }
+      // this lane's table rows, one per source species
+      const double *tabrow[NG];
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        {
+          if(PM && TAB_LDS)
+            {
+              const int a = tg < g ? tg : g, b = tg < g ? g : tg;
+              tabrow[g] = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
+            }
+          else
+            tabrow[g] = tabp + ((size_t)tg * NG + g) * NTAB;
         }
       // group bounding box and the conservative scalars
       double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
@@ -542,7 +566,7 @@ __global__ __launch_bounds__(GW_WAVES * 64) void k_walk_group(
               {
                 int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
                 tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
-                f -= wp.utor2wpi * tabp[((size_t)tg * NG + g) * NTAB + tab];
+                f -= wp.utor2wpi * tabrow[g][tab];
               }
             fac[k] = f * e[k].w * ri;
             h[k] = hT > hs[k] ? hT : hs[k];
@@ -1093,24 +1117,30 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngr
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  size_t lds = ((PM && TAB_LDS) ? sizeof(double) * NG * NG * NTAB : 0) + 32 * sizeof(double) + GW_WAVES * GW_WAVE_LDS(NG);
-  int per_cu = (int)((160 * 1024) / lds);
-  if(per_cu < 1)
-    per_cu = 1;
-  if(per_cu > 4)
-    per_cu = 4;
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
+  // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
+  int waves = (int)((160 * 1024 - fixed) / GW_WAVE_LDS(NG));
+  int per_cu = 1;
+  if(waves > GW_MAXWAVES)
+    {
+      per_cu = waves / 8 > 4 ? 4 : waves / 8;
+      waves = 8;
+    }
+  if(waves < 1)
+    waves = 1;
+  size_t lds = fixed + (size_t)waves * GW_WAVE_LDS(NG);
   long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
   long long nblk = (long long)ncu * per_cu;
-  if(nblk > (ngroups + GW_WAVES - 1) / GW_WAVES)
-    nblk = (ngroups + GW_WAVES - 1) / GW_WAVES;
+  if(nblk > (ngroups + waves - 1) / waves)
+    nblk = (ngroups + waves - 1) / waves;
   if(nblk < 1)
     nblk = 1;
-  if(c->walk_stack.ensure((size_t)nblk * GW_WAVES * GW_STACK) || c->d_counters.ensure(16))
+  if(c->walk_stack.ensure((size_t)nblk * waves * GW_STACK) || c->d_counters.ensure(16))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(int) * 16, c->stream));
   auto kern = k_walk_group<NG, PM, YUK, TAB_LDS>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(GW_WAVES * 64), lds, c->stream, tree_view(c), c->s_pm.p,
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, c->table.p, wp, (long long)c->shard_first,
                      (long long)c->shard_count, c->d_counters.p, c->walk_stack.p, c->d_counters.p + 1, c->r_acc.p,
                      c->r_nint.p);
