@@ -150,9 +150,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    # rehearsal knobs (one-GPU box): NGRAVS_BENCH_BACKEND=gloo NGRAVS_BENCH_DEVICE=0 puts every rank on GPU 0
+    backend = os.environ.get("NGRAVS_BENCH_BACKEND", "nccl")
+    if "NGRAVS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["NGRAVS_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     pkg = ge.load_package()
     if not os.path.exists(pkg.LIB_PATH):
@@ -214,7 +221,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()

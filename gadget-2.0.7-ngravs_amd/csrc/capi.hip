@@ -446,11 +446,21 @@ static double ev_ms(ngravs_ctx *c)
   return ms;
 }
 
-extern "C" int ngravs_domain_decomposition(ngravs_ctx *c)
+static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
 {
   if(!c || !c->have_particles)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  // P[].GravPM survives between PM steps (it is only rewritten by pmforce_periodic): park it in caller order
+  // under the OLD Peano order before re-sorting, unless this step recomputes it anyway
+  if(c->have_pm && keep_pm)
+    {
+      if(c->pm_orig.ensure(3 * c->n))
+        return NGRAVS_ERR_NOMEM;
+      hipLaunchKernelGGL(k_unpermute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->r_pm.p, c->pm_orig.p);
+    }
+  else
+    c->have_pm = false;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   int rc = dom_find_extent(c);
   if(rc)
@@ -473,7 +483,6 @@ extern "C" int ngravs_domain_decomposition(ngravs_ctx *c)
   c->shard_count = hi - lo;
   c->have_order = true;
   c->have_tree = false;   // TreeReconstructFlag = 1 (domain.c:84)
-  // P[].GravPM survives between PM steps (it is only rewritten by pmforce_periodic): carry it into the new order
   if(c->have_pm)
     {
       if(c->r_pm.ensure(3 * c->n))
@@ -483,6 +492,8 @@ extern "C" int ngravs_domain_decomposition(ngravs_ctx *c)
     }
   return NGRAVS_OK;
 }
+
+extern "C" int ngravs_domain_decomposition(ngravs_ctx *c) { return domain_decomposition_impl(c, true); }
 
 extern "C" int64_t ngravs_force_treebuild(ngravs_ctx *c)
 {
@@ -567,9 +578,6 @@ extern "C" int ngravs_pmforce_periodic(ngravs_ctx *c)
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   if((rc = pm_run(c)))
     return rc;
-  if(c->pm_orig.ensure(3 * c->n))
-    return NGRAVS_ERR_NOMEM;
-  hipLaunchKernelGGL(k_unpermute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->r_pm.p, c->pm_orig.p);
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   c->stats.t_pm = ev_ms(c) * 1e-3;
   return NGRAVS_OK;
@@ -580,7 +588,7 @@ extern "C" int ngravs_compute_accelerations(ngravs_ctx *c, int pm_step)
   if(!c || !c->have_particles)
     return NGRAVS_ERR_STATE;
   int rc;
-  if((rc = ngravs_domain_decomposition(c)))
+  if((rc = domain_decomposition_impl(c, !(pm_step && c->cfg.pmgrid))))
     return rc;
   if(pm_step && c->cfg.pmgrid && (rc = ngravs_pmforce_periodic(c)))   // accel.c:34-42
     return rc;
