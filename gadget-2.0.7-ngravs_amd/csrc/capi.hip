@@ -285,6 +285,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->d_counters.release();
   c->table.release();
   c->walk_stack.release();
+  c->walk_counters.release();
   c->r_acc.release();
   c->r_pm.release();
   c->r_oldacc.release();

@@ -127,6 +127,7 @@ struct ngravs_ctx
   DevBuf<double> table;       // [ng][ng][NTAB] shortrange_fourier_force
   bool table_ready = false;
   DevBuf<int> walk_stack;     // per-wave scratch
+  DevBuf<int> walk_counters;  // [1] overflow flag, [2..5] walk statistics, [8..15] per-XCD group counters
   DevBuf<double> r_acc, r_pm, r_oldacc;
   DevBuf<int> r_nint;
   // pm

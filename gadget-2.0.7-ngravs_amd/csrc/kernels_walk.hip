@@ -422,16 +422,36 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
   const long long ngroups = (t_count + WAVE - 1) / WAVE;
   const double BIG = 1e300;
 
+  // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
+  // workgroup pulls groups from the segment of the XCD it runs on (neighbouring groups share most of their
+  // tree nodes and sources); an exhausted segment steals from the others.  Placement only affects speed.
+  unsigned xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const long long seg = (ngroups + 7) / 8;
+  int steal = 0;
   for(;;)
     {
-      int grp = 0;
-      if(lane == 0)
-        grp = atomicAdd(counter, 1);
-      grp = __builtin_amdgcn_readfirstlane(grp);
-      if(grp >= ngroups)
+      long long grp = -1;
+      while(steal < 8)
+        {
+          const int sx = (int)((xcc + steal) & 7u);
+          int k = 0;
+          if(lane == 0)
+            k = atomicAdd(&counter[8 + sx], 1);
+          k = __builtin_amdgcn_readfirstlane(k);
+          const long long g0 = seg * sx + k;
+          if(k < seg && g0 < ngroups)
+            {
+              grp = g0;
+              break;
+            }
+          steal++;
+        }
+      if(grp < 0)
         break;
-      const long long ti = t_first + (long long)grp * WAVE + lane;
-      const bool valid = ((long long)grp * WAVE + lane) < t_count && s_active[ti] != 0;
+      const long long ti = t_first + grp * WAVE + lane;
+      const bool valid = (grp * WAVE + lane) < t_count && s_active[ti] != 0;
       if(!__any(valid ? 1 : 0))
         continue;
       double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
@@ -1135,14 +1155,14 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngr
     nblk = (ngroups + waves - 1) / waves;
   if(nblk < 1)
     nblk = 1;
-  if(c->walk_stack.ensure((size_t)nblk * waves * GW_STACK) || c->d_counters.ensure(16))
+  if(c->walk_stack.ensure((size_t)nblk * waves * GW_STACK) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(c->d_counters.p, 0, sizeof(int) * 16, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kern = k_walk_group<NG, PM, YUK, TAB_LDS>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, c->table.p, wp, (long long)c->shard_first,
-                     (long long)c->shard_count, c->d_counters.p, c->walk_stack.p, c->d_counters.p + 1, c->r_acc.p,
+                     (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
                      c->r_nint.p);
   return NGRAVS_OK;
 }
@@ -1212,7 +1232,7 @@ int walk_run(ngravs_ctx *c)
   if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
     {
       unsigned int flags[5] = {0, 0, 0, 0, 0};
-      HIP_TRY(c, hipMemcpyAsync(flags, c->d_counters.p + 1, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(flags, c->walk_counters.p + 1, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       int flag = (int)flags[0];
       double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
