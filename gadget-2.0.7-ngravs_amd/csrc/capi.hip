@@ -576,6 +576,12 @@ extern "C" int ngravs_pmforce_periodic(ngravs_ctx *c)
   int rc;
   if(!c->have_order && (rc = ngravs_domain_decomposition(c)))   // domain.c:66-73: PM steps always re-decompose
     return rc;
+  if(!c->have_tree)   // the mesh patches of the tiled deposit / gather are the cells of one tree level
+    {
+      int64_t nn = ngravs_force_treebuild(c);
+      if(nn < 0)
+        return (int)nn;
+    }
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   if((rc = pm_run(c)))
     return rc;

@@ -116,12 +116,13 @@ __global__ void k_green(const double2 *__restrict__ rho, double2 *__restrict__ p
 
 // fused 4-point gradient at the 8 CIC corners + CIC gather (pm_periodic.c:681-763)
 __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
-                                  long long n, double to_slab, int N, const int *__restrict__ t2g_tab,
+                                  long long first, long long n, double to_slab, int N, const int *__restrict__ t2g_tab,
                                   const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
     return;
+  i += first;
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
   const long long NZ = N + 2;
@@ -151,6 +152,233 @@ __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsign
   r_pm[3 * i + 0] = acc[0];
   r_pm[3 * i + 1] = acc[1];
   r_pm[3 * i + 2] = acc[2];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Tiled variants.  The particles are Peano-sorted and the tree node of a level-Lt cell owns one contiguous
+// particle range, so one workgroup per node can deposit into / gather from an LDS copy of the mesh patch
+// the cell touches: the 8 scattered fp64 global atomics per particle (64 lanes -> 64 rows, the slow atomic
+// shape) become LDS atomics plus one coalesced atomic flush per patch row, and the gather's 72 scattered L2
+// reads per particle become LDS reads.  Particles that are direct children of nodes above level Lt (sparse
+// regions) go through the per-particle kernels.
+// ---------------------------------------------------------------------------------------------------
+#define PM_DT 18                     // deposit patch edge: 16-cell node + CIC neighbour + 1 slack
+#define PM_GT (PM_DT + 4)            // gather patch edge: +-2 for the 4-point gradient
+#define PM_TILE_THREADS 1024
+
+__device__ __forceinline__ int wrapN(int a, int N) { return a < 0 ? a + N : (a >= N ? a - N : a); }
+
+template <int NG>
+__global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
+    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const int *__restrict__ n_first,
+    const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0, double to_slab, int N,
+    const int *__restrict__ t2g_tab, double *__restrict__ rho)
+{
+  extern __shared__ double tile[];   // [NG][DT][DT][DT]
+  const int node = node0 + blockIdx.x;
+  const double4 geo = n_geo[node];
+  const int first = n_first[node], count = n_count[node];
+  const long long NZ = N + 2;
+  int o[3];
+  {
+    const double h = 0.5 * geo.w;
+    o[0] = (int)floor((geo.x - h) * to_slab);
+    o[1] = (int)floor((geo.y - h) * to_slab);
+    o[2] = (int)floor((geo.z - h) * to_slab);
+  }
+  for(int t = threadIdx.x; t < NG * PM_DT * PM_DT * PM_DT; t += blockDim.x)
+    tile[t] = 0.0;
+  __syncthreads();
+  for(int k = threadIdx.x; k < count; k += blockDim.x)
+    {
+      const int i = first + k;
+      const double4 p = s_pm[i];
+      const int g = t2g_tab[s_type[i]];
+      double dx, dy, dz;
+      const int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+      const int lx = sx - o[0], ly = sy - o[1], lz = sz - o[2];
+      const double m = p.w;
+      const double w[8] = {m * (1.0 - dx) * (1.0 - dy) * (1.0 - dz), m * (1.0 - dx) * dy * (1.0 - dz),
+                           m * (1.0 - dx) * (1.0 - dy) * dz,         m * (1.0 - dx) * dy * dz,
+                           m * (dx) * (1.0 - dy) * (1.0 - dz),       m * (dx)*dy * (1.0 - dz),
+                           m * (dx) * (1.0 - dy) * dz,               m * (dx)*dy * dz};   // pm_periodic.c:322-329
+      const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+      if(lx >= 0 && ly >= 0 && lz >= 0 && lx < PM_DT - 1 && ly < PM_DT - 1 && lz < PM_DT - 1)
+        {
+          double *tg = tile + (size_t)g * PM_DT * PM_DT * PM_DT;
+#pragma unroll
+          for(int c = 0; c < 8; c++)
+            atomicAdd(&tg[((lx + ox[c]) * PM_DT + (ly + oy[c])) * PM_DT + (lz + oz[c])], w[c]);
+        }
+      else
+        {
+          double *grid = rho + (size_t)g * N * N * NZ;   // outside the patch (cannot happen for in-cell particles): direct
+#pragma unroll
+          for(int c = 0; c < 8; c++)
+            atomicAdd(&grid[((long long)wrapN(sx + ox[c], N) * N + wrapN(sy + oy[c], N)) * NZ + wrapN(sz + oz[c], N)], w[c]);
+        }
+    }
+  __syncthreads();
+  for(int t = threadIdx.x; t < NG * PM_DT * PM_DT * PM_DT; t += blockDim.x)
+    {
+      const double v = tile[t];
+      if(v != 0.0)
+        {
+          const int g = t / (PM_DT * PM_DT * PM_DT), r = t % (PM_DT * PM_DT * PM_DT);
+          const int lx = r / (PM_DT * PM_DT), ly = (r / PM_DT) % PM_DT, lz = r % PM_DT;
+          atomicAdd(&rho[(size_t)g * N * N * NZ + ((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)], v);
+        }
+    }
+}
+
+// particles that hang directly off nodes above the tile level
+__global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                    const int *__restrict__ n_child, int nnodes_above, double to_slab, int N,
+                                    const int *__restrict__ t2g_tab, double *__restrict__ rho)
+{
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(t >= 8ll * nnodes_above)
+    return;
+  const int c = n_child[t];
+  if(c > -2)
+    return;
+  const int i = -2 - c;
+  double4 p = s_pm[i];
+  int g = t2g_tab[s_type[i]];
+  const long long NZ = N + 2;
+  double *grid = rho + (size_t)g * N * N * NZ;
+  double dx, dy, dz;
+  int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+  int sxx = sx + 1 == N ? 0 : sx + 1, syy = sy + 1 == N ? 0 : sy + 1, szz = sz + 1 == N ? 0 : sz + 1;
+  double m = p.w;
+  atomicAdd(&grid[((long long)sx * N + sy) * NZ + sz], m * (1.0 - dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[((long long)sx * N + syy) * NZ + sz], m * (1.0 - dx) * dy * (1.0 - dz));
+  atomicAdd(&grid[((long long)sx * N + sy) * NZ + szz], m * (1.0 - dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[((long long)sx * N + syy) * NZ + szz], m * (1.0 - dx) * dy * dz);
+  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + sz], m * (dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + sz], m * (dx)*dy * (1.0 - dz));
+  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + szz], m * (dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + szz], m * (dx)*dy * dz);
+}
+
+// gather: one workgroup per level-Lt node, one species at a time through an LDS copy of the potential patch
+template <int NG>
+__global__ __launch_bounds__(PM_TILE_THREADS) void k_gradient_gather_tiled(
+    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const int *__restrict__ n_first,
+    const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0, long long shard_first,
+    long long shard_count, double to_slab, int N, const int *__restrict__ t2g_tab, const double *__restrict__ phi,
+    double fac, double *__restrict__ r_pm)
+{
+  extern __shared__ double tile[];   // [GT][GT][GT]
+  const int node = node0 + blockIdx.x;
+  const int first = n_first[node], count = n_count[node];
+  if((long long)first + count <= shard_first || (long long)first >= shard_first + shard_count)
+    return;                                     // no target of this task in the cell (uniform per block)
+  const double4 geo = n_geo[node];
+  const long long NZ = N + 2;
+  int o[3];
+  {
+    const double h = 0.5 * geo.w;
+    o[0] = (int)floor((geo.x - h) * to_slab) - 2;
+    o[1] = (int)floor((geo.y - h) * to_slab) - 2;
+    o[2] = (int)floor((geo.z - h) * to_slab) - 2;
+  }
+  for(int g = 0; g < NG; g++)
+    {
+      const double *grid = phi + (size_t)g * N * N * NZ;
+      __syncthreads();
+      for(int t = threadIdx.x; t < PM_GT * PM_GT * PM_GT; t += blockDim.x)
+        {
+          const int lx = t / (PM_GT * PM_GT), ly = (t / PM_GT) % PM_GT, lz = t % PM_GT;
+          tile[t] = grid[((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)];
+        }
+      __syncthreads();
+      for(int k = threadIdx.x; k < count; k += blockDim.x)
+        {
+          const long long i = (long long)first + k;
+          if(i < shard_first || i >= shard_first + shard_count || t2g_tab[s_type[i]] != g)
+            continue;
+          const double4 p = s_pm[i];
+          double dx, dy, dz;
+          const int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+          const int lx = sx - o[0], ly = sy - o[1], lz = sz - o[2];
+          const bool inside = lx >= 2 && ly >= 2 && lz >= 2 && lx < PM_GT - 3 && ly < PM_GT - 3 && lz < PM_GT - 3;
+          const double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+          double acc[3] = {0, 0, 0};
+          const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+          auto at = [&](int x, int y, int z) -> double {
+            if(inside)
+              return tile[(x * PM_GT + y) * PM_GT + z];
+            return grid[((long long)wrapN(o[0] + x, N) * N + wrapN(o[1] + y, N)) * NZ + wrapN(o[2] + z, N)];
+          };
+          for(int c = 0; c < 8; c++)
+            {
+              const int x = lx + ox[c], y = ly + oy[c], z = lz + oz[c];
+              const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
+              const double fxv = fac * ((4.0 / 3) * (at(x - 1, y, z) - at(x + 1, y, z)) - (1.0 / 6) * (at(x - 2, y, z) - at(x + 2, y, z)));
+              const double fyv = fac * ((4.0 / 3) * (at(x, y - 1, z) - at(x, y + 1, z)) - (1.0 / 6) * (at(x, y - 2, z) - at(x, y + 2, z)));
+              const double fzv = fac * ((4.0 / 3) * (at(x, y, z - 1) - at(x, y, z + 1)) - (1.0 / 6) * (at(x, y, z - 2) - at(x, y, z + 2)));
+              acc[0] += fxv * w;
+              acc[1] += fyv * w;
+              acc[2] += fzv * w;
+            }
+          r_pm[3 * i + 0] = acc[0];
+          r_pm[3 * i + 1] = acc[1];
+          r_pm[3 * i + 2] = acc[2];
+        }
+    }
+}
+
+__global__ void k_gradient_gather_loose(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                        const int *__restrict__ n_child, int nnodes_above, long long shard_first,
+                                        long long shard_count, double to_slab, int N, const int *__restrict__ t2g_tab,
+                                        const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
+{
+  long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(t >= 8ll * nnodes_above)
+    return;
+  const int c = n_child[t];
+  if(c > -2)
+    return;
+  const long long i = -2 - c;
+  if(i < shard_first || i >= shard_first + shard_count)
+    return;
+  double4 p = s_pm[i];
+  int g = t2g_tab[s_type[i]];
+  const long long NZ = N + 2;
+  const double *grid = phi + (size_t)g * N * N * NZ;
+  double dx, dy, dz;
+  int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+  double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+  double acc[3] = {0, 0, 0};
+  auto at = [&](int x, int y, int z) { return grid[((long long)wrapN(x, N) * N + wrapN(y, N)) * NZ + wrapN(z, N)]; };
+  const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+  for(int cc = 0; cc < 8; cc++)
+    {
+      int x = sx + ox[cc], y = sy + oy[cc], z = sz + oz[cc];
+      double w = wx[ox[cc]] * wy[oy[cc]] * wz[oz[cc]];
+      double fxv = fac * ((4.0 / 3) * (at(x - 1, y, z) - at(x + 1, y, z)) - (1.0 / 6) * (at(x - 2, y, z) - at(x + 2, y, z)));
+      double fyv = fac * ((4.0 / 3) * (at(x, y - 1, z) - at(x, y + 1, z)) - (1.0 / 6) * (at(x, y - 2, z) - at(x, y + 2, z)));
+      double fzv = fac * ((4.0 / 3) * (at(x, y, z - 1) - at(x, y, z + 1)) - (1.0 / 6) * (at(x, y, z - 2) - at(x, y, z + 2)));
+      acc[0] += fxv * w;
+      acc[1] += fyv * w;
+      acc[2] += fzv * w;
+    }
+  r_pm[3 * i + 0] = acc[0];
+  r_pm[3 * i + 1] = acc[1];
+  r_pm[3 * i + 2] = acc[2];
+}
+
+// the level whose cells are at most 16 mesh cells wide (-1: no such level in this tree -> per-particle kernels)
+static int pm_tile_level(const ngravs_ctx *c, double to_slab)
+{
+  if(!c->have_tree || getenv("NGRAVS_PM_NOTILE"))
+    return -1;
+  double len = c->dom[6];
+  for(int l = 0; l < c->nlevels && l < TREE_BITS; l++, len *= 0.5)
+    if(len * to_slab <= 16.0)
+      return (c->level_start[l + 1] - c->level_start[l] > 0) ? l : -1;
+  return -1;
 }
 
 void pm_release(ngravs_ctx *c)
@@ -211,8 +439,27 @@ int pm_run(ngravs_ctx *c)
   HIP_TRY(c, hipMemsetAsync(c->pm_rho.p, 0, sizeof(double) * real_elems * ng, c->stream));
   const int bs = 256;
   unsigned nbp = (unsigned)((n + bs - 1) / bs);
-  hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N, ng,
-                     c->d_counters.p + 8, c->pm_rho.p);
+  const int tl = pm_tile_level(c, to_slab);
+  const long long tl0 = tl >= 0 ? c->level_start[tl] : 0, tln = tl >= 0 ? c->level_start[tl + 1] - tl0 : 0;
+  if(tl >= 0)
+    {
+      const size_t lds = sizeof(double) * ng * PM_DT * PM_DT * PM_DT;
+      auto launch_dep = [&](auto kern) -> int {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                           c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
+        return NGRAVS_OK;
+      };
+      int rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2>) : launch_dep(k_cic_deposit_tiled<3>));
+      if(rc)
+        return rc;
+      if(tl0 > 0)
+        hipLaunchKernelGGL(k_cic_deposit_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
+                           c->s_type.p, c->n_child.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
+    }
+  else
+    hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N, ng,
+                       c->d_counters.p + 8, c->pm_rho.p);
   for(int a = 0; a < ng; a++)
     FFT_TRY(c, hipfftExecD2Z(*(hipfftHandle *)c->fft_fwd, c->pm_rho.p + real_elems * a,
                              (hipfftDoubleComplex *)(c->pm_rho.p + real_elems * a)));
@@ -251,8 +498,33 @@ int pm_run(ngravs_ctx *c)
                              c->pm_phi.p + real_elems * b));
   double fac = c->cfg.G / (M_PI * L);      // pm_periodic.c:237-238
   fac *= 1 / (2 * L / N);
-  hipLaunchKernelGGL(k_gradient_gather, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N,
-                     c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+  // GravPM is needed for this task's own particles only (its target shard); the rest stays zero
+  if(c->cfg.world_size > 1)
+    HIP_TRY(c, hipMemsetAsync(c->r_pm.p, 0, sizeof(double) * 3 * n, c->stream));
+  unsigned nbg = (unsigned)((c->shard_count + bs - 1) / bs);
+  // measured at C4: the tiled gather (24.6 ms) loses to the per-particle one (13.3 ms) because each species pass
+  // leaves half the lanes idle; it stays available for tuning behind NGRAVS_PM_TILE_GATHER
+  if(tl >= 0 && getenv("NGRAVS_PM_TILE_GATHER"))
+    {
+      const size_t lds = sizeof(double) * PM_GT * PM_GT * PM_GT;
+      auto launch_gat = [&](auto kern) -> int {
+        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                           c->n_count.p, c->n_geo.p, (int)tl0, (long long)c->shard_first, (long long)c->shard_count, to_slab, N,
+                           c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+        return NGRAVS_OK;
+      };
+      int rc = ng == 1 ? launch_gat(k_gradient_gather_tiled<1>) : (ng == 2 ? launch_gat(k_gradient_gather_tiled<2>) : launch_gat(k_gradient_gather_tiled<3>));
+      if(rc)
+        return rc;
+      if(tl0 > 0)
+        hipLaunchKernelGGL(k_gradient_gather_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
+                           c->s_type.p, c->n_child.p, (int)tl0, (long long)c->shard_first, (long long)c->shard_count, to_slab, N,
+                           c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+    }
+  else if(nbg > 0)
+    hipLaunchKernelGGL(k_gradient_gather, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, (long long)c->shard_first,
+                       (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
   HIP_TRY(c, hipGetLastError());
   c->have_pm = true;
   return NGRAVS_OK;

@@ -647,6 +647,14 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
                   if(wp.dbg & 1)
                     n = 0;
                   st_iters += n;
+                  if(wp.dbg & 2)
+                    {
+                      int tot = 0;
+#pragma unroll
+                      for(int u = 0; u < GW_SUBS; u++)
+                        tot += cnt[g][u];
+                      st_batches += tot;   // debug: overloads the batches statistic with the sum of sub-list lengths
+                    }
                   const unsigned char *myl = sl + ((size_t)g * GW_SUBS + mysub) * GW_POOL;
                   // four entries per trip: one 32-bit read brings four pool indices, the four entries are
                   // fetched together, then evaluated -- the LDS latency of trip j+1 hides under trip j's math
