@@ -44,6 +44,16 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
     return b
 
 
+def walk_traffic(args, n, world):
+    """HBM-side bytes per launch of the walk kernel from the committed rocprofv3 --pmc passes (profiles/), only when
+    the run IS that workload (PMC counters cannot be collected inside this process)"""
+    path = os.path.join(ROOT, "profiles", "r01b_walk_traffic.json")
+    if args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    return None
+
+
 def make_box(pkg, n, L, n_gravs, seed):
     rng = np.random.default_rng(seed)
     chunk = 1 << 22
@@ -137,7 +147,13 @@ def main():
     ap.add_argument("--wiring", default="c4")
     ap.add_argument("--walk", default="group", choices=["group", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"],
+                    help="BASELINE.json config: c4 (default, the metric's) | c3: 16M N_GRAVS=1 PMGRID=256 | c2: 4M Plummer tree-only")
     args = ap.parse_args()
+    if args.config == "c3":
+        args.log2n, args.ngravs, args.wiring, args.pmgrid = (24 if args.log2n == 26 else args.log2n), 1, "newton", args.pmgrid or 256
+    if args.config == "c2":
+        args.log2n, args.ngravs, args.wiring = (22 if args.log2n == 26 else args.log2n), 1, "newton"
 
     import torch
     import torch.distributed as dist
@@ -177,12 +193,18 @@ def main():
             pmgrid *= 2
     cells_per_particle = pmgrid ** 3 / n
     eps = L / (40 * n ** (1 / 3))
-    cfg = pkg.make_config(n_gravs=args.ngravs, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5,
-                          err_tol_force_acc=0.005, softening=[eps] * 6,
+    treeonly = args.config == "c2"
+    if treeonly:
+        pmgrid, cells_per_particle, eps = 0, 0.0, 0.01
+    cfg = pkg.make_config(n_gravs=args.ngravs, periodic=0 if treeonly else 1, pmgrid=pmgrid, box_size=0.0 if treeonly else L,
+                          G=1.0, theta=0.5, err_tol_force_acc=0.005, softening=[eps] * 6,
                           type_to_grav=pkg.ic.default_type_to_grav(args.ngravs), wiring=args.wiring,
                           walk_mode=pkg.WALK_GROUP if args.walk == "group" else pkg.WALK_STRICT,
                           device=local_rank, rank=rank, world_size=world)
-    pos, mass, ptype = make_box(pkg, n, L, args.ngravs, 12345)
+    if treeonly:
+        pos, mass, ptype = pkg.ic.plummer_sphere(n, a=1.0, seed=12345)
+    else:
+        pos, mass, ptype = make_box(pkg, n, L, args.ngravs, 12345)
     dev = torch.device("cuda", local_rank)
     d_pos = torch.from_numpy(pos).to(dev)
     d_mass = torch.from_numpy(mass).to(dev)
@@ -238,9 +260,9 @@ def main():
             "metric": "particle-steps/s (tree+PM)", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C4: %d-particle uniform periodic box, N_GRAVS=%d (%s wiring: Newton + Yukawa), TreePM "
-                                   "PMGRID=%d, relative criterion ErrTolForceAcc=0.005, %s walk" %
-                                   (n, args.ngravs, args.wiring, pmgrid, args.walk),
+            "config": {"workload": "%s: %d-particle %s, N_GRAVS=%d (%s wiring), %s, relative criterion ErrTolForceAcc=0.005, %s walk" %
+                                   (args.config.upper(), n, "Plummer sphere" if treeonly else "uniform periodic box", args.ngravs,
+                                    args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
                        "parallelism": "walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world,
                        "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
@@ -248,14 +270,14 @@ def main():
                        "ia_per_particle": st.interactions / max(1, st.n_active), "tree_nodes": st.n_nodes,
                        "walk_list_entries_per_group": st.reserved[0], "walk_nodes_tested_per_group": st.reserved[1],
                        "walk_batches_per_group": st.reserved[2], "walk_force_iters_per_group": st.reserved[3],
-                       "step_algorithmic_bytes_per_particle": step_alg_bytes(args.ngravs, cells_per_particle),
-                       "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle) / HBM_PEAK},
+                       "step_algorithmic_bytes_per_particle": step_alg_bytes(args.ngravs, cells_per_particle, pm=not treeonly),
+                       "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle, pm=not treeonly) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": "k_walk_group" if args.walk == "group" else "k_walk_strict",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": walk_traffic(args, n, world),
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not treeonly:
             out["cpu_baseline"] = cpu_baseline(pkg, args.ngravs, args.wiring, cells_per_particle)
         else:
             out["cpu_baseline"] = None

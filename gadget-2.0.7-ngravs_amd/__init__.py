@@ -30,6 +30,9 @@ EXPORTS = [
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
+    "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_dd_histogram", "ngravs_dd_pack",
+    "ngravs_dd_apply_migration", "ngravs_dd_set_halo", "ngravs_dd_set_ids", "ngravs_dd_get_ids",
+    "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
 ]
 
 
@@ -77,6 +80,18 @@ def lib():
         L.ngravs_peano_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
         L.ngravs_shortrange_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_direct_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ngravs_dd_local_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngravs_dd_set_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngravs_dd_histogram.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ngravs_dd_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+        L.ngravs_dd_apply_migration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.ngravs_dd_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.ngravs_dd_set_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ngravs_dd_get_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.ngravs_pm_deposit.argtypes = [C.c_void_p]
+        L.ngravs_pm_finish.argtypes = [C.c_void_p]
+        L.ngravs_pm_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 

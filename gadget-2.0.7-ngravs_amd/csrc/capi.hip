@@ -99,7 +99,7 @@ __global__ void k_sum_active(const unsigned char *act, const int *nint, long lon
 {
   double s = 0, a = 0;
   for(long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < count; k += (long long)gridDim.x * blockDim.x)
-    if(act[first + k])
+    if(act[first + k] & 1)
       {
         s += nint[first + k];
         a += 1;
@@ -263,6 +263,12 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->in_type.release();
   c->in_active.release();
   c->in_key.release();
+  c->in_id.release();
+  c->dd_mask.release();
+  c->dd_counts.release();
+  c->dd_owner_ph.release();
+  c->dd_owner_xyz.release();
+  c->dd_send.release();
   c->s_pm.release();
   c->s_type.release();
   c->s_active.release();
@@ -370,7 +376,10 @@ extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p)
       return NGRAVS_ERR_NOMEM;
     }
   c->n = n;
+  c->n_local = n;
   int rc;
+  if((rc = dd_fill_ids(c)))
+    return rc;
   if((rc = upload_column_f64(c, p->pos, p->pos_stride, 3, n, p->on_device, c->in_pos.p)))
     return rc;
   if((rc = upload_column_f64(c, p->mass, p->mass_stride, 1, n, p->on_device, c->in_mass.p)))
@@ -787,4 +796,141 @@ extern "C" int ngravs_direct_sum(ngravs_ctx *c, const int32_t *idx, int64_t nt, 
   dout.release();
   dacc.release();
   return rc;
+}
+
+// ---- multi-task domain decomposition (host-driven collectives; see kernels_domain.hip) -------------------------------
+extern "C" int64_t ngravs_dd_num_local(ngravs_ctx *c) { return c ? c->n_local : NGRAVS_ERR_ARG; }
+
+extern "C" int ngravs_dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3])
+{
+  if(!c || !c->have_particles)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  c->n = c->n_local;   // a new step: forget the previous halo
+  c->have_order = c->have_tree = false;
+  return dd_local_extent(c, lo, hi);
+}
+
+extern "C" int ngravs_dd_set_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  c->extent_override = lo && hi;
+  if(c->extent_override)
+    {
+      for(int j = 0; j < 3; j++)
+        {
+          c->ext_lo[j] = lo[j];
+          c->ext_hi[j] = hi[j];
+        }
+      dd_apply_extent(c, lo, hi);
+    }
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_dd_histogram(ngravs_ctx *c, int level, int64_t *hist)
+{
+  if(!c || !c->have_particles || !c->extent_override || !hist || level < 1 || level > 7)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_histogram(c, level, hist);
+}
+
+extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
+                              int my_rank, int64_t *counts, void **dev_records, int64_t *nrec)
+{
+  if(!c || !c->have_particles || !c->extent_override || !owner_ph || !owner_xyz || !counts || !dev_records || !nrec)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  double reach = 0;
+  if(what == 1)
+    {
+      if(!c->cfg.pmgrid)
+        {
+          ngravs_report(c, NGRAVS_ERR_ARG, "halo decomposition needs the finite TreePM cut (tree-only runs use replicated sources)");
+          return NGRAVS_ERR_ARG;
+        }
+      WalkParams wp;
+      make_walk_params(c, &wp);
+      reach = sqrt(wp.reach2);
+      if(c->cfg.periodic)
+        reach += c->dom[6] - c->cfg.box_size;   // the curve's cube is 1.001 x the box: seam slack, conservative
+    }
+  return dd_pack(c, what, level, owner_ph, owner_xyz, nranks, my_rank, reach, counts, dev_records, nrec);
+}
+
+extern "C" int ngravs_dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  if(!c || !c->have_particles || nrec < 0)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_apply_migration(c, dev_records, nrec);
+}
+
+extern "C" int ngravs_dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  if(!c || !c->have_particles || nrec < 0)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_set_halo(c, dev_records, nrec);
+}
+
+extern "C" int ngravs_dd_set_ids(ngravs_ctx *c, const int64_t *ids, int on_device)
+{
+  if(!c || !c->have_particles || !ids)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  HIP_TRY(c, hipMemcpyAsync(c->in_id.p, ids, sizeof(long long) * c->n_local, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                            c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_dd_get_ids(ngravs_ctx *c, int64_t *ids, int on_device)
+{
+  if(!c || !c->have_particles || !ids)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return download_strided(c, c->in_id.p, sizeof(long long), 1, c->n_local, ids, sizeof(long long), on_device);
+}
+
+// pmforce_periodic in two halves, so that a multi-task host can all-reduce the density mesh in between
+extern "C" int ngravs_pm_deposit(ngravs_ctx *c)
+{
+  if(!c || !c->have_order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  if(!c->have_tree)
+    {
+      int64_t nn = ngravs_force_treebuild(c);
+      if(nn < 0)
+        return (int)nn;
+    }
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  int rc = pm_deposit(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return rc;
+}
+
+extern "C" int ngravs_pm_density(ngravs_ctx *c, void **dev, int64_t *count)
+{
+  if(!c || !dev || !count || !c->pm_rho.p)
+    return NGRAVS_ERR_STATE;
+  const int64_t N = c->cfg.pmgrid;
+  *dev = c->pm_rho.p;
+  *count = (int64_t)c->cfg.n_gravs * N * N * (N + 2);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_pm_finish(ngravs_ctx *c)
+{
+  if(!c || !c->have_order || !c->pm_rho.p)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = pm_finish(c);
+  if(rc)
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_pm = ev_ms(c) * 1e-3;
+  return NGRAVS_OK;
 }

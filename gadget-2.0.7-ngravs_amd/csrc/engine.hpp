@@ -95,7 +95,11 @@ struct ngravs_ctx
   ngravs_fatal_fn on_fatal = nullptr;
   hipStream_t stream = nullptr;
   double asmth = 0, rcut = 0;
-  int64_t n = 0;
+  int64_t n = 0;           // particles in the working set (own + halo copies)
+  int64_t n_local = 0;     // own particles: the first n_local of the input columns
+  bool extent_override = false;
+  double ext_lo[3], ext_hi[3];
+  int dd_last_what = -1;
   bool have_particles = false, have_order = false, have_tree = false, have_pm = false, have_acc = false;
   double dom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t shard_first = 0, shard_count = 0;
@@ -105,6 +109,11 @@ struct ngravs_ctx
   DevBuf<int> in_type;
   DevBuf<unsigned char> in_active;
   DevBuf<unsigned long long> in_key;
+  DevBuf<long long> in_id;
+  // multi-task decomposition scratch
+  DevBuf<unsigned long long> dd_mask, dd_counts;
+  DevBuf<int> dd_owner_ph, dd_owner_xyz;
+  DevBuf<unsigned char> dd_send;
   // sorted
   DevBuf<double4> s_pm;
   DevBuf<unsigned char> s_type, s_active;
@@ -150,6 +159,14 @@ int dom_find_extent(ngravs_ctx *c);
 int dom_keys_and_sort(ngravs_ctx *c);
 int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double corner[3], double fac, int bits,
                   long long *d_keys);
+int dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3]);
+void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3]);
+int dd_histogram(ngravs_ctx *c, int level, int64_t *hist);
+int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *owner_xyz, int nranks, int me, double reach,
+            int64_t *counts, void **dev_records, int64_t *nrec);
+int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_fill_ids(ngravs_ctx *c);
 // ---- kernels_tree.hip
 int tree_build(ngravs_ctx *c);
 // ---- kernels_walk.hip
@@ -159,6 +176,8 @@ int walk_finish(ngravs_ctx *c);
 int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc);
 // ---- kernels_pm.hip
 int pm_run(ngravs_ctx *c);
+int pm_deposit(ngravs_ctx *c);
+int pm_finish(ngravs_ctx *c);
 void pm_release(ngravs_ctx *c);
 // ---- shortrange_table.cpp
 void host_shortrange_table(const ngravs_config_t *cfg, double *force, double *pot);

@@ -59,6 +59,11 @@ __global__ void k_minmax(const double *__restrict__ pos, long long n, double *__
 
 int dom_find_extent(ngravs_ctx *c)
 {
+  if(c->extent_override)   // multi-task: the all-reduced extent (domain.c:906-907) was handed in by the host
+    {
+      dd_apply_extent(c, c->ext_lo, c->ext_hi);
+      return NGRAVS_OK;
+    }
   const int nb = 1024, bs = 256;
   if(c->red_tmp.ensure(nb * 6))
     return NGRAVS_ERR_NOMEM;
@@ -172,5 +177,406 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
   hipLaunchKernelGGL(k_keys, dim3(nb), dim3(bs), 0, c->stream, d_pos, (long long)n, corner[0], corner[1], corner[2],
                      fac, bits, (unsigned long long *)d_keys, (unsigned int *)nullptr);
   HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+// =====================================================================================================
+//  Multi-task domain decomposition (the role of domain_decompose / domain_exchangeParticles,
+//  domain.c:164-330, 554-760, and of the pseudo-particle export of gravtree.c:112-285).
+//
+//  MI355X design: the global Peano curve is cut at the boundaries of level-`level` Peano cells (cubes of the
+//  domain cube, the analogue of the reference's top-level tree leaves); a task owns a contiguous run of
+//  cells.  Two all-to-all-v exchanges per step, both built here as packed 48-byte records grouped by
+//  destination: (0) migration of particles whose cell changed owner, (1) the *halo*: copies of particles
+//  lying within the short-range cut of a cell owned by another task.  With TreePM the cut is finite
+//  (group_reach * Asmth), so a task that holds its own particles + halo can build a tree over them and
+//  walk its own targets with no further communication -- instead of exporting targets and importing
+//  partial forces (gravtree.c:170-280).  The host drives the collectives (RCCL through torch.distributed
+//  in bench.py, MPI in the reference glue); this file only packs and unpacks.
+// =====================================================================================================
+struct DDRecord
+{
+  double x, y, z, m, oldacc;
+  long long meta;   // type | active << 8 | id << 16
+};
+
+__global__ void k_dd_iota(long long *p, long long n)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    p[i] = i;
+}
+
+__device__ __forceinline__ void dd_cell(const unsigned short (*step)[8], const double *pos, long long i, double cx, double cy,
+                                        double cz, double fac21, int level, int *ix, int *iy, int *iz, long long *phcell)
+{
+  int x = (int)__dmul_rn(__dsub_rn(pos[3 * i + 0], cx), fac21);
+  int y = (int)__dmul_rn(__dsub_rn(pos[3 * i + 1], cy), fac21);
+  int z = (int)__dmul_rn(__dsub_rn(pos[3 * i + 2], cz), fac21);
+  long long key = ngravs_ph_key_tab(step, x, y, z, TREE_BITS);
+  *phcell = key >> (3 * (TREE_BITS - level));
+  *ix = x >> (TREE_BITS - level);
+  *iy = y >> (TREE_BITS - level);
+  *iz = z >> (TREE_BITS - level);
+}
+
+__global__ void k_dd_hist(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
+                          unsigned long long *__restrict__ hist)
+{
+  __shared__ unsigned short step[48][8];
+  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
+    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
+  __syncthreads();
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int ix, iy, iz;
+  long long cell;
+  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+  atomicAdd(&hist[cell], 1ull);
+}
+
+// which other tasks receive particle i?  what = 0: its new owner (migration); what = 1: every task owning a cell within
+// `reach` of it (halo).  One bit per task (world_size <= 64).
+__global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
+                          double cell_len, int periodic, const int *__restrict__ owner_ph, const int *__restrict__ owner_xyz,
+                          int me, int what, double reach, unsigned long long *__restrict__ mask)
+{
+  __shared__ unsigned short step[48][8];
+  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
+    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
+  __syncthreads();
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int ix, iy, iz;
+  long long cell;
+  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+  unsigned long long m = 0;
+  if(what == 0)
+    {
+      int o = owner_ph[cell];
+      if(o != me)
+        m = 1ull << o;
+    }
+  else
+    {
+      const int nc = 1 << level;
+      // offsets of the particle inside its cell
+      const double lx = pos[3 * i + 0] - (cx + ix * cell_len), ly = pos[3 * i + 1] - (cy + iy * cell_len),
+                   lz = pos[3 * i + 2] - (cz + iz * cell_len);
+      const double r2 = reach * reach;
+      for(int dx = -1; dx <= 1; dx++)
+        for(int dy = -1; dy <= 1; dy++)
+          for(int dz = -1; dz <= 1; dz++)
+            {
+              if(!dx && !dy && !dz)
+                continue;
+              int jx = ix + dx, jy = iy + dy, jz = iz + dz;
+              if(periodic)
+                {
+                  // the domain cube is 1.001 x the box: the outermost cell layers wrap onto each other; treat the
+                  // curve's cube as periodic -- conservative (a few extra halo particles at the seam)
+                  jx = (jx + nc) % nc;
+                  jy = (jy + nc) % nc;
+                  jz = (jz + nc) % nc;
+                }
+              else if(jx < 0 || jy < 0 || jz < 0 || jx >= nc || jy >= nc || jz >= nc)
+                continue;
+              int o = owner_xyz[(jx * nc + jy) * nc + jz];
+              if(o == me || o < 0)
+                continue;
+              double ax = dx < 0 ? lx : (dx > 0 ? cell_len - lx : 0.0);
+              double ay = dy < 0 ? ly : (dy > 0 ? cell_len - ly : 0.0);
+              double az = dz < 0 ? lz : (dz > 0 ? cell_len - lz : 0.0);
+              if(ax * ax + ay * ay + az * az < r2)
+                m |= 1ull << o;
+            }
+    }
+  mask[i] = m;
+}
+
+__global__ void k_dd_count(const unsigned long long *__restrict__ mask, long long n, int nranks, unsigned long long *__restrict__ counts)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  unsigned long long m = mask[i];
+  while(m)
+    {
+      int r = __builtin_ctzll(m);
+      m &= m - 1;
+      atomicAdd(&counts[r], 1ull);
+    }
+  if(mask[i] == 0)
+    atomicAdd(&counts[nranks], 1ull);   // stays / not exported
+}
+
+__global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
+                          const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
+                          const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                          const unsigned long long *__restrict__ offs, unsigned long long *__restrict__ cursor,
+                          DDRecord *__restrict__ out)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  unsigned long long m = mask[i];
+  if(!m)
+    return;
+  DDRecord rec;
+  rec.x = pos[3 * i + 0];
+  rec.y = pos[3 * i + 1];
+  rec.z = pos[3 * i + 2];
+  rec.m = mass[i];
+  rec.oldacc = oldacc[i];
+  rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
+  while(m)
+    {
+      int r = __builtin_ctzll(m);
+      m &= m - 1;
+      unsigned long long k = atomicAdd(&cursor[r], 1ull);
+      out[offs[r] + k] = rec;
+    }
+}
+
+// keep the particles that stay (mask == 0), compacted to the front of fresh columns
+__global__ void k_dd_keep(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
+                          const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
+                          const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                          unsigned long long *__restrict__ cursor, double *__restrict__ pos2, double *__restrict__ mass2,
+                          int *__restrict__ type2, double *__restrict__ oldacc2, unsigned char *__restrict__ active2,
+                          long long *__restrict__ id2)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n || mask[i])
+    return;
+  unsigned long long k = atomicAdd(cursor, 1ull);
+  pos2[3 * k + 0] = pos[3 * i + 0];
+  pos2[3 * k + 1] = pos[3 * i + 1];
+  pos2[3 * k + 2] = pos[3 * i + 2];
+  mass2[k] = mass[i];
+  type2[k] = type[i];
+  oldacc2[k] = oldacc[i];
+  active2[k] = active[i];
+  id2[k] = id[i];
+}
+
+__global__ void k_dd_unpack(const DDRecord *__restrict__ rec, long long nrec, long long at, int halo, double *__restrict__ pos,
+                            double *__restrict__ mass, int *__restrict__ type, double *__restrict__ oldacc,
+                            unsigned char *__restrict__ active, long long *__restrict__ id)
+{
+  long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(k >= nrec)
+    return;
+  DDRecord r = rec[k];
+  long long i = at + k;
+  pos[3 * i + 0] = r.x;
+  pos[3 * i + 1] = r.y;
+  pos[3 * i + 2] = r.z;
+  mass[i] = r.m;
+  oldacc[i] = r.oldacc;
+  type[i] = (int)(r.meta & 255);
+  active[i] = halo ? (unsigned char)2 : (unsigned char)((r.meta >> 8) & 1);   // bit 1 = halo copy: source only
+  id[i] = r.meta >> 16;
+}
+
+template <typename T> static int grow_keep(ngravs_ctx *c, DevBuf<T> &b, size_t keep, size_t want)
+{
+  if(want <= b.cap)
+    return 0;
+  DevBuf<T> nb;
+  if(nb.ensure(want + want / 4))
+    return -1;
+  if(keep && b.p)
+    if(hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+      return -1;
+  (void)hipStreamSynchronize(c->stream);
+  b.release();
+  b = nb;
+  return 0;
+}
+
+static void dd_fac(const ngravs_ctx *c, double *fac21) { *fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION)); }
+
+int dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3])
+{
+  const int nb = 1024, bs = 256;
+  if(c->red_tmp.ensure(nb * 6))
+    return NGRAVS_ERR_NOMEM;
+  hipLaunchKernelGGL(k_minmax, dim3(nb), dim3(bs), 0, c->stream, c->in_pos.p, (long long)c->n_local, c->red_tmp.p);
+  std::vector<double> h(nb * 6);
+  HIP_TRY(c, hipMemcpyAsync(h.data(), c->red_tmp.p, sizeof(double) * nb * 6, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for(int j = 0; j < 3; j++)
+    {
+      lo[j] = 1e37;
+      hi[j] = -1e37;
+    }
+  for(int b = 0; b < nb; b++)
+    for(int j = 0; j < 3; j++)
+      {
+        if(h[b * 6 + j] < lo[j])
+          lo[j] = h[b * 6 + j];
+        if(h[b * 6 + 3 + j] > hi[j])
+          hi[j] = h[b * 6 + 3 + j];
+      }
+  return NGRAVS_OK;
+}
+
+void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
+{
+  double len = 0;   // domain.c:909-923
+  for(int j = 0; j < 3; j++)
+    if(hi[j] - lo[j] > len)
+      len = hi[j] - lo[j];
+  len *= 1.001;
+  for(int j = 0; j < 3; j++)
+    {
+      c->dom[3 + j] = 0.5 * (lo[j] + hi[j]);
+      c->dom[j] = 0.5 * (lo[j] + hi[j]) - 0.5 * len;
+    }
+  c->dom[6] = len;
+  c->dom[7] = 1.0 / len * (double)(((long long)1) << NGRAVS_BITS_PER_DIMENSION);
+}
+
+int dd_histogram(ngravs_ctx *c, int level, int64_t *hist)
+{
+  const long long ncell = 1ll << (3 * level);
+  DevBuf<unsigned long long> d;
+  if(d.ensure(ncell))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * ncell, c->stream));
+  double fac21;
+  dd_fac(c, &fac21);
+  const long long n = c->n_local;
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1],
+                       c->dom[2], fac21, level, d.p);
+  HIP_TRY(c, hipMemcpyAsync(hist, d.p, sizeof(unsigned long long) * ncell, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  d.release();
+  return NGRAVS_OK;
+}
+
+int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *owner_xyz, int nranks, int me, double reach,
+            int64_t *counts, void **dev_records, int64_t *nrec)
+{
+  if(nranks > 64 || level < 1 || level > 7)
+    return NGRAVS_ERR_ARG;
+  const long long n = c->n_local, ncell = 1ll << (3 * level);
+  const double cell_len = c->dom[6] / (double)(1 << level);
+  if(what == 1 && !(reach <= cell_len))
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "halo: the decomposition cells must be at least as wide as the short-range cut");
+      return NGRAVS_ERR_ARG;
+    }
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->dd_owner_ph.ensure(ncell) || c->dd_owner_xyz.ensure(ncell) || c->dd_counts.ensure(3 * 65 + 2))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_ph.p, owner_ph, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_xyz.p, owner_xyz, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
+  double fac21;
+  dd_fac(c, &fac21);
+  unsigned nb = (unsigned)((n + 255) / 256);
+  std::vector<unsigned long long> h(65, 0), offs(65, 0);
+  if(n > 0)
+    {
+      hipLaunchKernelGGL(k_dd_dest, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
+                         cell_len, c->cfg.periodic, c->dd_owner_ph.p, c->dd_owner_xyz.p, me, what, reach, c->dd_mask.p);
+      hipLaunchKernelGGL(k_dd_count, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
+      HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  long long tot = 0;
+  for(int r = 0; r < nranks; r++)
+    {
+      offs[r] = tot;
+      counts[r] = (int64_t)h[r];
+      tot += h[r];
+    }
+  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(DDRecord)))
+    return NGRAVS_ERR_NOMEM;
+  if(tot > 0)
+    {
+      HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_dd_fill, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
+                         c->in_oldacc.p, c->in_active.p, c->in_id.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
+                         (DDRecord *)c->dd_send.p);
+    }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  *dev_records = c->dd_send.p;
+  *nrec = tot;
+  c->dd_last_what = what;
+  return NGRAVS_OK;
+}
+
+// after the migration all-to-all: drop what was sent (mask != 0 from the last dd_pack(what=0)), append what arrived
+int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  if(c->dd_last_what != 0)
+    return NGRAVS_ERR_STATE;
+  const long long n = c->n_local;
+  DevBuf<double> pos2, mass2, old2;
+  DevBuf<int> type2;
+  DevBuf<unsigned char> act2;
+  DevBuf<long long> id2;
+  const size_t cap = (size_t)(n + nrec + 64);
+  if(pos2.ensure(3 * cap) || mass2.ensure(cap) || old2.ensure(cap) || type2.ensure(cap) || act2.ensure(cap) || id2.ensure(cap))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p + 195, 0, sizeof(unsigned long long), c->stream));
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p,
+                       c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->dd_counts.p + 195, pos2.p, mass2.p,
+                       type2.p, old2.p, act2.p, id2.p);
+  unsigned long long kept = 0;
+  HIP_TRY(c, hipMemcpyAsync(&kept, c->dd_counts.p + 195, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if(nrec > 0)
+    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
+                       (long long)nrec, (long long)kept, 0, pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->in_pos.release();
+  c->in_mass.release();
+  c->in_oldacc.release();
+  c->in_type.release();
+  c->in_active.release();
+  c->in_id.release();
+  c->in_pos = pos2;
+  c->in_mass = mass2;
+  c->in_oldacc = old2;
+  c->in_type = type2;
+  c->in_active = act2;
+  c->in_id = id2;
+  c->n_local = (int64_t)kept + nrec;
+  c->n = c->n_local;
+  c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
+  return NGRAVS_OK;
+}
+
+int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  const long long nl = c->n_local, tot = nl + nrec;
+  if(grow_keep(c, c->in_pos, 3 * nl, 3 * tot) || grow_keep(c, c->in_mass, nl, tot) || grow_keep(c, c->in_oldacc, nl, tot) ||
+     grow_keep(c, c->in_type, nl, tot) || grow_keep(c, c->in_active, nl, tot) || grow_keep(c, c->in_id, nl, tot))
+    return NGRAVS_ERR_NOMEM;
+  if(nrec > 0)
+    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
+                       (long long)nrec, nl, 1, c->in_pos.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->n = tot;
+  c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
+  return NGRAVS_OK;
+}
+
+int dd_fill_ids(ngravs_ctx *c)
+{
+  if(c->in_id.ensure(c->n > 0 ? c->n : 1))
+    return NGRAVS_ERR_NOMEM;
+  if(c->n > 0)
+    hipLaunchKernelGGL(k_dd_iota, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, c->in_id.p, (long long)c->n);
   return NGRAVS_OK;
 }

@@ -23,11 +23,12 @@ __device__ __forceinline__ int cell_of(double x, double to_slab, int N, double *
   return s;
 }
 
-__global__ void k_cic_deposit(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, long long n,
+__global__ void k_cic_deposit(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                              const unsigned char *__restrict__ s_flag, long long n,
                               double to_slab, int N, int ng, const int *__restrict__ t2g_tab, double *__restrict__ rho)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
+  if(i >= n || (s_flag[i] & 2))   // bit 1: halo copy of another task's particle -- its owner deposits it
     return;
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
@@ -116,6 +117,7 @@ __global__ void k_green(const double2 *__restrict__ rho, double2 *__restrict__ p
 
 // fused 4-point gradient at the 8 CIC corners + CIC gather (pm_periodic.c:681-763)
 __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                  const unsigned char *__restrict__ s_flag,
                                   long long first, long long n, double to_slab, int N, const int *__restrict__ t2g_tab,
                                   const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
 {
@@ -123,6 +125,11 @@ __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsign
   if(i >= n)
     return;
   i += first;
+  if(s_flag[i] & 2)
+    {
+      r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
+      return;
+    }
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
   const long long NZ = N + 2;
@@ -170,9 +177,9 @@ __device__ __forceinline__ int wrapN(int a, int N) { return a < 0 ? a + N : (a >
 
 template <int NG>
 __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
-    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const int *__restrict__ n_first,
-    const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0, double to_slab, int N,
-    const int *__restrict__ t2g_tab, double *__restrict__ rho)
+    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const unsigned char *__restrict__ s_flag,
+    const int *__restrict__ n_first, const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0,
+    double to_slab, int N, const int *__restrict__ t2g_tab, double *__restrict__ rho)
 {
   extern __shared__ double tile[];   // [NG][DT][DT][DT]
   const int node = node0 + blockIdx.x;
@@ -192,6 +199,8 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
   for(int k = threadIdx.x; k < count; k += blockDim.x)
     {
       const int i = first + k;
+      if(s_flag[i] & 2)
+        continue;
       const double4 p = s_pm[i];
       const int g = t2g_tab[s_type[i]];
       double dx, dy, dz;
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
 
 // particles that hang directly off nodes above the tile level
 __global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                    const unsigned char *__restrict__ s_flag,
                                     const int *__restrict__ n_child, int nnodes_above, double to_slab, int N,
                                     const int *__restrict__ t2g_tab, double *__restrict__ rho)
 {
@@ -243,6 +253,8 @@ __global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsi
   if(c > -2)
     return;
   const int i = -2 - c;
+  if(s_flag[i] & 2)
+    return;
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
   const long long NZ = N + 2;
@@ -410,7 +422,7 @@ void pm_release(ngravs_ctx *c)
     }                                                                                       \
   while(0)
 
-int pm_run(ngravs_ctx *c)
+int pm_deposit(ngravs_ctx *c)
 {
   const int N = c->cfg.pmgrid, ng = c->cfg.n_gravs;
   const long long n = c->n;
@@ -446,8 +458,8 @@ int pm_run(ngravs_ctx *c)
       const size_t lds = sizeof(double) * ng * PM_DT * PM_DT * PM_DT;
       auto launch_dep = [&](auto kern) -> int {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                           c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
+                           c->n_first.p, c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
         return NGRAVS_OK;
       };
       int rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2>) : launch_dep(k_cic_deposit_tiled<3>));
@@ -455,11 +467,27 @@ int pm_run(ngravs_ctx *c)
         return rc;
       if(tl0 > 0)
         hipLaunchKernelGGL(k_cic_deposit_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
-                           c->s_type.p, c->n_child.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
+                           c->s_type.p, c->s_active.p, c->n_child.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
     }
   else
-    hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, n, to_slab, N, ng,
+    hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, to_slab, N, ng,
                        c->d_counters.p + 8, c->pm_rho.p);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+// forward FFTs, Green multiply, inverse FFTs, gradient + gather.  Between pm_deposit() and pm_finish() a multi-task
+// host all-reduces the density mesh (pm_periodic.c:333-427 ships patches to slab owners instead).
+int pm_finish(ngravs_ctx *c)
+{
+  const int N = c->cfg.pmgrid, ng = c->cfg.n_gravs;
+  const long long n = c->n;
+  const size_t real_elems = (size_t)N * N * (N + 2);
+  const double L = c->cfg.box_size, to_slab = N / L;
+  const int bs = 256;
+  const int tl = pm_tile_level(c, to_slab);
+  const long long tl0 = tl >= 0 ? c->level_start[tl] : 0, tln = tl >= 0 ? c->level_start[tl + 1] - tl0 : 0;
+  (void)tln;
   for(int a = 0; a < ng; a++)
     FFT_TRY(c, hipfftExecD2Z(*(hipfftHandle *)c->fft_fwd, c->pm_rho.p + real_elems * a,
                              (hipfftDoubleComplex *)(c->pm_rho.p + real_elems * a)));
@@ -523,9 +551,17 @@ int pm_run(ngravs_ctx *c)
                            c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
     }
   else if(nbg > 0)
-    hipLaunchKernelGGL(k_gradient_gather, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, (long long)c->shard_first,
+    hipLaunchKernelGGL(k_gradient_gather, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, (long long)c->shard_first,
                        (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
   HIP_TRY(c, hipGetLastError());
   c->have_pm = true;
   return NGRAVS_OK;
+}
+
+int pm_run(ngravs_ctx *c)
+{
+  int rc = pm_deposit(c);
+  if(rc)
+    return rc;
+  return pm_finish(c);
 }

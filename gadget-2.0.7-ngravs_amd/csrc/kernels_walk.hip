@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long grp = (long long)blockIdx.x * 4 + wave;
   const long long ti = t_first + grp * WAVE + lane;
-  const bool valid = (grp * WAVE + lane) < t_count && s_active[ti < t_first + t_count ? ti : t_first] != 0;
+  const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti < t_first + t_count ? ti : t_first] & 1) != 0;
   if(grp * WAVE >= t_count)
     return;
   double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
       if(grp < 0)
         break;
       const long long ti = t_first + grp * WAVE + lane;
-      const bool valid = (grp * WAVE + lane) < t_count && s_active[ti] != 0;
+      const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
       if(!__any(valid ? 1 : 0))
         continue;
       double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
@@ -971,7 +971,7 @@ __global__ void k_finish(long long t_first, long long t_count, const unsigned ch
   if(k >= t_count)
     return;
   long long i = t_first + k;
-  if(!s_active[i])
+  if(!(s_active[i] & 1))
     return;
   double ax = r_acc[3 * i], ay = r_acc[3 * i + 1], az = r_acc[3 * i + 2];
   double bx = ax, by = ay, bz = az;

@@ -208,6 +208,35 @@ int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, doubl
  * nearest-image (no Ewald term); result xG into acc[3*nt] (forcetree.c:3428-3548). */
 int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *acc);
 
+/* ---- multi-task domain decomposition ------------------------------------------------------------------
+ * The role of domain_decompose()/domain_exchangeParticles() (domain.c:164-330, 554-760) and of the
+ * target export of gravity_tree() (gravtree.c:112-285).  The Peano curve is cut at the boundaries of
+ * level-`level` Peano cells; a task owns a run of cells, holds its own particles plus a halo of copies of
+ * every foreign particle within the short-range cut of its cells, and then needs no communication for
+ * tree build and walk.  The library packs/unpacks; the HOST performs the collectives (MPI_Allreduce /
+ * MPI_Alltoallv in the reference glue, RCCL through torch.distributed in bench.py):
+ *   lo,hi   = ngravs_dd_local_extent()        -> all-reduce min/max    -> ngravs_dd_set_extent()
+ *   hist    = ngravs_dd_histogram(level)       -> all-reduce sum        -> host cuts the curve: owner maps
+ *   records = ngravs_dd_pack(0, ...)           -> all-to-all-v          -> ngravs_dd_apply_migration()
+ *   records = ngravs_dd_pack(1, ...)           -> all-to-all-v          -> ngravs_dd_set_halo()
+ *   ngravs_domain_decomposition(); ngravs_pm_deposit() -> all-reduce of ngravs_pm_density() -> ngravs_pm_finish();
+ *   ngravs_gravity_tree();  results: the first ngravs_dd_num_local() rows of ngravs_get_accel(), ids from ngravs_dd_get_ids().
+ * Records are 48 bytes: x,y,z,mass,old_acc (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64. */
+int64_t ngravs_dd_num_local(ngravs_ctx *ctx);
+int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);             /* domain.c:894-905 */
+int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */
+int ngravs_dd_histogram(ngravs_ctx *ctx, int level, int64_t *hist);                  /* 8^level counts, Peano-cell order (host) */
+int ngravs_dd_pack(ngravs_ctx *ctx, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
+                   int my_rank, int64_t *counts, void **dev_records, int64_t *nrec);
+int ngravs_dd_apply_migration(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
+int ngravs_dd_set_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
+int ngravs_dd_set_ids(ngravs_ctx *ctx, const int64_t *ids, int on_device);
+int ngravs_dd_get_ids(ngravs_ctx *ctx, int64_t *ids, int on_device);
+/* pmforce_periodic() in two halves around the all-reduce of the density mesh (pm_periodic.c:333-427) */
+int ngravs_pm_deposit(ngravs_ctx *ctx);
+int ngravs_pm_density(ngravs_ctx *ctx, void **dev, int64_t *count);
+int ngravs_pm_finish(ngravs_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,88 @@
+"""-m gpu: the multi-task domain decomposition (migration + halo + all-reduced PM mesh) with 3 ranks sharing the
+one GPU of the box over gloo.  Merged results must reproduce the single-task engine and keep the accuracy
+of the Ewald golden."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    from make_ewald_golden import N, L, SEED, case_config
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ewald_truth_c4.npz"))
+    pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=2, seed=SEED)
+    old = gold["old_acc"]
+    cfg, eps = case_config(pkg, "c4", 2, walk_mode=pkg.WALK_GROUP)
+    cfg.err_tol_theta = 0.0
+    mine = np.arange(rank, N, world)                      # an arbitrary initial distribution: every rank has particles everywhere
+    eng = dd.DistributedEngine(cfg)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], old_acc=old[mine], ids=mine)
+    eng.compute_accelerations(pm_step=True)
+    acc, oa, cost, pm = eng.get_accel(want_pm=True)
+    ids = eng.local_ids()
+    first_mig, first_halo = eng.timings["migrated"], eng.timings["halo"]
+    eng.compute_accelerations(pm_step=True)               # second step: nothing should migrate any more
+    acc2, _, _, pm2 = eng.get_accel(want_pm=True)
+    ids2 = eng.local_ids()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ids=ids, acc=acc, pm=pm, cost=cost, ids2=ids2, acc2=acc2,
+             mig=np.array([first_mig, eng.timings["migrated"], first_halo, eng.num_local()]))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_three_rank_domain_decomposition(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_ewald_golden import N, L, SEED, case_config
+    world = 3
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    acc = np.zeros((N, 3))
+    pm = np.zeros((N, 3))
+    seen = np.zeros(N, dtype=np.int64)
+    nloc = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        acc[d["ids"]] = d["acc"]
+        pm[d["ids"]] = d["pm"]
+        seen[d["ids"]] += 1
+        mig = d["mig"]
+        assert mig[0] > 0 and mig[1] == 0 and mig[2] > 0          # first step migrates, second does not; halo non-empty
+        assert np.array_equal(np.sort(d["ids"]), np.sort(d["ids2"]))
+        nloc.append(int(mig[3]))
+    assert np.all(seen == 1)                                       # every particle owned exactly once
+    assert max(nloc) < 1.2 * N / world                             # balanced cut of the curve
+    # single-task engine on the same input
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ewald_truth_c4.npz"))
+    pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=2, seed=SEED)
+    cfg, eps = case_config(pkg, "c4", 2, walk_mode=pkg.WALK_GROUP)
+    cfg.err_tol_theta = 0.0
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=gold["old_acc"])
+    eng.compute_accelerations(pm_step=True)
+    a1, _, _, p1 = eng.get_accel(want_pm=True)
+    eng.close()
+    assert np.abs(pm - p1).max() / np.abs(p1).max() < 1e-10         # all-reduced mesh == single mesh
+    tot = np.linalg.norm(a1 + p1, axis=1)
+    d = np.linalg.norm(acc - a1, axis=1) / tot
+    print("3 ranks vs 1: tree force diff relative to total: median %.2e p99 %.2e max %.2e" % (np.median(d), np.quantile(d, 0.99), d.max()))
+    assert np.quantile(d, 0.99) < 2e-3
+    # accuracy against the Ewald truth stays in the reference's band
+    idx, truth = gold["idx"], gold["truth"]
+    e = np.linalg.norm((acc + pm)[idx] - truth, axis=1) / np.linalg.norm(truth, axis=1)
+    e_ref = np.linalg.norm(gold["ref_total"] - truth, axis=1) / np.linalg.norm(truth, axis=1)
+    assert np.sqrt(np.mean(e ** 2)) <= np.sqrt(np.mean(e_ref ** 2))
