@@ -147,6 +147,10 @@ def main():
     ap.add_argument("--wiring", default="c4")
     ap.add_argument("--walk", default="group", choices=["group", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomp", default="replicated", choices=["replicated", "domain"],
+                    help="N>1: 'replicated' = every rank holds all particles, the walk is sharded (default, no data-path "
+                         "collective); 'domain' = Peano-Hilbert domain decomposition with migration + halo all-to-all-v and "
+                         "an all-reduced PM mesh (memory-scalable; see DESIGN.md Multi-GPU)")
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"],
                     help="BASELINE.json config: c4 (default, the metric's) | c3: 16M N_GRAVS=1 PMGRID=256 | c2: 4M Plummer tree-only")
     args = ap.parse_args()
@@ -211,8 +215,19 @@ def main():
     d_type = torch.from_numpy(ptype).to(dev)
     d_old = torch.zeros(n, dtype=torch.float64, device=dev)
     del pos, mass, ptype
-    eng = pkg.Engine(cfg)
-    eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_type.data_ptr())
+    domain = args.decomp == "domain" and world > 1 and not treeonly
+    if domain:
+        import importlib
+        dd = importlib.import_module("ngravs_amd.distributed")
+        eng = dd.DistributedEngine(cfg)
+        sel = torch.arange(rank, n, world, device=dev)          # arbitrary initial ownership; the first step migrates
+        l_pos, l_mass, l_type = d_pos[sel].contiguous(), d_mass[sel].contiguous(), d_type[sel].contiguous()
+        eng.set_particles_device(int(sel.numel()), l_pos.data_ptr(), l_mass.data_ptr(), l_type.data_ptr())
+        eng._check(pkg.lib().ngravs_dd_set_ids(eng._h, sel.data_ptr(), 1), "ngravs_dd_set_ids")
+        del d_pos, d_mass, d_type
+    else:
+        eng = pkg.Engine(cfg)
+        eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_type.data_ptr())
     torch.cuda.synchronize()
 
     # pass 1 (untimed): Barnes-Hut theta=0.5 with OldAcc=0, as the reference's first force computation
@@ -220,8 +235,16 @@ def main():
     if world > 1:
         # every rank needs OldAcc of all particles only for ITS targets; its own shard is what it has
         pass
-    eng.get_old_acc_device(d_old.data_ptr())
-    eng.set_old_acc_device(d_old.data_ptr())
+    if domain:
+        # OldAcc of the own particles (first num_local rows of the working set) feeds the next pass
+        nl = eng.num_local()
+        tot = nl + int(eng.timings.get("halo", 0))
+        tmp = torch.zeros(tot, dtype=torch.float64, device=dev)
+        eng.get_old_acc_device(tmp.data_ptr())
+        eng._check(pkg.lib().ngravs_set_old_acc(eng._h, tmp.data_ptr(), 8, 1), "ngravs_set_old_acc")
+    else:
+        eng.get_old_acc_device(d_old.data_ptr())
+        eng.set_old_acc_device(d_old.data_ptr())
     eng.set_opening(0.0, 0.005)     # All.ErrTolTheta = 0 latch (gravtree.c:334-335)
 
     def sync():
@@ -248,6 +271,8 @@ def main():
         dt = float(t.item())
     st = eng.stats()
     shard_first, shard_count = eng.shard()
+    if domain:
+        shard_count = eng.num_local()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -264,7 +289,8 @@ def main():
                                    (args.config.upper(), n, "Plummer sphere" if treeonly else "uniform periodic box", args.ngravs,
                                     args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
-                       "parallelism": "walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world,
+                       "parallelism": ("Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, all-reduced PM mesh" % world)
+                       if domain else ("walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world),
                        "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
                                      "treewalk": ph[3] * 1e3},
                        "ia_per_particle": st.interactions / max(1, st.n_active), "tree_nodes": st.n_nodes,
