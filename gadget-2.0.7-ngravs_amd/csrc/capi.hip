@@ -290,6 +290,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->scan_tmp.release();
   c->d_counters.release();
   c->table.release();
+  c->lat.release();
   c->walk_stack.release();
   c->walk_counters.release();
   c->r_acc.release();

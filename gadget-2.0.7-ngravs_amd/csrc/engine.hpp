@@ -76,6 +76,7 @@ struct WalkParams
   double errtol_acc;        // ErrTolForceAcc
   double rcut, rcut2, asmthfac, utor2wpi, reach2;   // TreePM constants (forcetree.c:1708-1711)
   double ym;                // YUKAWA_IMASS / BoxSize (ngravs.c:859)
+  double fac_intp;          // 2*NGRAVS_EN/BoxSize: lattice-table lookup scale (forcetree.c:3737)
   double fsoft[NGRAVS_NTYPES];
   int t2g[NGRAVS_NTYPES];
   // law coefficients [target][source]: accel = m*(cN/r2 + cY*exp(-r ym)(ym/r + 1/r2)); spline = cS*plummer
@@ -135,6 +136,8 @@ struct ngravs_ctx
   // walk
   DevBuf<double> table;       // [ng][ng][NTAB] shortrange_fourier_force
   bool table_ready = false;
+  DevBuf<double> lat;         // [ng][ng][3][65^3] Ewald / lattice-sum force corrections (periodic tree-only, periodic direct sum)
+  bool lat_ready = false;
   DevBuf<int> walk_stack;     // per-wave scratch
   DevBuf<int> walk_counters;  // [1] overflow flag, [2..5] walk statistics, [8..15] per-XCD group counters
   DevBuf<double> r_acc, r_pm, r_oldacc;

@@ -76,11 +76,132 @@ struct LawIds
 };
 
 // =============================================================================================
+//  periodic tree-only path: Ewald / lattice-sum correction (reference lattice_init forcetree.c:3611-3793,
+//  ewald_force ngravs.c:1170-1232, yukawa_lattice_force ngravs.c:1019-1090, lattice_corr forcetree.c:3803-3885)
+// =============================================================================================
+#define LAT_EN 64
+#define LAT_E1 (LAT_EN + 1)
+#define LAT_SZ ((size_t)3 * LAT_E1 * LAT_E1 * LAT_E1)
+
+#pragma clang fp contract(off)
+// one thread per table point of one law; out[3][E1^3], already divided by BoxSize^2
+__global__ void k_lattice_table(int law, double ymass, double L2, double *__restrict__ out)
+{
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if(n >= LAT_E1 * LAT_E1 * LAT_E1)
+    return;
+  const int i = n / (LAT_E1 * LAT_E1), j = (n / LAT_E1) % LAT_E1, k = n % LAT_E1;
+  const double x[3] = {0.5 * ((double)i) / LAT_EN, 0.5 * ((double)j) / LAT_EN, 0.5 * ((double)k) / LAT_EN};
+  double f[3] = {0, 0, 0};
+  if(n != 0 && (law == NGRAVS_LAW_NEWTON || law == NGRAVS_LAW_NEG_NEWTON || law == NGRAVS_LAW_COLOYUK))
+    {
+      const double alpha = 2.0, sgn = law == NGRAVS_LAW_NEG_NEWTON ? -1.0 : 1.0;
+      double g[3] = {0, 0, 0};
+      const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+      for(int c = 0; c < 3; c++)
+        g[c] += x[c] / (r2 * sqrt(r2));
+      for(int n0 = -4; n0 <= 4; n0++)
+        for(int n1 = -4; n1 <= 4; n1++)
+          for(int n2 = -4; n2 <= 4; n2++)
+            {
+              const double dx[3] = {x[0] - n0, x[1] - n1, x[2] - n2};
+              const double r = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+              const double val = erfc(alpha * r) + 2 * alpha * r / sqrt(M_PI) * exp(-alpha * alpha * r * r);
+              for(int c = 0; c < 3; c++)
+                g[c] -= dx[c] / (r * r * r) * val;
+            }
+      for(int h0 = -4; h0 <= 4; h0++)
+        for(int h1 = -4; h1 <= 4; h1++)
+          for(int h2_ = -4; h2_ <= 4; h2_++)
+            {
+              const int h[3] = {h0, h1, h2_};
+              const int h2 = h0 * h0 + h1 * h1 + h2_ * h2_;
+              if(h2 > 0)
+                {
+                  const double hdotx = x[0] * h0 + x[1] * h1 + x[2] * h2_;
+                  const double val = 2.0 / ((double)h2) * exp(-M_PI * M_PI * h2 / (alpha * alpha)) * sin(2 * M_PI * hdotx);
+                  for(int c = 0; c < 3; c++)
+                    g[c] -= h[c] * val;
+                }
+            }
+      for(int c = 0; c < 3; c++)
+        f[c] += sgn * g[c];
+    }
+  if(n != 0 && (law == NGRAVS_LAW_YUKAWA || law == NGRAVS_LAW_COLOYUK))
+    {
+      const double alpha = 5.64;
+      double ym = ymass, g[3];
+      const double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+      double r = sqrt(r2);
+      for(int c = 0; c < 3; c++)
+        g[c] = exp(-r * ym) * (ym + 1.0 / r) * x[c] / r2;
+      for(int n0 = -5; n0 <= 5; n0++)
+        for(int n1 = -5; n1 <= 5; n1++)
+          for(int n2 = -5; n2 <= 5; n2++)
+            {
+              const double dx[3] = {x[0] - n0, x[1] - n1, x[2] - n2};
+              r = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+              const double ep = exp(ym * r) * erfc(alpha * r + ym / (2 * alpha)), em = exp(-ym * r) * erfc(alpha * r - ym / (2 * alpha));
+              double val = 0.5 * (ep + em);
+              for(int c = 0; c < 3; c++)
+                g[c] -= dx[c] / (r * r * r) * val;
+              val = 0.5 * ym * (-ep + em) + 2 * alpha * exp(-alpha * alpha * r * r - ym * ym / (4 * alpha * alpha)) / sqrt(M_PI);
+              for(int c = 0; c < 3; c++)
+                g[c] -= dx[c] / (r * r) * val;
+            }
+      ym /= 2 * M_PI;
+      for(int h0 = -5; h0 <= 5; h0++)
+        for(int h1 = -5; h1 <= 5; h1++)
+          for(int h2_ = -5; h2_ <= 5; h2_++)
+            {
+              const int h[3] = {h0, h1, h2_};
+              const int h2 = h0 * h0 + h1 * h1 + h2_ * h2_;
+              if(h2 > 0)
+                {
+                  const double hdotx = x[0] * h0 + x[1] * h1 + x[2] * h2_;
+                  const double val = 2 * exp(-M_PI * M_PI * (h2 + ym * ym) / (alpha * alpha)) * sin(2 * M_PI * hdotx) / (h2 + ym * ym);
+                  for(int c = 0; c < 3; c++)
+                    g[c] -= h[c] * val;
+                }
+            }
+      for(int c = 0; c < 3; c++)
+        f[c] += g[c];
+    }
+  for(int c = 0; c < 3; c++)
+    out[(size_t)c * LAT_E1 * LAT_E1 * LAT_E1 + n] = f[c] / L2;
+}
+
+// lattice_corr: trilinear lookup in the octant table of one species pair; result to be multiplied by the source mass
+__device__ __forceinline__ void lat_lookup(const double *__restrict__ t3, double fac_intp, double dx, double dy, double dz,
+                                           double &fx, double &fy, double &fz)
+{
+  const double sx = dx < 0 ? 1.0 : -1.0, sy = dy < 0 ? 1.0 : -1.0, sz = dz < 0 ? 1.0 : -1.0;
+  double u = fabs(dx) * fac_intp, v = fabs(dy) * fac_intp, w = fabs(dz) * fac_intp;
+  int i = (int)u, j = (int)v, k = (int)w;
+  i = i >= LAT_EN ? LAT_EN - 1 : i;
+  j = j >= LAT_EN ? LAT_EN - 1 : j;
+  k = k >= LAT_EN ? LAT_EN - 1 : k;
+  u -= i;
+  v -= j;
+  w -= k;
+  const double f1 = (1 - u) * (1 - v) * (1 - w), f2 = (1 - u) * (1 - v) * (w), f3 = (1 - u) * (v) * (1 - w), f4 = (1 - u) * (v) * (w),
+               f5 = (u) * (1 - v) * (1 - w), f6 = (u) * (1 - v) * (w), f7 = (u) * (v) * (1 - w), f8 = (u) * (v) * (w);
+  const size_t o = ((size_t)i * LAT_E1 + j) * LAT_E1 + k, sj = LAT_E1, si = (size_t)LAT_E1 * LAT_E1, sc = si * LAT_E1;
+  const double *a = t3;
+  fx = sx * (a[o] * f1 + a[o + 1] * f2 + a[o + sj] * f3 + a[o + sj + 1] * f4 + a[o + si] * f5 + a[o + si + 1] * f6 + a[o + si + sj] * f7 + a[o + si + sj + 1] * f8);
+  a = t3 + sc;
+  fy = sy * (a[o] * f1 + a[o + 1] * f2 + a[o + sj] * f3 + a[o + sj + 1] * f4 + a[o + si] * f5 + a[o + si + 1] * f6 + a[o + si + sj] * f7 + a[o + si + sj + 1] * f8);
+  a = t3 + 2 * sc;
+  fz = sz * (a[o] * f1 + a[o + 1] * f2 + a[o + sj] * f3 + a[o + sj + 1] * f4 + a[o + si] * f5 + a[o + si + 1] * f6 + a[o + si + sj] * f7 + a[o + si + sj + 1] * f8);
+}
+#pragma clang fp contract(fast)
+
+// =============================================================================================
 //  strict walk
 // =============================================================================================
 #pragma clang fp contract(off)
 
-template <int NG, bool PM>
+template <int NG, bool PM, bool LATT>
 __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 *__restrict__ s_pm,
                                                      const unsigned char *__restrict__ s_type,
                                                      const double *__restrict__ s_oldacc,
@@ -263,49 +384,139 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
     return __any(open ? 1 : 0) != 0;
   };
 
-  if(visit(0))
+  // lock-step depth-first driver, shared by the force walk and the lattice-correction walk
+  auto dfs = [&](auto &&visit_fn, auto &&particle_fn) {
+    sp = -1;
+    if(visit_fn(0))
+      {
+        sp = 0;
+        sn[0] = 0;
+        ss[0] = 0;
+      }
+    while(sp >= 0)
+      {
+        int node = __builtin_amdgcn_readfirstlane(sn[sp]);
+        int slot = __builtin_amdgcn_readfirstlane(ss[sp]);
+        int fl = tv.flags[node];
+        if(fl & FLAG_BUCKET)
+          {
+            int f = tv.first[node], cnt = tv.count[node];
+            if(slot >= cnt)
+              {
+                sp--;
+                continue;
+              }
+            ss[sp] = slot + 1;
+            particle_fn(f + slot);
+            continue;
+          }
+        if(slot >= 8)
+          {
+            sp--;
+            continue;
+          }
+        ss[sp] = slot + 1;
+        int c = __builtin_amdgcn_readfirstlane(tv.child[8 * (long long)node + slot]);
+        if(c == -1)
+          continue;
+        if(c <= -2)
+          {
+            particle_fn(-2 - c);
+            continue;
+          }
+        if(visit_fn(c))
+          {
+            sp++;
+            sn[sp] = c;
+            ss[sp] = 0;
+          }
+      }
+  };
+  dfs(visit, do_particle);
+
+  if(LATT)
     {
-      sp = 0;
-      sn[0] = 0;
-      ss[0] = 0;
-    }
-  while(sp >= 0)
-    {
-      int node = __builtin_amdgcn_readfirstlane(sn[sp]);
-      int slot = __builtin_amdgcn_readfirstlane(ss[sp]);
-      int fl = tv.flags[node];
-      if(fl & FLAG_BUCKET)
-        {
-          int f = tv.first[node], cnt = tv.count[node];
-          if(slot >= cnt)
-            {
-              sp--;
-              continue;
-            }
-          ss[sp] = slot + 1;
-          do_particle(f + slot);
-          continue;
-        }
-      if(slot >= 8)
-        {
-          sp--;
-          continue;
-        }
-      ss[sp] = slot + 1;
-      int c = __builtin_amdgcn_readfirstlane(tv.child[8 * (long long)node + slot]);
-      if(c == -1)
-        continue;
-      if(c <= -2)
-        {
-          do_particle(-2 - c);
-          continue;
-        }
-      if(visit(c))
-        {
-          sp++;
-          sn[sp] = c;
-          ss[sp] = 0;
-        }
+      // force_treeevaluate_lattice_correction (forcetree.c:2077-2455): its own walk -- a node the opening criterion
+      // rejects may still be used if it is small (<= 0.2 box) and does not straddle the half-box seam
+      const double *lat = table;   // [tg][sg][3][E1^3]
+      resume_at = valid ? 0 : 0x7fffffff;
+      auto lat_particle = [&](int p) {
+        double4 q = s_pm[p];
+        int qt = s_type[p];
+        if(p >= resume_at)
+          {
+            int sg = wp.t2g[qt];
+            double dx = nearest(q.x - px, wp.box, wp.boxhalf), dy = nearest(q.y - py, wp.box, wp.boxhalf),
+                   dz = nearest(q.z - pz, wp.box, wp.boxhalf);
+            double fx, fy, fz;
+            lat_lookup(lat + ((size_t)tg * NG + sg) * LAT_SZ, wp.fac_intp, dx, dy, dz, fx, fy, fz);
+            ax += q.w * fx;
+            ay += q.w * fy;
+            az += q.w * fz;
+            nint++;
+          }
+      };
+      auto lat_visit = [&](int c) -> bool {
+        int first = tv.first[c], cnt = tv.count[c];
+        double4 geo = tv.geo[c];
+        double4 mom[NG];
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          mom[g] = tv.mom[(long long)c * NG + g];
+        bool open = false;
+        if(first >= resume_at)
+          {
+            double dx[NG], dy[NG], dz[NG];
+            double r2min = INFINITY, summass = 0;
+#pragma unroll
+            for(int g = 0; g < NG; g++)
+              {
+                summass += mom[g].w;
+                dx[g] = nearest(mom[g].x - px, wp.box, wp.boxhalf);
+                dy[g] = nearest(mom[g].y - py, wp.box, wp.boxhalf);
+                dz[g] = nearest(mom[g].z - pz, wp.box, wp.boxhalf);
+                double r2 = dx[g] * dx[g] + dy[g] * dy[g] + dz[g] * dz[g];
+                if(r2 < r2min)
+                  r2min = r2;
+              }
+            const double len = geo.w;
+            bool openflag = false;
+            if(wp.use_theta)
+              openflag = len * len > r2min * wp.theta2;
+            else
+              {
+                if(summass * len * len > r2min * r2min * aold)
+                  openflag = true;
+                else if(fabs(geo.x - px) < 0.60 * len && fabs(geo.y - py) < 0.60 * len && fabs(geo.z - pz) < 0.60 * len)
+                  openflag = true;
+              }
+            if(openflag)
+              {
+                double u0 = nearest(geo.x - px, wp.box, wp.boxhalf), u1 = nearest(geo.y - py, wp.box, wp.boxhalf),
+                       u2 = nearest(geo.z - pz, wp.box, wp.boxhalf);
+                const double lim = 0.5 * (wp.box - len);
+                if(fabs(u0) > lim || fabs(u1) > lim || fabs(u2) > lim || len > 0.20 * wp.box)   // forcetree.c:2203-2243
+                  open = true;
+              }
+            if(!open)
+              {
+#pragma unroll
+                for(int g = 0; g < NG; g++)
+                  if(mom[g].w != 0.0)
+                    {
+                      double fx, fy, fz;
+                      lat_lookup(lat + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, dx[g], dy[g], dz[g], fx, fy, fz);
+                      ax += mom[g].w * fx;
+                      ay += mom[g].w * fy;
+                      az += mom[g].w * fz;
+                    }
+                nint++;
+                resume_at = first + cnt;
+              }
+          }
+        return __any(open ? 1 : 0) != 0;
+      };
+      dfs(lat_visit, lat_particle);
     }
   if(valid)
     {
@@ -379,7 +590,7 @@ __device__ __forceinline__ double wave_max(double v)
   return v;
 }
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS>
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
 __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
     TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
     const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
@@ -614,6 +825,17 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
             ay = __builtin_fma(dy[k], f, ay);
             az = __builtin_fma(dz[k], f, az);
             nint += in[k] ? 1 : 0;
+            if(LATT)
+              {
+                // periodic tree-only: every source also contributes its infinite lattice of images (forcetree.c:1605-1607);
+                // here on the SAME (finer) interaction list as the nearest-image force
+                double fx, fy, fz;
+                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, dx[k], dy[k], dz[k], fx, fy, fz);
+                const double mk = in[k] ? e[k].w : 0.0;
+                ax = __builtin_fma(mk, fx, ax);
+                ay = __builtin_fma(mk, fy, ay);
+                az = __builtin_fma(mk, fz, az);
+              }
           }
       };
 
@@ -993,7 +1215,7 @@ __global__ void k_finish(long long t_first, long long t_count, const unsigned ch
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void k_direct(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
                                                  long long n, const int *__restrict__ tidx, long long nt, WalkParams wp,
-                                                 LawIds li, double G, double *__restrict__ acc)
+                                                 LawIds li, double G, const double *__restrict__ lat, double *__restrict__ acc)
 {
   // one block per target, threads stride over sources, fp64 block reduction
   long long k = blockIdx.x;
@@ -1023,6 +1245,14 @@ __global__ __launch_bounds__(256) void k_direct(const double4 *__restrict__ s_pm
       ax += dx * fac;
       ay += dy * fac;
       az += dz * fac;
+      if(lat && u > 1.0e-5)   // forcetree.c:3519-3528
+        {
+          double fx, fy, fz;
+          lat_lookup(lat + ((size_t)tg * wp.ng + sg) * LAT_SZ, wp.fac_intp, dx, dy, dz, fx, fy, fz);
+          ax += q.w * fx;
+          ay += q.w * fy;
+          az += q.w * fz;
+        }
     }
   __shared__ double sh[3][4];
   for(int off = 32; off > 0; off >>= 1)
@@ -1081,6 +1311,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
       wp->reach2 = reach * reach;
     }
   wp->ym = cfg.box_size > 0 ? cfg.yukawa_imass / cfg.box_size : 0.0;
+  wp->fac_intp = cfg.box_size > 0 ? 2.0 * LAT_EN / cfg.box_size : 0.0;   // forcetree.c:3737
   for(int t = 0; t < NGRAVS_NTYPES; t++)
     {
       wp->fsoft[t] = cfg.force_softening[t];
@@ -1130,16 +1361,49 @@ static TreeView tree_view(ngravs_ctx *c)
   return tv;
 }
 
-template <int NG, bool PM> static void launch_strict(ngravs_ctx *c, const WalkParams &wp, const LawIds &li)
+// lattice_init: one Ewald / lattice sum per distinct law, replicated into the [target][source] slots
+static int ensure_lattice(ngravs_ctx *c)
+{
+  if(c->lat_ready)
+    return NGRAVS_OK;
+  const int ng = c->cfg.n_gravs;
+  if(c->lat.ensure((size_t)ng * ng * LAT_SZ))
+    return NGRAVS_ERR_NOMEM;
+  const double L2 = c->cfg.box_size * c->cfg.box_size;
+  const int npts = LAT_E1 * LAT_E1 * LAT_E1;
+  for(int a = 0; a < ng; a++)
+    for(int b = 0; b < ng; b++)
+      {
+        const int law = c->cfg.law_accel[a][b];
+        int src = -1;
+        for(int k = 0; k < a * ng + b; k++)
+          if(c->cfg.law_accel[k / ng][k % ng] == law)
+            {
+              src = k;
+              break;
+            }
+        double *dst = c->lat.p + (size_t)(a * ng + b) * LAT_SZ;
+        if(src >= 0)
+          HIP_TRY(c, hipMemcpyAsync(dst, c->lat.p + (size_t)src * LAT_SZ, sizeof(double) * LAT_SZ, hipMemcpyDeviceToDevice, c->stream));
+        else
+          hipLaunchKernelGGL(k_lattice_table, dim3((npts + 63) / 64), dim3(64), 0, c->stream, law, c->cfg.yukawa_imass, L2, dst);
+      }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->lat_ready = true;
+  return NGRAVS_OK;
+}
+
+template <int NG, bool PM, bool LATT> static void launch_strict(ngravs_ctx *c, const WalkParams &wp, const LawIds &li)
 {
   long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
   unsigned nb = (unsigned)((ngroups + 3) / 4);
-  hipLaunchKernelGGL((k_walk_strict<NG, PM>), dim3(nb), dim3(256), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
-                     c->s_oldacc.p, c->s_active.p, c->table.p, wp, li, (long long)c->shard_first,
+  hipLaunchKernelGGL((k_walk_strict<NG, PM, LATT>), dim3(nb), dim3(256), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
+                     c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, li, (long long)c->shard_first,
                      (long long)c->shard_count, c->r_acc.p, c->r_nint.p);
 }
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngravs_ctx *c, const WalkParams &wp)
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_group_t(ngravs_ctx *c, const WalkParams &wp)
 {
   int ncu = 256;
   hipDeviceProp_t prop;
@@ -1166,10 +1430,10 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS> static int launch_group_t(ngr
   if(c->walk_stack.ensure((size_t)nblk * waves * GW_STACK) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
-  auto kern = k_walk_group<NG, PM, YUK, TAB_LDS>;
+  auto kern = k_walk_group<NG, PM, YUK, TAB_LDS, LATT>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
-                     c->s_type.p, c->s_oldacc.p, c->s_active.p, c->table.p, wp, (long long)c->shard_first,
+                     c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                      (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
                      c->r_nint.p);
   return NGRAVS_OK;
@@ -1180,8 +1444,10 @@ template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp)
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 144 KB of tables do not fit beside the lists -> read through L1/L2
   if(pm)
-    return yuk ? launch_group_t<NG, true, true, TL>(c, wp) : launch_group_t<NG, true, false, TL>(c, wp);
-  return yuk ? launch_group_t<NG, false, true, false>(c, wp) : launch_group_t<NG, false, false, false>(c, wp);
+    return yuk ? launch_group_t<NG, true, true, TL, false>(c, wp) : launch_group_t<NG, true, false, TL, false>(c, wp);
+  if(c->cfg.periodic)
+    return yuk ? launch_group_t<NG, false, true, false, true>(c, wp) : launch_group_t<NG, false, false, false, true>(c, wp);
+  return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
 }
 
 int walk_run(ngravs_ctx *c)
@@ -1189,10 +1455,12 @@ int walk_run(ngravs_ctx *c)
   const long long n = c->n;
   if(c->r_acc.ensure(3 * n) || c->r_nint.ensure(n) || c->r_oldacc.ensure(n))
     return NGRAVS_ERR_NOMEM;
-  if(c->cfg.periodic && !c->cfg.pmgrid)
+  const bool latt = c->cfg.periodic && !c->cfg.pmgrid;
+  if(latt)
     {
-      ngravs_report(c, NGRAVS_ERR_ARG, "PERIODIC without PMGRID (Ewald lattice correction, forcetree.c:2077) is not built yet");
-      return NGRAVS_ERR_ARG;
+      int rcl = ensure_lattice(c);   // begrun.c:47-49: lattice_init() if PERIODIC && !PMGRID
+      if(rcl)
+        return rcl;
     }
   WalkParams wp;
   make_walk_params(c, &wp);
@@ -1208,13 +1476,13 @@ int walk_run(ngravs_ctx *c)
       switch(c->cfg.n_gravs)
         {
         case 1:
-          pm ? launch_strict<1, true>(c, wp, li) : launch_strict<1, false>(c, wp, li);
+          pm ? launch_strict<1, true, false>(c, wp, li) : (latt ? launch_strict<1, false, true>(c, wp, li) : launch_strict<1, false, false>(c, wp, li));
           break;
         case 2:
-          pm ? launch_strict<2, true>(c, wp, li) : launch_strict<2, false>(c, wp, li);
+          pm ? launch_strict<2, true, false>(c, wp, li) : (latt ? launch_strict<2, false, true>(c, wp, li) : launch_strict<2, false, false>(c, wp, li));
           break;
         default:
-          pm ? launch_strict<3, true>(c, wp, li) : launch_strict<3, false>(c, wp, li);
+          pm ? launch_strict<3, true, false>(c, wp, li) : (latt ? launch_strict<3, false, true>(c, wp, li) : launch_strict<3, false, false>(c, wp, li));
           break;
         }
     }
@@ -1275,8 +1543,15 @@ int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc)
   make_walk_params(c, &wp);
   LawIds li;
   make_law_ids(c, &li);
+  const bool latt = c->cfg.periodic != 0;   // forcetree.c:3515-3529: the PERIODIC direct sum adds lattice_corr
+  if(latt)
+    {
+      int rcl = ensure_lattice(c);
+      if(rcl)
+        return rcl;
+    }
   hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, (long long)c->n, d_idx,
-                     (long long)nt, wp, li, c->cfg.G, d_acc);
+                     (long long)nt, wp, li, c->cfg.G, latt ? c->lat.p : (const double *)nullptr, d_acc);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }

@@ -204,8 +204,9 @@ int ngravs_peano_keys(ngravs_ctx *ctx, const double *pos, int64_t n, const doubl
 /* shortrange_fourier_force[target][source][NTAB] (forcetree.c:3246-3403): out has
  * n_gravs*n_gravs*NTAB doubles; pot_out (may be NULL) the matching shortrange_fourier_pot. */
 int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, double *pot_out);
-/* force_treeevaluate_direct for targets idx[0..nt) against all particles, non-periodic or
- * nearest-image (no Ewald term); result xG into acc[3*nt] (forcetree.c:3428-3548). */
+/* force_treeevaluate_direct for targets idx[0..nt) against all particles; with PERIODIC the nearest-image
+ * sum plus lattice_corr (Ewald / lattice-sum tables, forcetree.c:3515-3529, 3803-3885), i.e. the truth
+ * gravity_forcetest() compares the tree / TreePM force against; result xG into acc[3*nt]. */
 int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *acc);
 
 /* ---- multi-task domain decomposition ------------------------------------------------------------------

@@ -1164,9 +1164,281 @@ int orc_pm_periodic(const ngravs_config_t *cfg, const double *pos, const double 
   return 0;
 }
 
-/* force_treeevaluate_direct (forcetree.c:3428-3548) without lattice_corr; xG as gravity_forcetest */
+
+/* ------------------------------------------------------------------------------------------
+ * Periodic tree-only path: Ewald / lattice-sum correction tables (lattice_init forcetree.c:3611-3793;
+ * ewald_force ngravs.c:1170-1232; yukawa_lattice_force ngravs.c:1019-1090; coloyuk_lattice_force :840-847)
+ * and their trilinear lookup (lattice_corr forcetree.c:3803-3885).  EN = NGRAVS_EN = 64.
+ * table layout: [3][EN+1][EN+1][EN+1], already divided by BoxSize^2 (forcetree.c:3742-3750).
+ * ------------------------------------------------------------------------------------------ */
+#define ORC_EN 64
+static void lat_newton(int i, int j, int k, const double x[3], double force[3])
+{
+  const double alpha = 2.0;
+  for(int c = 0; c < 3; c++)
+    force[c] = 0;
+  if(i == 0 && j == 0 && k == 0)
+    return;
+  double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  for(int c = 0; c < 3; c++)
+    force[c] += x[c] / (r2 * sqrt(r2));
+  for(int n0 = -4; n0 <= 4; n0++)
+    for(int n1 = -4; n1 <= 4; n1++)
+      for(int n2 = -4; n2 <= 4; n2++)
+        {
+          double dx[3] = {x[0] - n0, x[1] - n1, x[2] - n2};
+          double r = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+          double val = erfc(alpha * r) + 2 * alpha * r / sqrt(M_PI) * exp(-alpha * alpha * r * r);
+          for(int c = 0; c < 3; c++)
+            force[c] -= dx[c] / (r * r * r) * val;
+        }
+  for(int h0 = -4; h0 <= 4; h0++)
+    for(int h1 = -4; h1 <= 4; h1++)
+      for(int h2_ = -4; h2_ <= 4; h2_++)
+        {
+          int h[3] = {h0, h1, h2_};
+          double hdotx = x[0] * h0 + x[1] * h1 + x[2] * h2_;
+          int h2 = h0 * h0 + h1 * h1 + h2_ * h2_;
+          if(h2 > 0)
+            {
+              double val = 2.0 / ((double)h2) * exp(-M_PI * M_PI * h2 / (alpha * alpha)) * sin(2 * M_PI * hdotx);
+              for(int c = 0; c < 3; c++)
+                force[c] -= h[c] * val;
+            }
+        }
+}
+static void lat_yukawa(double ymass, int i, int j, int k, const double x[3], double force[3])
+{
+  const double alpha = 5.64;
+  for(int c = 0; c < 3; c++)
+    force[c] = 0;   /* the reference leaves the origin entry unset (ngravs.c:1029-1030); 0 here */
+  if(i == 0 && j == 0 && k == 0)
+    return;
+  double r2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], r = sqrt(r2), ym = ymass;
+  for(int c = 0; c < 3; c++)
+    force[c] = exp(-r * ym) * (ym + 1.0 / r) * x[c] / r2;
+  for(int n0 = -5; n0 <= 5; n0++)
+    for(int n1 = -5; n1 <= 5; n1++)
+      for(int n2 = -5; n2 <= 5; n2++)
+        {
+          double dx[3] = {x[0] - n0, x[1] - n1, x[2] - n2};
+          r = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+          double ep = exp(ym * r) * erfc(alpha * r + ym / (2 * alpha)), em = exp(-ym * r) * erfc(alpha * r - ym / (2 * alpha));
+          double val = 0.5 * (ep + em);
+          for(int c = 0; c < 3; c++)
+            force[c] -= dx[c] / (r * r * r) * val;
+          val = 0.5 * ym * (-ep + em) + 2 * alpha * exp(-alpha * alpha * r * r - ym * ym / (4 * alpha * alpha)) / sqrt(M_PI);
+          for(int c = 0; c < 3; c++)
+            force[c] -= dx[c] / (r * r) * val;
+        }
+  ym /= 2 * M_PI;
+  for(int h0 = -5; h0 <= 5; h0++)
+    for(int h1 = -5; h1 <= 5; h1++)
+      for(int h2_ = -5; h2_ <= 5; h2_++)
+        {
+          int h[3] = {h0, h1, h2_};
+          double hdotx = x[0] * h0 + x[1] * h1 + x[2] * h2_;
+          int h2 = h0 * h0 + h1 * h1 + h2_ * h2_;
+          if(h2 > 0)
+            {
+              double val = 2 * exp(-M_PI * M_PI * (h2 + ym * ym) / (alpha * alpha)) * sin(2 * M_PI * hdotx) / (h2 + ym * ym);
+              for(int c = 0; c < 3; c++)
+                force[c] -= h[c] * val;
+            }
+        }
+}
+void orc_lattice_table(const ngravs_config_t *cfg, int law, double *tab)
+{
+  const int E1 = ORC_EN + 1;
+  const double L2 = cfg->box_size * cfg->box_size;
+#pragma omp parallel for schedule(dynamic, 64)
+  for(int n = 0; n < E1 * E1 * E1; n++)
+    {
+      int i = n / (E1 * E1), j = (n / E1) % E1, k = n % E1;
+      double x[3] = {0.5 * ((double)i) / ORC_EN, 0.5 * ((double)j) / ORC_EN, 0.5 * ((double)k) / ORC_EN};
+      double f[3] = {0, 0, 0}, g[3];
+      if(law == NGRAVS_LAW_NEWTON || law == NGRAVS_LAW_NEG_NEWTON || law == NGRAVS_LAW_COLOYUK)
+        {
+          lat_newton(i, j, k, x, g);
+          for(int c = 0; c < 3; c++)
+            f[c] += (law == NGRAVS_LAW_NEG_NEWTON ? -g[c] : g[c]);
+        }
+      if(law == NGRAVS_LAW_YUKAWA || law == NGRAVS_LAW_COLOYUK)
+        {
+          lat_yukawa(cfg->yukawa_imass, i, j, k, x, g);
+          for(int c = 0; c < 3; c++)
+            f[c] += g[c];
+        }
+      for(int c = 0; c < 3; c++)
+        tab[(size_t)c * E1 * E1 * E1 + n] = f[c] / L2;
+    }
+}
+/* lattice_corr: dx,dy,dz dimensionful nearest-image displacement -> fper[3] (to be multiplied by the source mass) */
+static void lat_lookup(const double *tab, double box, double dx, double dy, double dz, double fper[3])
+{
+  const int E1 = ORC_EN + 1;
+  const double fac_intp = 2 * ORC_EN / box;
+  int sx, sy, sz;
+  if(dx < 0) { dx = -dx; sx = +1; } else sx = -1;
+  if(dy < 0) { dy = -dy; sy = +1; } else sy = -1;
+  if(dz < 0) { dz = -dz; sz = +1; } else sz = -1;
+  double u = dx * fac_intp, v = dy * fac_intp, w = dz * fac_intp;
+  int i = (int)u, j = (int)v, k = (int)w;
+  if(i >= ORC_EN) i = ORC_EN - 1;
+  if(j >= ORC_EN) j = ORC_EN - 1;
+  if(k >= ORC_EN) k = ORC_EN - 1;
+  u -= i; v -= j; w -= k;
+  double f[8] = {(1 - u) * (1 - v) * (1 - w), (1 - u) * (1 - v) * (w), (1 - u) * (v) * (1 - w), (1 - u) * (v) * (w),
+                 (u) * (1 - v) * (1 - w),     (u) * (1 - v) * (w),     (u) * (v) * (1 - w),     (u) * (v) * (w)};
+  const int sg[3] = {sx, sy, sz};
+  for(int c = 0; c < 3; c++)
+    {
+      const double *t = tab + (size_t)c * E1 * E1 * E1;
+#define T3(a, b, d) t[((size_t)(a) * E1 + (b)) * E1 + (d)]
+      fper[c] = sg[c] * (T3(i, j, k) * f[0] + T3(i, j, k + 1) * f[1] + T3(i, j + 1, k) * f[2] + T3(i, j + 1, k + 1) * f[3] +
+                         T3(i + 1, j, k) * f[4] + T3(i + 1, j, k + 1) * f[5] + T3(i + 1, j + 1, k) * f[6] + T3(i + 1, j + 1, k + 1) * f[7]);
+#undef T3
+    }
+}
+
+/* force_treeevaluate_lattice_correction (forcetree.c:2077-2455), mode 0; lat = [tg][sg][3][E1^3] */
+static int lattice_walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t target, double aold_in, const double *lat,
+                            double acc[3])
+{
+  const int ng = t->ng, E1 = ORC_EN + 1;
+  const size_t tsz = (size_t)3 * E1 * E1 * E1;
+  const double boxsize = cfg->box_size, boxhalf = 0.5 * cfg->box_size;
+  const double px = t->pos[3 * target], py = t->pos[3 * target + 1], pz = t->pos[3 * target + 2];
+  const int tg = cfg->type_to_grav[t->type[target]];
+  const double aold = cfg->err_tol_force_acc * aold_in;
+  double ax = 0, ay = 0, az = 0;
+  int cost = 0;
+  double dx[MAXG], dy[MAXG], dz[MAXG], m[MAXG], r2[MAXG];
+  int no = (int)t->maxpart;
+  while(no >= 0)
+    {
+      int sg;
+      if(no < t->maxpart)
+        {
+          sg = cfg->type_to_grav[t->type[no]];
+          m[sg] = t->mass[no];
+          dx[sg] = NEAREST(t->pos[3 * no] - px);
+          dy[sg] = NEAREST(t->pos[3 * no + 1] - py);
+          dz[sg] = NEAREST(t->pos[3 * no + 2] - pz);
+          no = t->pnext[no];
+        }
+      else
+        {
+          int64_t a = no - t->maxpart;
+          double r2min = INFINITY, summass = 0;
+          for(int g = 0; g < ng; g++)
+            {
+              m[g] = t->nmass[a * ng + g];
+              summass += m[g];
+              dx[g] = NEAREST(t->s[(a * 3 + 0) * ng + g] - px);
+              dy[g] = NEAREST(t->s[(a * 3 + 1) * ng + g] - py);
+              dz[g] = NEAREST(t->s[(a * 3 + 2) * ng + g] - pz);
+              r2[g] = dx[g] * dx[g] + dy[g] * dy[g] + dz[g] * dz[g];
+              if(r2[g] < r2min)
+                r2min = r2[g];
+            }
+          sg = -1;
+          const double len = t->len[a];
+          const double *ctr = &t->center[3 * a];
+          int openflag = 0;
+          if(cfg->err_tol_theta != 0)
+            {
+              if(len * len > r2min * cfg->err_tol_theta * cfg->err_tol_theta)
+                openflag = 1;
+            }
+          else
+            {
+              if(summass * len * len > r2min * r2min * aold)
+                openflag = 1;
+              else if(fabs(ctr[0] - px) < 0.60 * len && fabs(ctr[1] - py) < 0.60 * len && fabs(ctr[2] - pz) < 0.60 * len)
+                openflag = 1;
+            }
+          if(openflag)
+            {
+              int must = 0;
+              for(int j = 0; j < 3 && !must; j++)
+                {
+                  double u = ctr[j] - (j == 0 ? px : (j == 1 ? py : pz));
+                  if(u > boxhalf)
+                    u -= boxsize;
+                  if(u < -boxhalf)
+                    u += boxsize;
+                  if(fabs(u) > 0.5 * (boxsize - len))
+                    must = 1;
+                }
+              if(!must && len > 0.20 * boxsize)
+                must = 1;
+              if(must)
+                {
+                  no = t->nextnode[a];
+                  continue;
+                }
+            }
+          no = t->sibling[a];
+        }
+      for(int g = (sg >= 0 ? sg : 0); g < (sg >= 0 ? sg + 1 : ng); g++)
+        {
+          if(sg < 0 && m[g] == 0.0)
+            continue;
+          double f[3];
+          lat_lookup(lat + ((size_t)tg * ng + g) * tsz, boxsize, dx[g], dy[g], dz[g], f);
+          ax += m[g] * f[0];
+          ay += m[g] * f[1];
+          az += m[g] * f[2];
+        }
+      cost++;
+    }
+  acc[0] = ax;
+  acc[1] = ay;
+  acc[2] = az;
+  return cost;
+}
+
+/* adds the lattice correction (and its cost) to acc/nint computed by orc_walk: forcetree.c:1605-1607 */
+int orc_lattice_walk(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,
+                     const double *lat, double *acc, int32_t *nint, int nthreads)
+{
+  if(!idx)
+    nt = t->n;
+#ifdef _OPENMP
+  if(nthreads > 0)
+    omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 256)
+  for(int64_t k = 0; k < nt; k++)
+    {
+      int64_t i = idx ? idx[k] : k;
+      double a[3];
+      int c = lattice_walk_one(t, cfg, i, old_acc ? old_acc[i] : 0.0, lat, a);
+      acc[3 * k] += a[0];
+      acc[3 * k + 1] += a[1];
+      acc[3 * k + 2] += a[2];
+      if(nint)
+        nint[k] += c;
+    }
+  return 0;
+}
+
+/* force_treeevaluate_direct (forcetree.c:3428-3548); lat != NULL adds lattice_corr (PERIODIC); xG as gravity_forcetest */
+static void orc_direct_impl(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                            const int32_t *idx, int64_t nt, double *acc, int nthreads, const double *lat);
 void orc_direct(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
                 const int32_t *idx, int64_t nt, double *acc, int nthreads)
+{
+  orc_direct_impl(cfg, pos, mass, type, n, idx, nt, acc, nthreads, NULL);
+}
+void orc_direct_lattice(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                        const int32_t *idx, int64_t nt, double *acc, int nthreads, const double *lat)
+{
+  orc_direct_impl(cfg, pos, mass, type, n, idx, nt, acc, nthreads, lat);
+}
+static void orc_direct_impl(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                            const int32_t *idx, int64_t nt, double *acc, int nthreads, const double *lat)
 {
   const double boxsize = cfg->box_size, boxhalf = 0.5 * cfg->box_size;
 #ifdef _OPENMP
@@ -1208,6 +1480,15 @@ void orc_direct(const ngravs_config_t *cfg, const double *pos, const double *mas
           ax += dx * fac;
           ay += dy * fac;
           az += dz * fac;
+          if(lat && u > 1.0e-5)   /* forcetree.c:3519-3528 */
+            {
+              double fc[3];
+              const size_t tsz = (size_t)3 * (ORC_EN + 1) * (ORC_EN + 1) * (ORC_EN + 1);
+              lat_lookup(lat + ((size_t)tg * cfg->n_gravs + sg) * tsz, cfg->box_size, dx, dy, dz, fc);
+              ax += mass[i] * fc[0];
+              ay += mass[i] * fc[1];
+              az += mass[i] * fc[2];
+            }
         }
       acc[3 * k] = ax * cfg->G;
       acc[3 * k + 1] = ay * cfg->G;

@@ -57,6 +57,12 @@ int orc_pm_periodic(const ngravs_config_t *cfg, const double *pos, const double 
 /* forcetree.c:3428-3548 without the Ewald term; acc xG */
 void orc_direct(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type,
                 int64_t n, const int32_t *idx, int64_t nt, double *acc, int nthreads);
+/* periodic tree-only path: lattice (Ewald) tables [3][65^3] for one law, the correction walk, direct sum with lattice_corr */
+void orc_lattice_table(const ngravs_config_t *cfg, int law, double *tab);
+int orc_lattice_walk(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,
+                     const double *lat, double *acc, int32_t *nint, int nthreads);
+void orc_direct_lattice(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                        const int32_t *idx, int64_t nt, double *acc, int nthreads, const double *lat);
 /* scalar law probes for the KATs: which = 0 accel,1 spline,2 greens,3 normed */
 double orc_law_eval(const ngravs_config_t *cfg, int which, int id, double a3, double a4);
 

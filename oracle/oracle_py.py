@@ -168,3 +168,41 @@ def direct(cfg, pos, mass, ptype, idx, nthreads=0):
 
 def law_eval(cfg, which, law_id, a3, a4):
     return float(lib().orc_law_eval(C.byref(cfg), which, law_id, a3, a4))
+
+
+EN1 = 65
+
+
+def lattice_tables(cfg):
+    """[tg][sg][3][65][65][65] force-correction tables (lattice_init), one Ewald/lattice sum per distinct law"""
+    ng = cfg.n_gravs
+    out = np.zeros((ng, ng, 3, EN1, EN1, EN1))
+    cache = {}
+    for a in range(ng):
+        for b in range(ng):
+            law = cfg.law_accel[a][b]
+            if law not in cache:
+                t = np.zeros((3, EN1, EN1, EN1))
+                lib().orc_lattice_table(C.byref(cfg), C.c_int(law), _p(t))
+                cache[law] = t
+            out[a, b] = cache[law]
+    return out
+
+
+def lattice_walk(tree, acc, nint, lat, old_acc=None, idx=None, cfg=None, nthreads=0):
+    """adds force_treeevaluate_lattice_correction to (acc, nint) in place"""
+    cfg = cfg if cfg is not None else tree.cfg
+    idx_a = _i32(idx) if idx is not None else None
+    nt = len(idx_a) if idx_a is not None else tree.n
+    oa = _f64(old_acc) if old_acc is not None else None
+    lat = _f64(lat)
+    lib().orc_lattice_walk(tree.h, C.byref(cfg), _p(idx_a), C.c_int64(nt), _p(oa), _p(lat), _p(acc), _p(nint), C.c_int(nthreads))
+    return acc, nint
+
+
+def direct_lattice(cfg, pos, mass, ptype, idx, lat, nthreads=0):
+    pos, mass, ptype, idx, lat = _f64(pos), _f64(mass), _i32(ptype), _i32(idx), _f64(lat)
+    out = np.zeros((len(idx), 3))
+    lib().orc_direct_lattice(C.byref(cfg), _p(pos), _p(mass), _p(ptype), C.c_int64(len(pos)), _p(idx), C.c_int64(len(idx)),
+                             _p(out), C.c_int(nthreads), _p(lat))
+    return out
