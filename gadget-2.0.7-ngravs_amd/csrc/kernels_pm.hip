@@ -273,15 +273,17 @@ __global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsi
   atomicAdd(&grid[((long long)sxx * N + syy) * NZ + szz], m * (dx)*dy * dz);
 }
 
-// gather: one workgroup per level-Lt node, one species at a time through an LDS copy of the potential patch
+// gather: one workgroup per node of the level whose cells are at most 8 mesh cells wide; the potential patches of
+// ALL species (edge 8 + misalignment + CIC neighbour + 2x2 gradient halo = 15) sit in LDS, one thread per particle
+#define PM_G8 15
 template <int NG>
-__global__ __launch_bounds__(PM_TILE_THREADS) void k_gradient_gather_tiled(
-    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const int *__restrict__ n_first,
-    const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0, long long shard_first,
-    long long shard_count, double to_slab, int N, const int *__restrict__ t2g_tab, const double *__restrict__ phi,
-    double fac, double *__restrict__ r_pm)
+__global__ __launch_bounds__(256) void k_gradient_gather_tiled(
+    const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const unsigned char *__restrict__ s_flag,
+    const int *__restrict__ n_first, const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0,
+    long long shard_first, long long shard_count, double to_slab, int N, const int *__restrict__ t2g_tab,
+    const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
 {
-  extern __shared__ double tile[];   // [GT][GT][GT]
+  extern __shared__ double tile[];   // [NG][G8][G8][G8]
   const int node = node0 + blockIdx.x;
   const int first = n_first[node], count = n_count[node];
   if((long long)first + count <= shard_first || (long long)first >= shard_first + shard_count)
@@ -295,53 +297,59 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_gradient_gather_tiled(
     o[1] = (int)floor((geo.y - h) * to_slab) - 2;
     o[2] = (int)floor((geo.z - h) * to_slab) - 2;
   }
-  for(int g = 0; g < NG; g++)
+  constexpr int T3 = PM_G8 * PM_G8 * PM_G8;
+  for(int t = threadIdx.x; t < NG * T3; t += blockDim.x)
     {
+      const int g = t / T3, r = t - g * T3;
+      const int lx = r / (PM_G8 * PM_G8), ly = (r / PM_G8) % PM_G8, lz = r % PM_G8;
+      tile[t] = phi[(size_t)g * N * N * NZ + ((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)];
+    }
+  __syncthreads();
+  for(int k = threadIdx.x; k < count; k += blockDim.x)
+    {
+      const long long i = (long long)first + k;
+      if(i < shard_first || i >= shard_first + shard_count)
+        continue;
+      if(s_flag[i] & 2)
+        {
+          r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
+          continue;
+        }
+      const int g = t2g_tab[s_type[i]];
       const double *grid = phi + (size_t)g * N * N * NZ;
-      __syncthreads();
-      for(int t = threadIdx.x; t < PM_GT * PM_GT * PM_GT; t += blockDim.x)
+      const double *tg = tile + (size_t)g * T3;
+      const double4 p = s_pm[i];
+      double dx, dy, dz;
+      const int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+      const int lx = sx - o[0], ly = sy - o[1], lz = sz - o[2];
+      const bool inside = lx >= 2 && ly >= 2 && lz >= 2 && lx < PM_G8 - 3 && ly < PM_G8 - 3 && lz < PM_G8 - 3;
+      const double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+      double acc[3] = {0, 0, 0};
+      const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+      auto at = [&](int x, int y, int z) -> double {
+        if(inside)
+          return tg[(x * PM_G8 + y) * PM_G8 + z];
+        return grid[((long long)wrapN(o[0] + x, N) * N + wrapN(o[1] + y, N)) * NZ + wrapN(o[2] + z, N)];
+      };
+      for(int c = 0; c < 8; c++)
         {
-          const int lx = t / (PM_GT * PM_GT), ly = (t / PM_GT) % PM_GT, lz = t % PM_GT;
-          tile[t] = grid[((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)];
+          const int x = lx + ox[c], y = ly + oy[c], z = lz + oz[c];
+          const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
+          const double fxv = fac * ((4.0 / 3) * (at(x - 1, y, z) - at(x + 1, y, z)) - (1.0 / 6) * (at(x - 2, y, z) - at(x + 2, y, z)));
+          const double fyv = fac * ((4.0 / 3) * (at(x, y - 1, z) - at(x, y + 1, z)) - (1.0 / 6) * (at(x, y - 2, z) - at(x, y + 2, z)));
+          const double fzv = fac * ((4.0 / 3) * (at(x, y, z - 1) - at(x, y, z + 1)) - (1.0 / 6) * (at(x, y, z - 2) - at(x, y, z + 2)));
+          acc[0] += fxv * w;
+          acc[1] += fyv * w;
+          acc[2] += fzv * w;
         }
-      __syncthreads();
-      for(int k = threadIdx.x; k < count; k += blockDim.x)
-        {
-          const long long i = (long long)first + k;
-          if(i < shard_first || i >= shard_first + shard_count || t2g_tab[s_type[i]] != g)
-            continue;
-          const double4 p = s_pm[i];
-          double dx, dy, dz;
-          const int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
-          const int lx = sx - o[0], ly = sy - o[1], lz = sz - o[2];
-          const bool inside = lx >= 2 && ly >= 2 && lz >= 2 && lx < PM_GT - 3 && ly < PM_GT - 3 && lz < PM_GT - 3;
-          const double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
-          double acc[3] = {0, 0, 0};
-          const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
-          auto at = [&](int x, int y, int z) -> double {
-            if(inside)
-              return tile[(x * PM_GT + y) * PM_GT + z];
-            return grid[((long long)wrapN(o[0] + x, N) * N + wrapN(o[1] + y, N)) * NZ + wrapN(o[2] + z, N)];
-          };
-          for(int c = 0; c < 8; c++)
-            {
-              const int x = lx + ox[c], y = ly + oy[c], z = lz + oz[c];
-              const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
-              const double fxv = fac * ((4.0 / 3) * (at(x - 1, y, z) - at(x + 1, y, z)) - (1.0 / 6) * (at(x - 2, y, z) - at(x + 2, y, z)));
-              const double fyv = fac * ((4.0 / 3) * (at(x, y - 1, z) - at(x, y + 1, z)) - (1.0 / 6) * (at(x, y - 2, z) - at(x, y + 2, z)));
-              const double fzv = fac * ((4.0 / 3) * (at(x, y, z - 1) - at(x, y, z + 1)) - (1.0 / 6) * (at(x, y, z - 2) - at(x, y, z + 2)));
-              acc[0] += fxv * w;
-              acc[1] += fyv * w;
-              acc[2] += fzv * w;
-            }
-          r_pm[3 * i + 0] = acc[0];
-          r_pm[3 * i + 1] = acc[1];
-          r_pm[3 * i + 2] = acc[2];
-        }
+      r_pm[3 * i + 0] = acc[0];
+      r_pm[3 * i + 1] = acc[1];
+      r_pm[3 * i + 2] = acc[2];
     }
 }
 
 __global__ void k_gradient_gather_loose(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                        const unsigned char *__restrict__ s_flag,
                                         const int *__restrict__ n_child, int nnodes_above, long long shard_first,
                                         long long shard_count, double to_slab, int N, const int *__restrict__ t2g_tab,
                                         const double *__restrict__ phi, double fac, double *__restrict__ r_pm)
@@ -355,6 +363,11 @@ __global__ void k_gradient_gather_loose(const double4 *__restrict__ s_pm, const 
   const long long i = -2 - c;
   if(i < shard_first || i >= shard_first + shard_count)
     return;
+  if(s_flag[i] & 2)
+    {
+      r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
+      return;
+    }
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
   const long long NZ = N + 2;
@@ -382,13 +395,13 @@ __global__ void k_gradient_gather_loose(const double4 *__restrict__ s_pm, const 
 }
 
 // the level whose cells are at most 16 mesh cells wide (-1: no such level in this tree -> per-particle kernels)
-static int pm_tile_level(const ngravs_ctx *c, double to_slab)
+static int pm_tile_level(const ngravs_ctx *c, double to_slab, double max_cells = 16.0)
 {
   if(!c->have_tree || getenv("NGRAVS_PM_NOTILE"))
     return -1;
   double len = c->dom[6];
   for(int l = 0; l < c->nlevels && l < TREE_BITS; l++, len *= 0.5)
-    if(len * to_slab <= 16.0)
+    if(len * to_slab <= max_cells)
       return (c->level_start[l + 1] - c->level_start[l] > 0) ? l : -1;
   return -1;
 }
@@ -530,25 +543,28 @@ int pm_finish(ngravs_ctx *c)
   if(c->cfg.world_size > 1)
     HIP_TRY(c, hipMemsetAsync(c->r_pm.p, 0, sizeof(double) * 3 * n, c->stream));
   unsigned nbg = (unsigned)((c->shard_count + bs - 1) / bs);
-  // measured at C4: the tiled gather (24.6 ms) loses to the per-particle one (13.3 ms) because each species pass
-  // leaves half the lanes idle; it stays available for tuning behind NGRAVS_PM_TILE_GATHER
-  if(tl >= 0 && getenv("NGRAVS_PM_TILE_GATHER"))
+  // tiled gather (cells at most 8 mesh cells wide, all species' potential patches in LDS): measured at C4 it LOSES to the
+  // per-particle gather (73 ms vs 13.3 ms -- 14 GB of short-row patch loads; the 16-cell one-species variant took 24.6 ms),
+  // so it is opt-in for tuning only
+  const int gl = getenv("NGRAVS_PM_TILE_GATHER") ? pm_tile_level(c, to_slab, 8.0) : -1;
+  if(gl >= 0)
     {
-      const size_t lds = sizeof(double) * PM_GT * PM_GT * PM_GT;
+      const long long gl0 = c->level_start[gl], gln = c->level_start[gl + 1] - gl0;
+      const size_t lds = sizeof(double) * ng * PM_G8 * PM_G8 * PM_G8;
       auto launch_gat = [&](auto kern) -> int {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                           c->n_count.p, c->n_geo.p, (int)tl0, (long long)c->shard_first, (long long)c->shard_count, to_slab, N,
+        hipLaunchKernelGGL(kern, dim3((unsigned)gln), dim3(256), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, c->n_first.p,
+                           c->n_count.p, c->n_geo.p, (int)gl0, (long long)c->shard_first, (long long)c->shard_count, to_slab, N,
                            c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
         return NGRAVS_OK;
       };
       int rc = ng == 1 ? launch_gat(k_gradient_gather_tiled<1>) : (ng == 2 ? launch_gat(k_gradient_gather_tiled<2>) : launch_gat(k_gradient_gather_tiled<3>));
       if(rc)
         return rc;
-      if(tl0 > 0)
-        hipLaunchKernelGGL(k_gradient_gather_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
-                           c->s_type.p, c->n_child.p, (int)tl0, (long long)c->shard_first, (long long)c->shard_count, to_slab, N,
-                           c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+      if(gl0 > 0)
+        hipLaunchKernelGGL(k_gradient_gather_loose, dim3((unsigned)((8 * gl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
+                           c->s_type.p, c->s_active.p, c->n_child.p, (int)gl0, (long long)c->shard_first, (long long)c->shard_count,
+                           to_slab, N, c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
     }
   else if(nbg > 0)
     hipLaunchKernelGGL(k_gradient_gather, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, (long long)c->shard_first,
