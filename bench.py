@@ -151,11 +151,13 @@ def main():
                     help="N>1: 'replicated' = every rank holds all particles, the walk is sharded (default, no data-path "
                          "collective); 'domain' = Peano-Hilbert domain decomposition with migration + halo all-to-all-v and "
                          "an all-reduced PM mesh (memory-scalable; see DESIGN.md Multi-GPU)")
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4"],
+    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 (default, the metric's) | c3: 16M N_GRAVS=1 PMGRID=256 | c2: 4M Plummer tree-only")
     args = ap.parse_args()
     if args.config == "c3":
         args.log2n, args.ngravs, args.wiring, args.pmgrid = (24 if args.log2n == 26 else args.log2n), 1, "newton", args.pmgrid or 256
+    if args.config == "c5":    # 256M, N_GRAVS=3, PMGRID=1024: the 8-GPU config of BASELINE.json; it also fits ONE 288 GB MI355X
+        args.log2n, args.ngravs, args.pmgrid = (28 if args.log2n == 26 else args.log2n), 3, args.pmgrid or 1024
     if args.config == "c2":
         args.log2n, args.ngravs, args.wiring = (22 if args.log2n == 26 else args.log2n), 1, "newton"
 

@@ -1161,10 +1161,12 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
         }
       if(lane == 0)
         {
-          atomicAdd(&err_flag[1], st_entries);   // d_counters[2..4]: list entries, nodes tested, batches
-          atomicAdd(&err_flag[2], st_nodes);
-          atomicAdd(&err_flag[3], st_batches);
-          atomicAdd(&err_flag[4], st_iters);
+          // 64-bit statistics behind the per-XCD counters (walk_counters[16..23]): entries, nodes, batches, force trips
+          unsigned long long *st64 = reinterpret_cast<unsigned long long *>(counter + 16);
+          atomicAdd(&st64[0], (unsigned long long)st_entries);
+          atomicAdd(&st64[1], (unsigned long long)st_nodes);
+          atomicAdd(&st64[2], (unsigned long long)st_batches);
+          atomicAdd(&st64[3], (unsigned long long)st_iters);
         }
       if(overflow)
         {
@@ -1507,15 +1509,16 @@ int walk_run(ngravs_ctx *c)
   HIP_TRY(c, hipGetLastError());
   if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
     {
-      unsigned int flags[5] = {0, 0, 0, 0, 0};
-      HIP_TRY(c, hipMemcpyAsync(flags, c->walk_counters.p + 1, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      int flag = 0;
+      unsigned long long st64[4] = {0, 0, 0, 0};
+      HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      int flag = (int)flags[0];
       double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
-      c->stats.reserved[0] = flags[1] / ngroups;   // interaction-list entries per group (mod 2^32 wrap at huge N: diagnostic)
-      c->stats.reserved[1] = flags[2] / ngroups;   // nodes tested per group
-      c->stats.reserved[2] = flags[3] / ngroups;   // traversal batches per group
-      c->stats.reserved[3] = flags[4] / ngroups;   // force-loop iterations per group (max sub-group list length, summed)
+      c->stats.reserved[0] = st64[0] / ngroups;   // pool entries per group
+      c->stats.reserved[1] = st64[1] / ngroups;   // nodes tested per group
+      c->stats.reserved[2] = st64[2] / ngroups;   // traversal batches per group
+      c->stats.reserved[3] = st64[3] / ngroups;   // force-loop trips per group (max sub-group list length, summed)
       if(flag)
         {
           ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");

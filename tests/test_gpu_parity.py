@@ -190,6 +190,32 @@ def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
     eng.close()
 
 
+def test_group_walk_three_species(pkg, O):
+    """N_GRAVS=3 (the C5 wiring: Newton diagonal, Newton+Yukawa off-diagonal; short-range tables read through L1/L2
+    instead of LDS): the group walk stays within the reference walk's own error band of the strict result"""
+    n, L, pmgrid, ng = 30000, 1e4, 32, 3
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=44)
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=43007.1, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=True)
+    acc_s, old, cost_s, pm = eng.get_accel(want_pm=True)
+    eng.set_opening(0.0, 0.005)
+    eng.set_old_acc(old)
+    eng.gravity_tree()
+    acc_s2, _, _ = eng.get_accel()
+    eng.set_walk_mode(pkg.WALK_GROUP)
+    eng.gravity_tree()
+    acc_g, _, cost_g = eng.get_accel()
+    d = np.linalg.norm(acc_g - acc_s2, axis=1) / np.linalg.norm(acc_s2 + pm, axis=1)
+    print("N_GRAVS=3 group vs strict: median %.2e p99 %.2e" % (np.median(d), np.quantile(d, 0.99)))
+    assert np.median(d) < 2e-2 and np.all(np.isfinite(acc_g)) and cost_g.min() >= 1
+    # momentum: symmetric wiring -> the short-range forces nearly cancel in the sum
+    assert np.abs(np.sum(mass[:, None] * acc_g, axis=0)).max() / np.sum(mass[:, None] * np.abs(acc_g)) < 2e-3
+    eng.close()
+
+
 def test_edge_cases_small_and_ragged(pkg, O):
     for n in (1, 2, 63, 64, 65, 130):
         rng = np.random.default_rng(n)
