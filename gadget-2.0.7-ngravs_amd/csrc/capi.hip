@@ -283,7 +283,6 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->n_child.release();
   c->n_flags.release();
   c->n_nchild.release();
-  c->n_level.release();
   c->n_geo.release();
   c->n_mom.release();
   c->scan_out.release();

@@ -128,7 +128,6 @@ struct ngravs_ctx
   int nlevels = 0;
   int64_t level_start[MAX_LEVELS + 2];
   DevBuf<int> n_first, n_count, n_child, n_flags, n_nchild;
-  DevBuf<unsigned char> n_level;
   DevBuf<double4> n_geo, n_mom;
   DevBuf<int> scan_out;
   DevBuf<unsigned char> scan_tmp;

@@ -17,11 +17,14 @@
 //  k_walk_group : the MI355X production walk.  The 64 lanes traverse cooperatively: a LIFO of
 //      pending nodes is popped 64 at a time, each lane tests ONE node against the group's
 //      bounding box with the conservative form of every reference test (a node is used only if
-//      every target would use it, dropped only if every target would drop it), ballot +
-//      popcount prefix compact accepted monopoles / particle leaves into per-species interaction
-//      lists in LDS, and all 64 lanes then stream those lists (LDS broadcast reads) through the
-//      force law.  The TreePM short-range table (NTAB fp64 per species pair) is staged in LDS once
-//      per workgroup; workgroups are persistent and pull groups from an atomic counter.
+//      every target would use it, dropped only if every target would drop it); accepted monopoles
+//      and particle leaves are queued as indices, fetched 64 at a time, culled against the bounding
+//      boxes of the 8 sub-groups (8 consecutive targets each) and stored once in an LDS pool, with a
+//      byte-index list per sub-group and species (ballot + mbcnt prefix compaction); every sub-group
+//      then streams ITS list through the force law (per-row LDS reads, four entries per trip as four
+//      independent straight-line streams).  The TreePM short-range tables (the distinct ones of the
+//      symmetric wiring) are staged in LDS once per persistent workgroup; workgroups pull groups
+//      from per-XCD atomic counters (XCD-aware Peano segments, stealing when exhausted).
 //
 // Force laws: the reference calls AccelFxns[tg][sg] through a pointer; here the wired table is
 // lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,

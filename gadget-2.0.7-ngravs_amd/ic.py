@@ -86,3 +86,39 @@ def read_gadget_format1(path):
             start += npart[t]
     return dict(pos=pos, vel=vel, ids=ids, mass=mass, type=ptype,
                 header=dict(npart=npart, mass=masstab, time=time, redshift=redshift, boxsize=boxsize))
+
+
+def write_gadget_format1(path, pos, vel, ids, ptype, masstab, mass=None, time=0.0, boxsize=0.0):
+    """Snapshot/IC format 1 (reference io.c:672-996, header allvars.h:685-708): header, POS, VEL,
+    ID and a MASS block for the types whose header mass is 0.  Particles are written grouped by type, fp32 on disk."""
+    pos, vel = np.asarray(pos, dtype=np.float64), np.asarray(vel, dtype=np.float64)
+    ids, ptype = np.asarray(ids, dtype=np.uint32), np.asarray(ptype, dtype=np.int32)
+    masstab = np.asarray(masstab, dtype=np.float64)
+    order = np.argsort(ptype, kind="stable")
+    npart = np.bincount(ptype, minlength=6).astype(np.int32)
+    hdr = bytearray(256)
+    struct.pack_into("<6i", hdr, 0, *npart)
+    struct.pack_into("<6d", hdr, 24, *masstab)
+    struct.pack_into("<dd", hdr, 72, time, 0.0)
+    struct.pack_into("<ii", hdr, 88, 0, 0)
+    struct.pack_into("<6I", hdr, 96, *npart)
+    struct.pack_into("<ii", hdr, 120, 0, 1)
+    struct.pack_into("<d", hdr, 128, boxsize)
+
+    def rec(f, payload):
+        f.write(struct.pack("<i", len(payload)))
+        f.write(payload)
+        f.write(struct.pack("<i", len(payload)))
+
+    with open(path, "wb") as f:
+        rec(f, bytes(hdr))
+        rec(f, pos[order].astype("<f4").tobytes())
+        rec(f, vel[order].astype("<f4").tobytes())
+        rec(f, ids[order].astype("<u4").tobytes())
+        need = [t for t in range(6) if masstab[t] == 0 and npart[t] > 0]
+        if need:
+            if mass is None:
+                raise ValueError("per-particle masses needed for types %s" % need)
+            m = np.asarray(mass, dtype=np.float64)[order]
+            t_sorted = ptype[order]
+            rec(f, np.concatenate([m[t_sorted == t] for t in need]).astype("<f4").tobytes())

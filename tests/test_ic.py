@@ -1,0 +1,41 @@
+"""format-1 reader/writer and the synthetic ICs of SURVEY.md 8(d)."""
+import os
+
+import numpy as np
+
+from conftest import galaxy_ic
+
+
+def test_galaxy_collision_header(pkg):
+    d = galaxy_ic(pkg)
+    assert list(d["header"]["npart"]) == [0, 10000, 20000, 10000, 10000, 10000]
+    assert abs(d["header"]["mass"][1] - 0.00104634) < 1e-8 and abs(d["header"]["mass"][2] - 0.00023252) < 1e-8
+    assert d["pos"].shape == (60000, 3) and len(np.unique(d["ids"])) == 60000
+
+
+def test_format1_roundtrip(pkg, tmp_path):
+    rng = np.random.default_rng(0)
+    n = 1000
+    ptype = rng.integers(1, 4, n).astype(np.int32)
+    pos = rng.uniform(0, 10, (n, 3)).astype(np.float32).astype(np.float64)
+    vel = rng.normal(0, 1, (n, 3)).astype(np.float32).astype(np.float64)
+    ids = np.arange(n, dtype=np.uint32)
+    mass = rng.uniform(1, 2, n).astype(np.float32).astype(np.float64)
+    masstab = [0, 0.5, 0, 0.25, 0, 0]              # type 2 carries per-particle masses
+    mass[ptype == 1] = 0.5
+    mass[ptype == 3] = 0.25
+    path = os.path.join(str(tmp_path), "snap.ic")
+    pkg.ic.write_gadget_format1(path, pos, vel, ids, ptype, masstab, mass=mass, boxsize=10.0)
+    d = pkg.ic.read_gadget_format1(path)
+    order = np.argsort(ptype, kind="stable")
+    assert np.array_equal(d["pos"], pos[order]) and np.array_equal(d["vel"], vel[order])
+    assert np.array_equal(d["ids"], ids[order]) and np.array_equal(d["type"], ptype[order])
+    assert np.allclose(d["mass"], mass[order]) and d["header"]["boxsize"] == 10.0
+
+
+def test_synthetic_ics(pkg):
+    pos, mass, typ = pkg.ic.uniform_box(10000, box=3.0, n_gravs=3, seed=1)
+    assert pos.min() >= 0 and pos.max() < 3.0 and abs(mass.sum() - 1) < 1e-12 and set(typ) == {1, 2, 3}
+    pos, mass, typ = pkg.ic.plummer_sphere(20000, seed=2)
+    r = np.linalg.norm(pos, axis=1)
+    assert r.max() < 100.0 and abs(np.median(r) - 1.305) < 0.05      # Plummer half-mass radius = 1.305 a
