@@ -541,6 +541,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
 #define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x NLEAF items
 #define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
+#define GW2_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * 128 * (NG))
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -1188,6 +1189,636 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 }
 
 // =============================================================================================
+//  group walk, second generation: traversal and force evaluation are separate phases per group.
+//
+//  Phase 1 is the same cooperative traversal as k_walk_group, but accepted monopoles / particle leaves are
+//  only recorded as item indices in a per-wave global scratch list.  Phase 2 visits that list in a
+//  golden-ratio stride order, so every chunk of 64 items is an even sample of the whole neighbourhood of the
+//  group instead of one corner of it; each lane tests the 64 chunk entries (LDS broadcast) against ITS OWN
+//  target and keeps a 64-bit hit mask per source species; the force loop then lets every lane walk its own
+//  bits (four per trip).  Per-lane lists remove the bounding-box waste of shared lists (a target needs ~375 of
+//  the ~1600 entries its group collects) and the stride order balances the lanes: the force loop runs ~400
+//  trips per group instead of ~1100 (sub-group lists) / ~1900 (one shared list).
+// =============================================================================================
+#define GW2_ITEMS 16384      // item scratch per wave (global); phase 2 runs early if it would overflow
+
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
+__global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
+    TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+    const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
+    const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
+    int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // LDS: [tables (if TAB_LDS)] [exp table 32] [per wave: chunk pool 64 x (double4 pos/mass, double h, uchar species)]
+  double *tab_s = reinterpret_cast<double *>(smem);
+  constexpr int NTABS = NG * (NG + 1) / 2;
+  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double *expT = reinterpret_cast<double *>(smem + tab_bytes);
+  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS(NG);
+  double4 *lpos = reinterpret_cast<double4 *>(wbase);
+  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE * NG);
+  if(threadIdx.x < 32)
+    expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
+  if(PM && TAB_LDS)
+    for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
+      {
+        int u = t / NTAB, a = 0;
+        while(u >= NG - a)
+          {
+            u -= NG - a;
+            a++;
+          }
+        tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
+      }
+  __syncthreads();
+  const double *tabp = (PM && TAB_LDS) ? tab_s : table;
+  int *stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (GW_STACK + GW2_ITEMS);
+  int *items = stack + GW_STACK;
+  const long long ngroups = (t_count + WAVE - 1) / WAVE;
+  const double BIG = 1e300;
+
+  // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
+  // workgroup pulls groups from the segment of the XCD it runs on (neighbouring groups share most of their
+  // tree nodes and sources); an exhausted segment steals from the others.  Placement only affects speed.
+  unsigned xcc = 0;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const long long seg = (ngroups + 7) / 8;
+  int steal = 0;
+  for(;;)
+    {
+      long long grp = -1;
+      while(steal < 8)
+        {
+          const int sx = (int)((xcc + steal) & 7u);
+          int k = 0;
+          if(lane == 0)
+            k = atomicAdd(&counter[8 + sx], 1);
+          k = __builtin_amdgcn_readfirstlane(k);
+          const long long g0 = seg * sx + k;
+          if(k < seg && g0 < ngroups)
+            {
+              grp = g0;
+              break;
+            }
+          steal++;
+        }
+      if(grp < 0)
+        break;
+      const long long ti = t_first + grp * WAVE + lane;
+      const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
+      if(!__any(valid ? 1 : 0))
+        continue;
+      double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
+      int tg = 0;
+      if(valid)
+        {
+          double4 p = s_pm[ti];
+          px = p.x;
+          py = p.y;
+          pz = p.z;
+          int ptype = s_type[ti];
+          tg = wp.t2g[ptype];
+          hT = wp.fsoft[ptype];
+          aold = wp.errtol_acc * s_oldacc[ti];
+        }
+      // per-lane law coefficients against each source species
+      double cN[NG], cY[NG], cS[NG];
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        {
+          cN[g] = wp.cN[tg][g];
+          cY[g] = wp.cY[tg][g];
+          cS[g] = wp.cS[tg][g];
+        }
+      // this lane's table rows, one per source species
+      const double *tabrow[NG];
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        {
+          if(PM && TAB_LDS)
+            {
+              const int a = tg < g ? tg : g, b = tg < g ? g : tg;
+              tabrow[g] = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
+            }
+          else
+            tabrow[g] = tabp + ((size_t)tg * NG + g) * NTAB;
+        }
+      // group bounding box and the conservative scalars
+      double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
+      double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
+      double loz = wave_min(valid ? pz : BIG), hiz = wave_max(valid ? pz : -BIG);
+      const double bcx = 0.5 * (lox + hix), bcy = 0.5 * (loy + hiy), bcz = 0.5 * (loz + hiz);
+      const double bhx = 0.5 * (hix - lox), bhy = 0.5 * (hiy - loy), bhz = 0.5 * (hiz - loz);
+      const double aold_min = wave_min(valid ? aold : BIG);
+      const double hT_min = wave_min(valid ? hT : BIG);
+      // may sources be wrapped once per group (relative to the box centre) instead of per pair?
+      const double bhmax = fmax(bhx, fmax(bhy, bhz));
+      const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
+                           (wp.boxhalf - bhmax) > 0;
+      const bool lanewrap = wp.periodic && !prewrap;
+
+      double ax = 0, ay = 0, az = 0;
+      int nint = 0;
+      int st_entries = 0, st_nodes = 0, st_batches = 0;   // walk statistics (per group, wave-uniform)
+
+      // FOUR list entries against this lane's target, written as four independent straight-line streams
+      // (no branch on the common path) so that the scheduler overlaps their v_rsq / LDS-table latencies:
+      // only 2 waves per SIMD fit beside the LDS tables, the ILP has to come from here.
+      auto eval4 = [&](auto lw_tag, const int g, const double4 (&e)[4], const double (&hs)[4], const bool (&act)[4]) {
+        constexpr bool LW = decltype(lw_tag)::value;
+        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4];
+        bool in[4];
+        bool anyin = false;
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+          {
+            dx[k] = e[k].x - px;
+            dy[k] = e[k].y - py;
+            dz[k] = e[k].z - pz;
+            if(LW)
+              {
+                dx[k] = nearest(dx[k], wp.box, wp.boxhalf);
+                dy[k] = nearest(dy[k], wp.box, wp.boxhalf);
+                dz[k] = nearest(dz[k], wp.box, wp.boxhalf);
+              }
+            r2[k] = dx[k] * dx[k] + dy[k] * dy[k] + dz[k] * dz[k];
+            in[k] = act[k] && (PM ? (r2[k] < wp.reach2) : true);
+            anyin |= in[k];
+          }
+        if(!__any(anyin ? 1 : 0))
+          return;                                                       // none of the four reaches any target
+        bool anysoft = false;
+        bool soft[4];
+        double h[4];
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+          {
+            // self / coincident pairs stay finite (d = 0 kills them); masked lanes are clamped at the table index
+            const double q2 = r2[k] + 1e-290;
+            double ri = __builtin_amdgcn_rsq(q2);
+            ri = ri * (1.5 - 0.5 * q2 * ri * ri);                         // one Newton step: ~2^-51
+            const double rr = q2 * ri;                                    // sqrt(r2) to ~2^-51
+            rinv[k] = ri;
+            r[k] = rr;
+            const double ri2 = ri * ri;
+            double f = cN[g] * ri2;
+            if(YUK)
+              f += cY[g] * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
+            if(PM)
+              {
+                int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
+                tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
+                f -= wp.utor2wpi * tabrow[g][tab];
+              }
+            fac[k] = f * e[k].w * ri;
+            h[k] = hT > hs[k] ? hT : hs[k];
+            soft[k] = in[k] && rr < h[k];
+            anysoft |= soft[k];
+          }
+        if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
+          {
+#pragma unroll
+            for(int k = 0; k < 4; k++)
+              {
+                double h_inv = 1 / h[k], u = r[k] * h_inv;
+                double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
+                                     : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
+                                        0.066666666667 / (u * u * u));
+                double fs = cS[g] * e[k].w * h_inv * h_inv * h_inv * v;
+                fac[k] = soft[k] ? fs : fac[k];
+              }
+          }
+#pragma unroll
+        for(int k = 0; k < 4; k++)
+          {
+            const double f = in[k] ? fac[k] : 0.0;
+            ax = __builtin_fma(dx[k], f, ax);
+            ay = __builtin_fma(dy[k], f, ay);
+            az = __builtin_fma(dz[k], f, az);
+            nint += in[k] ? 1 : 0;
+            if(LATT)
+              {
+                // periodic tree-only: every source also contributes its infinite lattice of images (forcetree.c:1605-1607);
+                // here on the SAME (finer) interaction list as the nearest-image force
+                double fx, fy, fz;
+                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, dx[k], dy[k], dz[k], fx, fy, fz);
+                const double mk = in[k] ? e[k].w : 0.0;
+                ax = __builtin_fma(mk, fx, ax);
+                ay = __builtin_fma(mk, fy, ay);
+                az = __builtin_fma(mk, fz, az);
+              }
+          }
+      };
+
+      int st_iters = 0;
+      int n_items = 0, sp = 1;
+      if(lane == 0)
+        stack[0] = 0;
+      wave_sync();
+      bool overflow = false;
+
+      // ---- phase 2: evaluate the recorded items ------------------------------------------------------------
+      auto phase2 = [&]() {
+        wave_sync();
+        const int n = n_items;
+        st_entries += n;
+        if(n == 0)
+          return;
+        // golden-ratio stride, coprime with n: item (i * s) mod n is visited i-th
+        int s_ = (int)(0.6180339887498949 * n) | 1;
+        if(s_ >= n)
+          s_ = 1;
+        for(;;)
+          {
+            int a = s_, b = n;
+            while(b)
+              {
+                int t = a % b;
+                a = b;
+                b = t;
+              }
+            if(a == 1)
+              break;
+            s_ += 2;
+            if(s_ >= n)
+              {
+                s_ = 1;
+                break;
+              }
+          }
+        const int step64 = (int)((64ll * s_) % n);
+        int slot = (int)(((long long)lane * s_) % n);
+        int npool[NG];
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          npool[g] = 0;
+        // one extra pass (c0 >= n) only drains what is left in the pools, so that the force loop exists once.
+        // Two-deep software pipeline on the memory side: while chunk c is evaluated, the source records of chunk c+1 and
+        // the item indices of chunk c+2 are already in flight.
+        auto fetch_item = [&](int c0) -> int {
+          const bool hv = c0 + lane < n;
+          const int it = hv ? items[slot] : 0;
+          slot += step64;
+          slot = slot >= n ? slot - n : slot;
+          return it;
+        };
+        auto fetch_rec = [&](int c0, int item, double4 &q, int &sg, double &hs) {
+          q.x = q.y = q.z = q.w = 0;
+          sg = 0;
+          hs = 0;
+          if(c0 + lane < n)
+            {
+              if(item >= 0)
+                {
+                  q = s_pm[item];
+                  int qt = s_type[item];
+                  sg = wp.t2g[qt];
+                  hs = wp.fsoft[qt];
+                }
+              else
+                {
+                  int k = -1 - item;
+                  q = tv.mom[k];
+                  int nd = k / NG;
+                  sg = k - nd * NG;
+                  hs = wp.fsoft[(tv.flags[nd] >> 2) & 7];
+                }
+            }
+        };
+        int item1 = fetch_item(0);
+        double4 q1;
+        int sg1;
+        double hs1;
+        fetch_rec(0, item1, q1, sg1, hs1);
+        int item2 = fetch_item(WAVE);
+        for(int c0 = 0; c0 < n + WAVE; c0 += WAVE)
+          {
+            const bool last = c0 >= n;
+            const bool have = c0 + lane < n;
+            double4 q = q1;
+            const int sg = sg1;
+            const double hs = hs1;
+            fetch_rec(c0 + WAVE, item2, q1, sg1, hs1);   // chunk c+1
+            item2 = fetch_item(c0 + 2 * WAVE);            // chunk c+2
+            bool live = have && q.w != 0.0;
+            double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
+            if(wp.periodic)
+              {
+                ex = nearest(ex, wp.box, wp.boxhalf);
+                ey = nearest(ey, wp.box, wp.boxhalf);
+                ez = nearest(ez, wp.box, wp.boxhalf);
+              }
+            if(PM)
+              {
+                // a source farther than the cut from the whole bounding box contributes to no target
+                double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
+                live = live && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+              }
+            if(prewrap)
+              {
+                q.x = bcx + ex;
+                q.y = bcy + ey;
+                q.z = bcz + ez;
+              }
+#pragma unroll
+            for(int g = 0; g < NG; g++)
+              {
+                // compact the live entries of species g behind the ones already waiting in its pool (capacity 2 x 64)
+                double4 *pp = lpos + g * 2 * WAVE;
+                double *ph = lh + g * 2 * WAVE;
+                const bool lg = live && sg == g;
+                const unsigned long long lm = __ballot(lg ? 1 : 0);
+                if(lg)
+                  {
+                    const int o = npool[g] + lane_prefix(lm);
+                    pp[o] = q;
+                    ph[o] = hs;
+                  }
+                npool[g] += __popcll(lm);
+                wave_sync();
+                if(npool[g] >= WAVE || (last && npool[g] > 0))
+                  {
+                    const int nc = npool[g] < WAVE ? npool[g] : WAVE;
+                    // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
+                    //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
+                    unsigned int mlo = 0, mhi = 0;
+                    if(!(wp.dbg & 1))
+                      {
+#pragma unroll
+                        for(int w = 0; w < 2; w++)
+                          {
+                            unsigned int word = 0;
+#pragma unroll
+                            for(int b = 0; b < 32; b++)
+                              {
+                                const int j = 32 * w + b;
+                                if(j < nc)
+                                  {
+                                    const double4 e = pp[j];
+                                    double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
+                                    if(lanewrap)
+                                      {
+                                        dx = nearest(dx, wp.box, wp.boxhalf);
+                                        dy = nearest(dy, wp.box, wp.boxhalf);
+                                        dz = nearest(dz, wp.box, wp.boxhalf);
+                                      }
+                                    const double r2 = dx * dx + dy * dy + dz * dz;
+                                    const bool hit = valid && (PM ? (r2 < wp.reach2) : true);
+                                    word |= hit ? (1u << b) : 0u;
+                                  }
+                              }
+                            if(w == 0)
+                              mlo = word;
+                            else
+                              mhi = word;
+                          }
+                      }
+                    // ---- force loop: every lane walks its own bits, four per trip
+                    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                    if(wp.dbg & 4)   // debug: masks are built but not evaluated
+                      {
+                        nint += __popcll(m);
+                        m = 0;
+                      }
+                    while(__any(m != 0 ? 1 : 0))
+                      {
+                        st_iters += 4;
+                        bool act[4];
+                        int jj[4];
+#pragma unroll
+                        for(int k = 0; k < 4; k++)
+                          {
+                            act[k] = m != 0;
+                            jj[k] = act[k] ? __builtin_ctzll(m) : 0;
+                            m &= m - 1;
+                          }
+                        const double4 e[4] = {pp[jj[0]], pp[jj[1]], pp[jj[2]], pp[jj[3]]};
+                        const double hh[4] = {ph[jj[0]], ph[jj[1]], ph[jj[2]], ph[jj[3]]};
+                        if(lanewrap)
+                          eval4(std::true_type{}, g, e, hh, act);
+                        else
+                          eval4(std::false_type{}, g, e, hh, act);
+                      }
+                    wave_sync();
+                    // move the remainder to the front
+                    const int rem = npool[g] - nc;
+                    double4 tq;
+                    double th = 0;
+                    tq.x = tq.y = tq.z = tq.w = 0;
+                    if(lane < rem)
+                      {
+                        tq = pp[WAVE + lane];
+                        th = ph[WAVE + lane];
+                      }
+                    wave_sync();
+                    if(lane < rem)
+                      {
+                        pp[lane] = tq;
+                        ph[lane] = th;
+                      }
+                    npool[g] = rem;
+                    wave_sync();
+                  }
+              }
+          }
+        wave_sync();
+        n_items = 0;
+      };
+
+      // ---- phase 1: cooperative traversal; items are only recorded ---------------------------------------------
+      while(sp > 0)
+        {
+          if(n_items + WAVE * (8 + NG) > GW2_ITEMS)   // the scratch list would overflow: evaluate what is there (rare)
+            phase2();
+          // ---------------- test up to 64 pending nodes against the group's bounding box ----------------
+          const int nb = sp < WAVE ? sp : WAVE;
+          sp -= nb;
+          st_nodes += nb;
+          st_batches++;
+          const int my = lane < nb ? stack[sp + lane] : -1;
+          wave_sync();
+          // decision: 0 drop, 1 accept (monopoles), 2 open (children), 3 open as a leaf (all particles of the range)
+          int dec = 0;
+          int first = 0, count = 0;
+          unsigned massmask = 0;
+          int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
+          if(my >= 0)
+            {
+              const double4 geo = tv.geo[my];
+              const int fl = tv.flags[my];
+              // fetched with the record, not after the decision: one dependent memory round trip less per batch
+              first = tv.first[my];
+              count = tv.count[my];
+              {
+                const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
+                ch_lo = cp[0];
+                ch_hi = cp[1];
+              }
+              const double len = geo.w;
+              double r2min = BIG, summass = 0;
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  const double4 mom = tv.mom[(long long)my * NG + g];
+                  summass += mom.w;
+                  massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
+                  double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
+                  if(wp.periodic)
+                    {
+                      dx = nearest(dx, wp.box, wp.boxhalf);
+                      dy = nearest(dy, wp.box, wp.boxhalf);
+                      dz = nearest(dz, wp.box, wp.boxhalf);
+                    }
+                  double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
+                  double r2g = a0 * a0 + a1 * a1 + a2 * a2;
+                  r2min = r2g < r2min ? r2g : r2min;
+                }
+              double cx = geo.x - bcx, cy = geo.y - bcy, cz = geo.z - bcz;   // plain (inside-cell test has no NEAREST)
+              double wx = cx, wy = cy, wz = cz;
+              if(wp.periodic)
+                {
+                  wx = nearest(cx, wp.box, wp.boxhalf);
+                  wy = nearest(cy, wp.box, wp.boxhalf);
+                  wz = nearest(cz, wp.box, wp.boxhalf);
+                }
+              const int mst = (fl >> 2) & 7;
+              bool drop = (mst == 7);   // empty
+              if(PM && !drop)
+                {
+                  // (i) nothing inside the cell can be within the cut of any target
+                  double half = 0.5 * len;
+                  double q0 = fmax(0.0, fabs(wx) - bhx - half), q1 = fmax(0.0, fabs(wy) - bhy - half),
+                         q2 = fmax(0.0, fabs(wz) - bhz - half);
+                  if(q0 * q0 + q1 * q1 + q2 * q2 >= wp.reach2)
+                    drop = true;
+                  // (ii) the reference's own cut (forcetree.c:1828-1862) holds for every target
+                  if(!drop && r2min > wp.rcut2)
+                    {
+                      double eff = wp.rcut + half;
+                      if(fabs(wx) - bhx > eff || fabs(wy) - bhy > eff || fabs(wz) - bhz > eff)
+                        drop = true;
+                    }
+                }
+              if(!drop)
+                {
+                  bool open;
+                  if(wp.use_theta)
+                    open = len * len > r2min * wp.theta2;
+                  else
+                    {
+                      open = summass * len * len > r2min * r2min * aold_min;
+                      if(!open)
+                        open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
+                               (fabs(cz) - bhz < 0.60 * len);
+                    }
+                  const double hs_node = wp.fsoft[mst];
+                  if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
+                    open = true;
+                  if(open)
+                    dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
+                  else
+                    dec = 1;
+                }
+            }
+          // record the items of this batch (appended in traversal order; phase 2 reads them in stride order)
+#pragma unroll
+          for(int g = 0; g < NG; g++)
+            {
+              const bool pg = dec == 1 && ((massmask >> g) & 1u);
+              unsigned long long mask = __ballot(pg ? 1 : 0);
+              if(pg)
+                items[n_items + lane_prefix(mask)] = -1 - (my * NG + g);
+              n_items += __popcll(mask);
+            }
+          if(__any(dec == 2))
+            {
+              const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
+#pragma unroll
+              for(int slot = 0; slot < 8; slot++)
+                {
+                  const int ch = (dec == 2) ? chv[slot] : -1;
+                  const bool isnode = ch >= 0;
+                  unsigned long long mask = __ballot(isnode ? 1 : 0);
+                  if(mask)
+                    {
+                      int npush = __popcll(mask);
+                      if(sp + npush > GW_STACK)
+                        overflow = true;
+                      else
+                        {
+                          if(isnode)
+                            stack[sp + lane_prefix(mask)] = ch;
+                          sp += npush;
+                        }
+                    }
+                  const bool ispart = ch <= -2;
+                  unsigned long long pmask = __ballot(ispart ? 1 : 0);
+                  if(ispart)
+                    items[n_items + lane_prefix(pmask)] = -2 - ch;
+                  n_items += __popcll(pmask);
+                }
+            }
+          if(__any(dec == 3))
+            {
+              // small or coincident-key nodes: all particles of the contiguous range, 64 lanes x k-th particle
+              int kmax = 0;
+              {
+                int cmine = (dec == 3) ? count : 0;
+                for(int off = 32; off > 0; off >>= 1)
+                  {
+                    int o = __shfl_xor(cmine, off);
+                    cmine = o > cmine ? o : cmine;
+                  }
+                kmax = cmine;
+              }
+              for(int k = 0; k < kmax; k++)
+                {
+                  if(n_items + WAVE > GW2_ITEMS)
+                    {
+                      overflow = true;   // a bucket larger than the scratch list: not a sane input
+                      break;
+                    }
+                  const bool more = (dec == 3) && k < count;
+                  unsigned long long pmask = __ballot(more ? 1 : 0);
+                  if(more)
+                    items[n_items + lane_prefix(pmask)] = first + k;
+                  n_items += __popcll(pmask);
+                }
+            }
+          if(overflow)
+            break;
+          wave_sync();
+        }
+      if(!overflow)
+        phase2();
+      if(lane == 0)
+        {
+          unsigned long long *st64 = reinterpret_cast<unsigned long long *>(counter + 16);
+          atomicAdd(&st64[0], (unsigned long long)st_entries);
+          atomicAdd(&st64[1], (unsigned long long)st_nodes);
+          atomicAdd(&st64[2], (unsigned long long)st_batches);
+          atomicAdd(&st64[3], (unsigned long long)st_iters);
+        }
+      if(overflow)
+        {
+          if(lane == 0)
+            atomicExch(err_flag, 1);
+          continue;
+        }
+      if(valid)
+        {
+          r_acc[3 * ti + 0] = ax;
+          r_acc[3 * ti + 1] = ay;
+          r_acc[3 * ti + 2] = az;
+          r_nint[ti] = nint;
+        }
+    }
+}
+
+// =============================================================================================
 //  post-processing (gravtree.c:318-341): OldAcc = |GravAccel + GravPM/G|, GravAccel *= G
 // =============================================================================================
 __global__ void k_finish(long long t_first, long long t_count, const unsigned char *__restrict__ s_active,
@@ -1444,15 +2075,57 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   return NGRAVS_OK;
 }
 
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp)
+{
+  int ncu = 256;
+  hipDeviceProp_t prop;
+  if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+    ncu = prop.multiProcessorCount;
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
+  // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
+  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS(NG));
+  int per_cu = 1;
+  if(waves > GW_MAXWAVES)
+    waves = GW_MAXWAVES;   // register-limited: 3 waves per SIMD (__launch_bounds__), one workgroup per CU
+  if(waves < 1)
+    waves = 1;
+  size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS(NG);
+  long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  long long nblk = (long long)ncu * per_cu;
+  if(nblk > (ngroups + waves - 1) / waves)
+    nblk = (ngroups + waves - 1) / waves;
+  if(nblk < 1)
+    nblk = 1;
+  if(c->walk_stack.ensure((size_t)nblk * waves * (GW_STACK + GW2_ITEMS)) || c->walk_counters.ensure(32))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
+  auto kern = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT>;
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
+                     c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
+                     (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
+                     c->r_nint.p);
+  return NGRAVS_OK;
+}
+
 template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp)
 {
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
-  constexpr bool TL = (NG <= 2);   // NG=3: 144 KB of tables do not fit beside the lists -> read through L1/L2
+  constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables do not fit beside the lists -> read through L1/L2
+  const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
+  if(v1)
+    {
+      if(pm)
+        return yuk ? launch_group_t<NG, true, true, TL, false>(c, wp) : launch_group_t<NG, true, false, TL, false>(c, wp);
+      if(c->cfg.periodic)
+        return yuk ? launch_group_t<NG, false, true, false, true>(c, wp) : launch_group_t<NG, false, false, false, true>(c, wp);
+      return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
+    }
   if(pm)
-    return yuk ? launch_group_t<NG, true, true, TL, false>(c, wp) : launch_group_t<NG, true, false, TL, false>(c, wp);
+    return yuk ? launch_group2_t<NG, true, true, TL, false>(c, wp) : launch_group2_t<NG, true, false, TL, false>(c, wp);
   if(c->cfg.periodic)
-    return yuk ? launch_group_t<NG, false, true, false, true>(c, wp) : launch_group_t<NG, false, false, false, true>(c, wp);
-  return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
+    return yuk ? launch_group2_t<NG, false, true, false, true>(c, wp) : launch_group2_t<NG, false, false, false, true>(c, wp);
+  return yuk ? launch_group2_t<NG, false, true, false, false>(c, wp) : launch_group2_t<NG, false, false, false, false>(c, wp);
 }
 
 int walk_run(ngravs_ctx *c)
