@@ -1202,12 +1202,20 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 // =============================================================================================
 #define GW2_ITEMS 16384      // item scratch per wave (global); phase 2 runs early if it would overflow
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
-__global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
+// MODE 0: fused (traversal + evaluation per group, per-wave scratch).  MODE 1: traversal only -- one wave per group of the
+// batch [g_first, g_first+g_cnt), no LDS, few registers, so that many waves hide the dependent node fetches; the item list
+// of group k goes to region_base + k*GW3_REGION (items grow up, the pending-node LIFO grows down from the top) and its
+// length to gcount[k].  MODE 2: evaluation only -- persistent workgroups with the tables in LDS run phase 2 over those lists.
+#define GW3_REGION 8192      // ints per group in the split walk (items + LIFO)
+#define GW3_TBLOCK 256       // traversal kernel: 4 groups per workgroup
+
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT, int MODE>
+__global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_walk_group2(
     TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
     const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
-    int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint)
+    int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint,
+    int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [tables (if TAB_LDS)] [exp table 32] [per wave: chunk pool 64 x (double4 pos/mass, double h, uchar species)]
@@ -1219,24 +1227,33 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
   unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS(NG);
   double4 *lpos = reinterpret_cast<double4 *>(wbase);
   double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE * NG);
-  if(threadIdx.x < 32)
-    expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
-  if(PM && TAB_LDS)
-    for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
-      {
-        int u = t / NTAB, a = 0;
-        while(u >= NG - a)
+  if(MODE != 1)
+    {
+      if(threadIdx.x < 32)
+        expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
+      if(PM && TAB_LDS)
+        for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
           {
-            u -= NG - a;
-            a++;
+            int u = t / NTAB, a = 0;
+            while(u >= NG - a)
+              {
+                u -= NG - a;
+                a++;
+              }
+            tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
           }
-        tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
-      }
-  __syncthreads();
+      __syncthreads();
+    }
   const double *tabp = (PM && TAB_LDS) ? tab_s : table;
-  int *stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (GW_STACK + GW2_ITEMS);
-  int *items = stack + GW_STACK;
-  const long long ngroups = (t_count + WAVE - 1) / WAVE;
+  int *stack = nullptr, *items = nullptr;
+  if(MODE == 0)
+    {
+      stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (GW_STACK + GW2_ITEMS);
+      items = stack + GW_STACK;
+    }
+  // MODE 0 walks all groups of the shard; the split kernels one batch of them
+  const long long ngroups = MODE == 0 ? (t_count + WAVE - 1) / WAVE : g_cnt;
+  const long long gbase = MODE == 0 ? 0 : g_first;
   const double BIG = 1e300;
 
   // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
@@ -1247,10 +1264,26 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
   xcc &= 7u;
   const long long seg = (ngroups + 7) / 8;
   int steal = 0;
+  bool t_done = false;
+  // walk statistics: summed per wave over its groups and flushed ONCE (device-scope atomics on four shared addresses,
+  // one set per group, serialise in the memory controller and cost more than the traversal itself)
+  unsigned long long acc_st[4] = {0, 0, 0, 0};
   for(;;)
     {
       long long grp = -1;
-      while(steal < 8)
+      if(MODE == 1)
+        {
+          // plain grid: workgroup b runs on XCD b%8 (round-robin dispatch), so give it groups of the b%8-th segment
+          if(t_done)
+            break;
+          t_done = true;
+          const long long nblk8 = gridDim.x / 8;
+          const long long gl = ((long long)(blockIdx.x & 7) * nblk8 + (blockIdx.x >> 3)) * (GW3_TBLOCK / 64) + wave;
+          if(gl >= ngroups)
+            break;
+          grp = gl;
+        }
+      while(MODE != 1 && steal < 8)
         {
           const int sx = (int)((xcc + steal) & 7u);
           int k = 0;
@@ -1267,10 +1300,20 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
         }
       if(grp < 0)
         break;
+      if(MODE != 0)
+        {
+          items = region_base + (size_t)grp * GW3_REGION;
+          stack = items;   // MODE 1 indexes it from the top (STK)
+        }
+      grp += gbase;
       const long long ti = t_first + grp * WAVE + lane;
       const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
       if(!__any(valid ? 1 : 0))
-        continue;
+        {
+          if(MODE == 1 && lane == 0)
+            gcount[grp - gbase] = 0;
+          continue;
+        }
       double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
       int tg = 0;
       if(valid)
@@ -1415,10 +1458,19 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
 
       int st_iters = 0;
       int n_items = 0, sp = 1;
-      if(lane == 0)
-        stack[0] = 0;
+      // pending-node LIFO slot i: per-wave scratch (fused) or the top of the group's region, growing down (split)
+      auto STK = [&](int i) -> int & { return MODE == 1 ? stack[GW3_REGION - 1 - i] : stack[i]; };
+      if(MODE == 2)
+        {
+          n_items = gcount[grp - gbase];
+          sp = 0;
+        }
+      else if(lane == 0)
+        STK(0) = 0;
       wave_sync();
       bool overflow = false;
+      if(MODE == 2 && n_items < 0)   // the traversal kernel overflowed this group's region (error flag already set)
+        continue;
 
       // ---- phase 2: evaluate the recorded items ------------------------------------------------------------
       auto phase2 = [&]() {
@@ -1631,14 +1683,22 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
       // ---- phase 1: cooperative traversal; items are only recorded ---------------------------------------------
       while(sp > 0)
         {
-          if(n_items + WAVE * (8 + NG) > GW2_ITEMS)   // the scratch list would overflow: evaluate what is there (rare)
+          if constexpr(MODE == 1)
+            {
+              if(n_items + WAVE * (8 + NG) + sp + 8 * WAVE > GW3_REGION)   // items and LIFO would meet: the host falls back
+                {
+                  overflow = true;
+                  break;
+                }
+            }
+          else if(n_items + WAVE * (8 + NG) > GW2_ITEMS)   // the scratch list would overflow: evaluate what is there (rare)
             phase2();
           // ---------------- test up to 64 pending nodes against the group's bounding box ----------------
           const int nb = sp < WAVE ? sp : WAVE;
           sp -= nb;
           st_nodes += nb;
           st_batches++;
-          const int my = lane < nb ? stack[sp + lane] : -1;
+          const int my = lane < nb ? STK(sp + lane) : -1;
           wave_sync();
           // decision: 0 drop, 1 accept (monopoles), 2 open (children), 3 open as a leaf (all particles of the range)
           int dec = 0;
@@ -1745,12 +1805,12 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
                   if(mask)
                     {
                       int npush = __popcll(mask);
-                      if(sp + npush > GW_STACK)
+                      if(MODE == 1 ? (sp + npush + n_items + 8 * WAVE > GW3_REGION) : (sp + npush > GW_STACK))
                         overflow = true;
                       else
                         {
                           if(isnode)
-                            stack[sp + lane_prefix(mask)] = ch;
+                            STK(sp + lane_prefix(mask)) = ch;
                           sp += npush;
                         }
                     }
@@ -1776,7 +1836,7 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
               }
               for(int k = 0; k < kmax; k++)
                 {
-                  if(n_items + WAVE > GW2_ITEMS)
+                  if(MODE == 1 ? (n_items + WAVE + sp > GW3_REGION) : (n_items + WAVE > GW2_ITEMS))
                     {
                       overflow = true;   // a bucket larger than the scratch list: not a sane input
                       break;
@@ -1792,15 +1852,32 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
             break;
           wave_sync();
         }
-      if(!overflow)
-        phase2();
-      if(lane == 0)
+      if constexpr(MODE == 1)
         {
-          unsigned long long *st64 = reinterpret_cast<unsigned long long *>(counter + 16);
-          atomicAdd(&st64[0], (unsigned long long)st_entries);
-          atomicAdd(&st64[1], (unsigned long long)st_nodes);
-          atomicAdd(&st64[2], (unsigned long long)st_batches);
-          atomicAdd(&st64[3], (unsigned long long)st_iters);
+          if(lane == 0)
+            gcount[grp - gbase] = overflow ? -1 : n_items;
+        }
+      else if(!overflow)
+        phase2();
+      if(MODE == 1)
+        {
+          if(lane == 0)
+            {
+              gcount[g_cnt + (grp - gbase)] = st_nodes;
+              gcount[2 * g_cnt + (grp - gbase)] = st_batches;
+            }
+        }
+      else
+        {
+          if(MODE == 2)
+            {
+              st_nodes = gcount[g_cnt + (grp - gbase)];
+              st_batches = gcount[2 * g_cnt + (grp - gbase)];
+            }
+          acc_st[0] += (unsigned long long)st_entries;
+          acc_st[1] += (unsigned long long)st_nodes;
+          acc_st[2] += (unsigned long long)st_batches;
+          acc_st[3] += (unsigned long long)st_iters;
         }
       if(overflow)
         {
@@ -1808,13 +1885,21 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group2(
             atomicExch(err_flag, 1);
           continue;
         }
-      if(valid)
+      if(MODE != 1 && valid)
         {
           r_acc[3 * ti + 0] = ax;
           r_acc[3 * ti + 1] = ay;
           r_acc[3 * ti + 2] = az;
           r_nint[ti] = nint;
         }
+    }
+  if(MODE != 1 && lane == 0)
+    {
+      unsigned long long *st64 = reinterpret_cast<unsigned long long *>(counter + 16);
+#pragma unroll
+      for(int q = 0; q < 4; q++)
+        if(acc_st[q])
+          atomicAdd(&st64[q], acc_st[q]);
     }
 }
 
@@ -2099,17 +2184,69 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   if(c->walk_stack.ensure((size_t)nblk * waves * (GW_STACK + GW2_ITEMS)) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
-  auto kern = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT>;
+  auto kern = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 0>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                      (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
-                     c->r_nint.p);
+                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, 0ll);
   return NGRAVS_OK;
 }
 
-template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp)
+// split walk: per batch of groups a high-occupancy traversal kernel (MODE 1) writes the item lists, then the persistent
+// evaluation kernel (MODE 2) consumes them.  Same results as the fused kernel (same lists, same order).
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_group3_t(ngravs_ctx *c, const WalkParams &wp)
 {
+  int ncu = 256;
+  hipDeviceProp_t prop;
+  if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+    ncu = prop.multiProcessorCount;
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
+  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS(NG));
+  if(waves > GW_MAXWAVES)
+    waves = GW_MAXWAVES;
+  if(waves < 1)
+    waves = 1;
+  const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS(NG);
+  const long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  long long batch = 131072;
+  if(getenv("NGRAVS_WALK_BATCH") && atoll(getenv("NGRAVS_WALK_BATCH")) > 0)
+    batch = atoll(getenv("NGRAVS_WALK_BATCH"));
+  if(batch > ngroups)
+    batch = ngroups;
+  if(batch < 1)
+    batch = 1;
+  if(c->walk_stack.ensure((size_t)batch * (GW3_REGION + 3)) || c->walk_counters.ensure(32))
+    return NGRAVS_ERR_NOMEM;
+  int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * GW3_REGION;
+  HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
+  auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
+  auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
+  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for(long long g0 = 0; g0 < ngroups; g0 += batch)
+    {
+      const long long nb = ngroups - g0 < batch ? ngroups - g0 : batch;
+      const long long tblk = 8 * (((nb + GW3_TBLOCK / 64 - 1) / (GW3_TBLOCK / 64) + 7) / 8);
+      hipLaunchKernelGGL(kt, dim3((unsigned)tblk), dim3(GW3_TBLOCK), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
+                         c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
+                         (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
+                         c->r_nint.p, region, gcount, g0, nb);
+      if(g0 > 0)
+        HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
+      long long nblk = ncu;
+      if(nblk > (nb + waves - 1) / waves)
+        nblk = (nb + waves - 1) / waves;
+      hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
+                         c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
+                         (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
+                         c->r_nint.p, region, gcount, g0, nb);
+    }
+  return NGRAVS_OK;
+}
+
+template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, bool *used_split)
+{
+  *used_split = false;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables do not fit beside the lists -> read through L1/L2
   const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
@@ -2120,6 +2257,16 @@ template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp)
       if(c->cfg.periodic)
         return yuk ? launch_group_t<NG, false, true, false, true>(c, wp) : launch_group_t<NG, false, false, false, true>(c, wp);
       return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
+    }
+  const bool v2 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 2;   // fused second-generation kernel
+  if(allow_split && !v2)
+    {
+      *used_split = true;
+      if(pm)
+        return yuk ? launch_group3_t<NG, true, true, TL, false>(c, wp) : launch_group3_t<NG, true, false, TL, false>(c, wp);
+      if(c->cfg.periodic)
+        return yuk ? launch_group3_t<NG, false, true, false, true>(c, wp) : launch_group3_t<NG, false, false, false, true>(c, wp);
+      return yuk ? launch_group3_t<NG, false, true, false, false>(c, wp) : launch_group3_t<NG, false, false, false, false>(c, wp);
     }
   if(pm)
     return yuk ? launch_group2_t<NG, true, true, TL, false>(c, wp) : launch_group2_t<NG, true, false, TL, false>(c, wp);
@@ -2149,6 +2296,18 @@ int walk_run(ngravs_ctx *c)
   const bool pm = c->cfg.pmgrid != 0;
   HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
   int rc = NGRAVS_OK;
+  bool used_split = false;
+  auto group_launch = [&](bool allow_split) -> int {
+    switch(c->cfg.n_gravs)
+      {
+      case 1:
+        return launch_group<1>(c, wp, allow_split, &used_split);
+      case 2:
+        return launch_group<2>(c, wp, allow_split, &used_split);
+      default:
+        return launch_group<3>(c, wp, allow_split, &used_split);
+      }
+  };
   if(c->cfg.walk_mode == NGRAVS_WALK_STRICT)
     {
       switch(c->cfg.n_gravs)
@@ -2165,20 +2324,7 @@ int walk_run(ngravs_ctx *c)
         }
     }
   else
-    {
-      switch(c->cfg.n_gravs)
-        {
-        case 1:
-          rc = launch_group<1>(c, wp);
-          break;
-        case 2:
-          rc = launch_group<2>(c, wp);
-          break;
-        default:
-          rc = launch_group<3>(c, wp);
-          break;
-        }
-    }
+    rc = group_launch(true);
   if(rc != NGRAVS_OK)
     return rc;
   HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
@@ -2190,6 +2336,22 @@ int walk_run(ngravs_ctx *c)
       HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if(flag && used_split)
+        {
+          // a group's item list outgrew its region of the split walk: redo the step with the fused kernel, which evaluates
+          // early instead (results are complete either way; rare, very clustered inputs only)
+          HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
+          HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
+          HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
+          rc = group_launch(false);
+          if(rc != NGRAVS_OK)
+            return rc;
+          HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
+          HIP_TRY(c, hipGetLastError());
+          HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
       double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
       c->stats.reserved[0] = st64[0] / ngroups;   // pool entries per group
       c->stats.reserved[1] = st64[1] / ngroups;   // nodes tested per group
