@@ -305,6 +305,8 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   (void)hipEventDestroy(c->ev1);
   (void)hipEventDestroy(c->evk0);
   (void)hipEventDestroy(c->evk1);
+  for(hipEvent_t e : c->ev_batch)
+    (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }

@@ -153,6 +153,8 @@ struct ngravs_ctx
   std::vector<unsigned char> host_stage;
   ngravs_stats_t stats;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
+  std::vector<hipEvent_t> ev_batch;   // split walk: 3 events per batch (before traversal, between, after evaluation)
+  int walk_batches = 0;               // batches of the last split walk (0: fused kernel)
   std::string last_error;
 };
 

@@ -2223,14 +2223,25 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
   auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  for(long long g0 = 0; g0 < ngroups; g0 += batch)
+  const size_t nbatches = (size_t)((ngroups + batch - 1) / batch);
+  while(c->ev_batch.size() < 3 * nbatches)
+    {
+      hipEvent_t e;
+      HIP_TRY(c, hipEventCreate(&e));
+      c->ev_batch.push_back(e);
+    }
+  c->walk_batches = (int)nbatches;
+  size_t ib = 0;
+  for(long long g0 = 0; g0 < ngroups; g0 += batch, ib++)
     {
       const long long nb = ngroups - g0 < batch ? ngroups - g0 : batch;
+      HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib], c->stream));
       const long long tblk = 8 * (((nb + GW3_TBLOCK / 64 - 1) / (GW3_TBLOCK / 64) + 7) / 8);
       hipLaunchKernelGGL(kt, dim3((unsigned)tblk), dim3(GW3_TBLOCK), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
                          c->r_nint.p, region, gcount, g0, nb);
+      HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 1], c->stream));
       if(g0 > 0)
         HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
       long long nblk = ncu;
@@ -2240,6 +2251,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
                          c->r_nint.p, region, gcount, g0, nb);
+      HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 2], c->stream));
     }
   return NGRAVS_OK;
 }
@@ -2247,6 +2259,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
 template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, bool *used_split)
 {
   *used_split = false;
+  c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables do not fit beside the lists -> read through L1/L2
   const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
@@ -2357,6 +2370,17 @@ int walk_run(ngravs_ctx *c)
       c->stats.reserved[1] = st64[1] / ngroups;   // nodes tested per group
       c->stats.reserved[2] = st64[2] / ngroups;   // traversal batches per group
       c->stats.reserved[3] = st64[3] / ngroups;   // force-loop trips per group (max sub-group list length, summed)
+      // split walk: time of the evaluation / traversal kernels summed over the batches, and the batch count
+      c->stats.reserved[4] = c->stats.reserved[5] = c->stats.reserved[6] = 0;
+      for(int b = 0; b < c->walk_batches; b++)
+        {
+          float te = 0, tt = 0;
+          (void)hipEventElapsedTime(&tt, c->ev_batch[3 * b], c->ev_batch[3 * b + 1]);
+          (void)hipEventElapsedTime(&te, c->ev_batch[3 * b + 1], c->ev_batch[3 * b + 2]);
+          c->stats.reserved[4] += te;
+          c->stats.reserved[6] += tt;
+        }
+      c->stats.reserved[5] = c->walk_batches;
       if(flag)
         {
           ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");

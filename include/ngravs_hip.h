@@ -139,8 +139,10 @@ typedef struct {
   int64_t n_nodes;           /* Numnodestree                                             */
   double interactions;       /* sum of ninteractions over active targets (ia/part * Nf)  */
   double t_domain, t_peano, t_treebuild, t_treewalk, t_pm; /* seconds, device time       */
-  double walk_kernel_ms;     /* duration of the dominant walk kernel, HIP events          */
-  double reserved[7];
+  double walk_kernel_ms;     /* all walk kernels of the call (traversal + evaluation), HIP events */
+  double reserved[7];        /* group walk, per group: [0] list entries [1] nodes tested [2] traversal batches
+                              * [3] force-loop slots; split walk: [4] ms in the evaluation kernel (summed over its
+                              * launches) [5] number of launches (batches) [6] ms in the traversal kernel */
 } ngravs_stats_t;
 
 typedef struct ngravs_ctx ngravs_ctx;
