@@ -79,6 +79,7 @@ struct WalkParams
   double fac_intp;          // 2*NGRAVS_EN/BoxSize: lattice-table lookup scale (forcetree.c:3737)
   double fsoft[NGRAVS_NTYPES];
   int t2g[NGRAVS_NTYPES];
+  unsigned t2g_packed;   // the same map, 2 bits per type (register-resident lookups)
   // law coefficients [target][source]: accel = m*(cN/r2 + cY*exp(-r ym)(ym/r + 1/r2)); spline = cS*plummer
   double cN[NG_MAX][NG_MAX], cY[NG_MAX][NG_MAX], cS[NG_MAX][NG_MAX];
 };

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
 #define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x NLEAF items
 #define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
-#define GW2_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * 128 * (NG))
+#define GW2_WAVE_LDS ((sizeof(double4) + sizeof(double)) * 128)   // one pool: the species are evaluated one after the other
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -1200,17 +1200,20 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 //  the ~1600 entries its group collects) and the stride order balances the lanes: the force loop runs ~400
 //  trips per group instead of ~1100 (sub-group lists) / ~1900 (one shared list).
 // =============================================================================================
-#define GW2_ITEMS 16384      // item scratch per wave (global); phase 2 runs early if it would overflow
+#define GW2_ITEMS 16384      // item scratch per wave and source species (global); phase 2 runs early if it would overflow
 
 // MODE 0: fused (traversal + evaluation per group, per-wave scratch).  MODE 1: traversal only -- one wave per group of the
 // batch [g_first, g_first+g_cnt), no LDS, few registers, so that many waves hide the dependent node fetches; the item list
-// of group k goes to region_base + k*GW3_REGION (items grow up, the pending-node LIFO grows down from the top) and its
-// length to gcount[k].  MODE 2: evaluation only -- persistent workgroups with the tables in LDS run phase 2 over those lists.
-#define GW3_REGION 8192      // ints per group in the split walk (items + LIFO)
+// of group k and source species g goes to region_base + k*GW3_REGION(NG) + g*GW3_LIST (the pending-node LIFO sits behind
+// the lists) and its length to gcount[k*NG+g].  MODE 2: evaluation only -- persistent workgroups with the tables in LDS run phase 2 over those lists.
+#define GW3_LIST 4096        // split walk: item ints per group and source species
+#define GW3_STK 4096         // split walk: pending-node LIFO ints per group
+#define GW3_REGION(NG) ((NG) * GW3_LIST + GW3_STK)
+#define GW2_MAXWAVES 16      // evaluation kernel: 4 waves per SIMD (128 VGPRs), 5 KB of LDS each beside the tables
 #define GW3_TBLOCK 256       // traversal kernel: 4 groups per workgroup
 
 template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT, int MODE>
-__global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_walk_group2(
+__global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES : GW_MAXWAVES) * 64) void k_walk_group2(
     TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
     const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
@@ -1224,9 +1227,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
   const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *expT = reinterpret_cast<double *>(smem + tab_bytes);
-  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS(NG);
+  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
   double4 *lpos = reinterpret_cast<double4 *>(wbase);
-  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE * NG);
+  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE);
   if(MODE != 1)
     {
       if(threadIdx.x < 32)
@@ -1245,11 +1248,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
       __syncthreads();
     }
   const double *tabp = (PM && TAB_LDS) ? tab_s : table;
-  int *stack = nullptr, *items = nullptr;
+  // item lists, one per source species: per-wave scratch (fused) or the group's region (split)
+  int *stack = nullptr, *lists[NG];
+  constexpr int LIST_CAP = MODE == 0 ? GW2_ITEMS : GW3_LIST;
+  constexpr int STK_CAP = MODE == 0 ? GW_STACK : GW3_STK;
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    lists[g] = nullptr;
   if(MODE == 0)
     {
-      stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (GW_STACK + GW2_ITEMS);
-      items = stack + GW_STACK;
+      stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (GW_STACK + NG * GW2_ITEMS);
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        lists[g] = stack + GW_STACK + g * GW2_ITEMS;
     }
   // MODE 0 walks all groups of the shard; the split kernels one batch of them
   const long long ngroups = MODE == 0 ? (t_count + WAVE - 1) / WAVE : g_cnt;
@@ -1302,16 +1313,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
         break;
       if(MODE != 0)
         {
-          items = region_base + (size_t)grp * GW3_REGION;
-          stack = items;   // MODE 1 indexes it from the top (STK)
+          int *base = region_base + (size_t)grp * GW3_REGION(NG);
+#pragma unroll
+          for(int g = 0; g < NG; g++)
+            lists[g] = base + g * GW3_LIST;
+          stack = base + NG * GW3_LIST;
         }
       grp += gbase;
       const long long ti = t_first + grp * WAVE + lane;
       const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
       if(!__any(valid ? 1 : 0))
         {
-          if(MODE == 1 && lane == 0)
-            gcount[grp - gbase] = 0;
+          if(MODE == 1 && lane < NG)
+            gcount[(grp - gbase) * NG + lane] = 0;
           continue;
         }
       double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
@@ -1327,28 +1341,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
           hT = wp.fsoft[ptype];
           aold = wp.errtol_acc * s_oldacc[ti];
         }
-      // per-lane law coefficients against each source species
-      double cN[NG], cY[NG], cS[NG];
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-        {
-          cN[g] = wp.cN[tg][g];
-          cY[g] = wp.cY[tg][g];
-          cS[g] = wp.cS[tg][g];
-        }
-      // this lane's table rows, one per source species
-      const double *tabrow[NG];
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-        {
-          if(PM && TAB_LDS)
-            {
-              const int a = tg < g ? tg : g, b = tg < g ? g : tg;
-              tabrow[g] = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
-            }
-          else
-            tabrow[g] = tabp + ((size_t)tg * NG + g) * NTAB;
-        }
+      // law coefficients and table row of this lane against the source species being evaluated (set by phase2)
+      double cNg = 0, cYg = 0, cSg = 0;
+      const double *trow = tabp;
       // group bounding box and the conservative scalars
       double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
       double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
@@ -1407,14 +1402,14 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
             rinv[k] = ri;
             r[k] = rr;
             const double ri2 = ri * ri;
-            double f = cN[g] * ri2;
+            double f = cNg * ri2;
             if(YUK)
-              f += cY[g] * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
+              f += cYg * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
             if(PM)
               {
                 int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
                 tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
-                f -= wp.utor2wpi * tabrow[g][tab];
+                f -= wp.utor2wpi * trow[tab];
               }
             fac[k] = f * e[k].w * ri;
             h[k] = hT > hs[k] ? hT : hs[k];
@@ -1430,7 +1425,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
                                      : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
                                         0.066666666667 / (u * u * u));
-                double fs = cS[g] * e[k].w * h_inv * h_inv * h_inv * v;
+                double fs = cSg * e[k].w * h_inv * h_inv * h_inv * v;
                 fac[k] = soft[k] ? fs : fac[k];
               }
           }
@@ -1457,28 +1452,40 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
       };
 
       int st_iters = 0;
-      int n_items = 0, sp = 1;
-      // pending-node LIFO slot i: per-wave scratch (fused) or the top of the group's region, growing down (split)
-      auto STK = [&](int i) -> int & { return MODE == 1 ? stack[GW3_REGION - 1 - i] : stack[i]; };
-      if(MODE == 2)
+      int n_items[NG], sp = 1;
+      bool bad = false;
+#pragma unroll
+      for(int g = 0; g < NG; g++)
         {
-          n_items = gcount[grp - gbase];
-          sp = 0;
+          n_items[g] = MODE == 2 ? gcount[(grp - gbase) * NG + g] : 0;
+          bad |= n_items[g] < 0;
         }
+      auto STK = [&](int i) -> int & { return stack[i]; };
+      if(MODE == 2)
+        sp = 0;
       else if(lane == 0)
         STK(0) = 0;
       wave_sync();
       bool overflow = false;
-      if(MODE == 2 && n_items < 0)   // the traversal kernel overflowed this group's region (error flag already set)
+      if(MODE == 2 && bad)   // the traversal kernel overflowed this group's region (error flag already set)
         continue;
 
       // ---- phase 2: evaluate the recorded items ------------------------------------------------------------
-      auto phase2 = [&]() {
+      auto phase2 = [&](const int g, const int *__restrict__ items, const int n) {
         wave_sync();
-        const int n = n_items;
         st_entries += n;
         if(n == 0)
           return;
+        cNg = wp.cN[tg][g];
+        cYg = wp.cY[tg][g];
+        cSg = wp.cS[tg][g];
+        if(PM && TAB_LDS)
+          {
+            const int a = tg < g ? tg : g, b = tg < g ? g : tg;
+            trow = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
+          }
+        else
+          trow = tabp + ((size_t)tg * NG + g) * NTAB;
         // golden-ratio stride, coprime with n: item (i * s) mod n is visited i-th
         int s_ = (int)(0.6180339887498949 * n) | 1;
         if(s_ >= n)
@@ -1503,11 +1510,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
           }
         const int step64 = (int)((64ll * s_) % n);
         int slot = (int)(((long long)lane * s_) % n);
-        int npool[NG];
-#pragma unroll
-        for(int g = 0; g < NG; g++)
-          npool[g] = 0;
-        // one extra pass (c0 >= n) only drains what is left in the pools, so that the force loop exists once.
+        int npool = 0;
+        // one extra pass (c0 >= n) only drains what is left in the pool, so that the force loop exists once.
         // Two-deep software pipeline on the memory side: while chunk c is evaluated, the source records of chunk c+1 and
         // the item indices of chunk c+2 are already in flight.
         auto fetch_item = [&](int c0) -> int {
@@ -1517,44 +1521,39 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
           slot = slot >= n ? slot - n : slot;
           return it;
         };
-        auto fetch_rec = [&](int c0, int item, double4 &q, int &sg, double &hs) {
+        auto fetch_rec = [&](int c0, int item, double4 &q, double &hs) {
           q.x = q.y = q.z = q.w = 0;
-          sg = 0;
           hs = 0;
           if(c0 + lane < n)
             {
               if(item >= 0)
                 {
                   q = s_pm[item];
-                  int qt = s_type[item];
-                  sg = wp.t2g[qt];
-                  hs = wp.fsoft[qt];
+                  hs = wp.fsoft[s_type[item]];
                 }
               else
                 {
-                  int k = -1 - item;
+                  const int k = -1 - item;   // node * NG + g
                   q = tv.mom[k];
-                  int nd = k / NG;
-                  sg = k - nd * NG;
-                  hs = wp.fsoft[(tv.flags[nd] >> 2) & 7];
+                  hs = wp.fsoft[(tv.flags[k / NG] >> 2) & 7];
                 }
             }
         };
         int item1 = fetch_item(0);
         double4 q1;
-        int sg1;
         double hs1;
-        fetch_rec(0, item1, q1, sg1, hs1);
+        fetch_rec(0, item1, q1, hs1);
         int item2 = fetch_item(WAVE);
+        double4 *pp = lpos;
+        double *ph = lh;
         for(int c0 = 0; c0 < n + WAVE; c0 += WAVE)
           {
             const bool last = c0 >= n;
             const bool have = c0 + lane < n;
             double4 q = q1;
-            const int sg = sg1;
             const double hs = hs1;
-            fetch_rec(c0 + WAVE, item2, q1, sg1, hs1);   // chunk c+1
-            item2 = fetch_item(c0 + 2 * WAVE);            // chunk c+2
+            fetch_rec(c0 + WAVE, item2, q1, hs1);   // chunk c+1
+            item2 = fetch_item(c0 + 2 * WAVE);       // chunk c+2
             bool live = have && q.w != 0.0;
             double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
             if(wp.periodic)
@@ -1575,124 +1574,141 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
                 q.y = bcy + ey;
                 q.z = bcz + ez;
               }
-#pragma unroll
-            for(int g = 0; g < NG; g++)
+            // compact the live entries behind the ones already waiting in the pool (capacity 2 x 64)
+            const unsigned long long lm = __ballot(live ? 1 : 0);
+            if(live)
               {
-                // compact the live entries of species g behind the ones already waiting in its pool (capacity 2 x 64)
-                double4 *pp = lpos + g * 2 * WAVE;
-                double *ph = lh + g * 2 * WAVE;
-                const bool lg = live && sg == g;
-                const unsigned long long lm = __ballot(lg ? 1 : 0);
-                if(lg)
+                const int o = npool + lane_prefix(lm);
+                pp[o] = q;
+                ph[o] = hs;
+              }
+            npool += __popcll(lm);
+            wave_sync();
+            if(npool >= WAVE || (last && npool > 0))
+              {
+                const int nc = npool < WAVE ? npool : WAVE;
+                // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
+                //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
+                unsigned int mlo = 0, mhi = 0;
+                if(!(wp.dbg & 1))
                   {
-                    const int o = npool[g] + lane_prefix(lm);
-                    pp[o] = q;
-                    ph[o] = hs;
-                  }
-                npool[g] += __popcll(lm);
-                wave_sync();
-                if(npool[g] >= WAVE || (last && npool[g] > 0))
-                  {
-                    const int nc = npool[g] < WAVE ? npool[g] : WAVE;
-                    // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
-                    //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
-                    unsigned int mlo = 0, mhi = 0;
-                    if(!(wp.dbg & 1))
+#pragma unroll
+                    for(int w = 0; w < 2; w++)
                       {
+                        unsigned int word = 0;
 #pragma unroll
-                        for(int w = 0; w < 2; w++)
+                        for(int b = 0; b < 32; b++)
                           {
-                            unsigned int word = 0;
-#pragma unroll
-                            for(int b = 0; b < 32; b++)
+                            const int j = 32 * w + b;
+                            if(j < nc)
                               {
-                                const int j = 32 * w + b;
-                                if(j < nc)
+                                const double4 e = pp[j];
+                                double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
+                                if(lanewrap)
                                   {
-                                    const double4 e = pp[j];
-                                    double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
-                                    if(lanewrap)
-                                      {
-                                        dx = nearest(dx, wp.box, wp.boxhalf);
-                                        dy = nearest(dy, wp.box, wp.boxhalf);
-                                        dz = nearest(dz, wp.box, wp.boxhalf);
-                                      }
-                                    const double r2 = dx * dx + dy * dy + dz * dz;
-                                    const bool hit = valid && (PM ? (r2 < wp.reach2) : true);
-                                    word |= hit ? (1u << b) : 0u;
+                                    dx = nearest(dx, wp.box, wp.boxhalf);
+                                    dy = nearest(dy, wp.box, wp.boxhalf);
+                                    dz = nearest(dz, wp.box, wp.boxhalf);
                                   }
+                                const double r2 = dx * dx + dy * dy + dz * dz;
+                                const bool hit = valid && (PM ? (r2 < wp.reach2) : true);
+                                word |= hit ? (1u << b) : 0u;
                               }
-                            if(w == 0)
-                              mlo = word;
-                            else
-                              mhi = word;
                           }
-                      }
-                    // ---- force loop: every lane walks its own bits, four per trip
-                    unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-                    if(wp.dbg & 4)   // debug: masks are built but not evaluated
-                      {
-                        nint += __popcll(m);
-                        m = 0;
-                      }
-                    while(__any(m != 0 ? 1 : 0))
-                      {
-                        st_iters += 4;
-                        bool act[4];
-                        int jj[4];
-#pragma unroll
-                        for(int k = 0; k < 4; k++)
-                          {
-                            act[k] = m != 0;
-                            jj[k] = act[k] ? __builtin_ctzll(m) : 0;
-                            m &= m - 1;
-                          }
-                        const double4 e[4] = {pp[jj[0]], pp[jj[1]], pp[jj[2]], pp[jj[3]]};
-                        const double hh[4] = {ph[jj[0]], ph[jj[1]], ph[jj[2]], ph[jj[3]]};
-                        if(lanewrap)
-                          eval4(std::true_type{}, g, e, hh, act);
+                        if(w == 0)
+                          mlo = word;
                         else
-                          eval4(std::false_type{}, g, e, hh, act);
+                          mhi = word;
                       }
-                    wave_sync();
-                    // move the remainder to the front
-                    const int rem = npool[g] - nc;
-                    double4 tq;
-                    double th = 0;
-                    tq.x = tq.y = tq.z = tq.w = 0;
-                    if(lane < rem)
-                      {
-                        tq = pp[WAVE + lane];
-                        th = ph[WAVE + lane];
-                      }
-                    wave_sync();
-                    if(lane < rem)
-                      {
-                        pp[lane] = tq;
-                        ph[lane] = th;
-                      }
-                    npool[g] = rem;
-                    wave_sync();
                   }
+                // ---- force loop: every lane walks its own bits, four per trip
+                unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                if(wp.dbg & 4)   // debug: masks are built but not evaluated
+                  {
+                    nint += __popcll(m);
+                    m = 0;
+                  }
+                while(__any(m != 0 ? 1 : 0))
+                  {
+                    st_iters += 4;
+                    bool act[4];
+                    int jj[4];
+#pragma unroll
+                    for(int k = 0; k < 4; k++)
+                      {
+                        act[k] = m != 0;
+                        jj[k] = act[k] ? __builtin_ctzll(m) : 0;
+                        m &= m - 1;
+                      }
+                    const double4 e[4] = {pp[jj[0]], pp[jj[1]], pp[jj[2]], pp[jj[3]]};
+                    const double hh[4] = {ph[jj[0]], ph[jj[1]], ph[jj[2]], ph[jj[3]]};
+                    if(lanewrap)
+                      eval4(std::true_type{}, g, e, hh, act);
+                    else
+                      eval4(std::false_type{}, g, e, hh, act);
+                  }
+                wave_sync();
+                // move the remainder to the front
+                const int rem = npool - nc;
+                double4 tq;
+                double th = 0;
+                tq.x = tq.y = tq.z = tq.w = 0;
+                if(lane < rem)
+                  {
+                    tq = pp[WAVE + lane];
+                    th = ph[WAVE + lane];
+                  }
+                wave_sync();
+                if(lane < rem)
+                  {
+                    pp[lane] = tq;
+                    ph[lane] = th;
+                  }
+                npool = rem;
+                wave_sync();
               }
           }
         wave_sync();
-        n_items = 0;
+      };
+      auto phase2_all = [&]() {
+        for(int g = 0; g < NG; g++)
+          {
+            const int *lg = lists[0];
+            int ng_ = n_items[0];
+#pragma unroll
+            for(int q = 1; q < NG; q++)
+              if(q == g)
+                {
+                  lg = lists[q];
+                  ng_ = n_items[q];
+                }
+            phase2(g, lg, ng_);
+          }
+#pragma unroll
+        for(int g = 0; g < NG; g++)
+          n_items[g] = 0;
       };
 
       // ---- phase 1: cooperative traversal; items are only recorded ---------------------------------------------
       while(sp > 0)
         {
-          if constexpr(MODE == 1)
-            {
-              if(n_items + WAVE * (8 + NG) + sp + 8 * WAVE > GW3_REGION)   // items and LIFO would meet: the host falls back
-                {
-                  overflow = true;
-                  break;
-                }
-            }
-          else if(n_items + WAVE * (8 + NG) > GW2_ITEMS)   // the scratch list would overflow: evaluate what is there (rare)
-            phase2();
+          {
+            // one batch appends at most 64 monopoles and 8 x 64 particles to a list
+            bool full = false;
+#pragma unroll
+            for(int g = 0; g < NG; g++)
+              full |= n_items[g] + 9 * WAVE > LIST_CAP;
+            if constexpr(MODE == 1)
+              {
+                if(full)   // the host falls back to the fused kernel, which evaluates early instead
+                  {
+                    overflow = true;
+                    break;
+                  }
+              }
+            else if(full)
+              phase2_all();
+          }
           // ---------------- test up to 64 pending nodes against the group's bounding box ----------------
           const int nb = sp < WAVE ? sp : WAVE;
           sp -= nb;
@@ -1790,12 +1806,29 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
               const bool pg = dec == 1 && ((massmask >> g) & 1u);
               unsigned long long mask = __ballot(pg ? 1 : 0);
               if(pg)
-                items[n_items + lane_prefix(mask)] = -1 - (my * NG + g);
-              n_items += __popcll(mask);
+                lists[g][n_items[g] + lane_prefix(mask)] = -1 - (my * NG + g);
+              n_items[g] += __popcll(mask);
+            }
+          const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
+          // source species of the (up to 8) particles this lane is about to record, 2 bits each: eight independent
+          // byte loads in flight instead of one dependent load per ballot round
+          unsigned sp8 = 0;
+          if(NG > 1)
+            {
+#pragma unroll
+              for(int q = 0; q < 8; q++)
+                {
+                  int pi = -1;
+                  if(dec == 2 && chv[q] <= -2)
+                    pi = -2 - chv[q];
+                  if(dec == 3 && q < count)
+                    pi = first + q;
+                  if(pi >= 0)
+                    sp8 |= ((wp.t2g_packed >> (2 * s_type[pi])) & 3u) << (2 * q);
+                }
             }
           if(__any(dec == 2))
             {
-              const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
 #pragma unroll
               for(int slot = 0; slot < 8; slot++)
                 {
@@ -1805,7 +1838,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
                   if(mask)
                     {
                       int npush = __popcll(mask);
-                      if(MODE == 1 ? (sp + npush + n_items + 8 * WAVE > GW3_REGION) : (sp + npush > GW_STACK))
+                      if(sp + npush > STK_CAP)
                         overflow = true;
                       else
                         {
@@ -1815,10 +1848,20 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
                         }
                     }
                   const bool ispart = ch <= -2;
-                  unsigned long long pmask = __ballot(ispart ? 1 : 0);
-                  if(ispart)
-                    items[n_items + lane_prefix(pmask)] = -2 - ch;
-                  n_items += __popcll(pmask);
+                  if(__any(ispart ? 1 : 0))
+                    {
+                      const int pi = -2 - ch;
+                      const int sgp = (int)((sp8 >> (2 * slot)) & 3u);
+#pragma unroll
+                      for(int g = 0; g < NG; g++)
+                        {
+                          const bool pg = ispart && sgp == g;
+                          unsigned long long pmask = __ballot(pg ? 1 : 0);
+                          if(pg)
+                            lists[g][n_items[g] + lane_prefix(pmask)] = pi;
+                          n_items[g] += __popcll(pmask);
+                        }
+                    }
                 }
             }
           if(__any(dec == 3))
@@ -1836,16 +1879,28 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
               }
               for(int k = 0; k < kmax; k++)
                 {
-                  if(MODE == 1 ? (n_items + WAVE + sp > GW3_REGION) : (n_items + WAVE > GW2_ITEMS))
+                  bool full = false;
+#pragma unroll
+                  for(int g = 0; g < NG; g++)
+                    full |= n_items[g] + WAVE > LIST_CAP;
+                  if(full)
                     {
                       overflow = true;   // a bucket larger than the scratch list: not a sane input
                       break;
                     }
                   const bool more = (dec == 3) && k < count;
-                  unsigned long long pmask = __ballot(more ? 1 : 0);
-                  if(more)
-                    items[n_items + lane_prefix(pmask)] = first + k;
-                  n_items += __popcll(pmask);
+                  int sgp = (int)((sp8 >> (2 * (k & 7))) & 3u);
+                  if(NG > 1 && k >= 8)   // coincident-key buckets only
+                    sgp = more ? (int)((wp.t2g_packed >> (2 * s_type[first + k])) & 3u) : 0;
+#pragma unroll
+                  for(int g = 0; g < NG; g++)
+                    {
+                      const bool pg = more && sgp == g;
+                      unsigned long long pmask = __ballot(pg ? 1 : 0);
+                      if(pg)
+                        lists[g][n_items[g] + lane_prefix(pmask)] = first + k;
+                      n_items[g] += __popcll(pmask);
+                    }
                 }
             }
           if(overflow)
@@ -1854,25 +1909,27 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : GW_MAXWAVES * 64) void k_w
         }
       if constexpr(MODE == 1)
         {
-          if(lane == 0)
-            gcount[grp - gbase] = overflow ? -1 : n_items;
+#pragma unroll
+          for(int g = 0; g < NG; g++)
+            if(lane == g)
+              gcount[(grp - gbase) * NG + g] = overflow ? -1 : n_items[g];
         }
       else if(!overflow)
-        phase2();
+        phase2_all();
       if(MODE == 1)
         {
           if(lane == 0)
             {
-              gcount[g_cnt + (grp - gbase)] = st_nodes;
-              gcount[2 * g_cnt + (grp - gbase)] = st_batches;
+              gcount[NG * g_cnt + (grp - gbase)] = st_nodes;
+              gcount[(NG + 1) * g_cnt + (grp - gbase)] = st_batches;
             }
         }
       else
         {
           if(MODE == 2)
             {
-              st_nodes = gcount[g_cnt + (grp - gbase)];
-              st_batches = gcount[2 * g_cnt + (grp - gbase)];
+              st_nodes = gcount[NG * g_cnt + (grp - gbase)];
+              st_batches = gcount[(NG + 1) * g_cnt + (grp - gbase)];
             }
           acc_st[0] += (unsigned long long)st_entries;
           acc_st[1] += (unsigned long long)st_nodes;
@@ -2037,6 +2094,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
     {
       wp->fsoft[t] = cfg.force_softening[t];
       wp->t2g[t] = cfg.type_to_grav[t];
+      wp->t2g_packed = (t == 0 ? 0u : wp->t2g_packed) | ((unsigned)(cfg.type_to_grav[t] & 3) << (2 * t));
     }
   for(int i = 0; i < NG_MAX; i++)
     for(int j = 0; j < NG_MAX; j++)
@@ -2168,20 +2226,20 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     ncu = prop.multiProcessorCount;
   const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
   // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
-  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS(NG));
+  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   int per_cu = 1;
   if(waves > GW_MAXWAVES)
     waves = GW_MAXWAVES;   // register-limited: 3 waves per SIMD (__launch_bounds__), one workgroup per CU
   if(waves < 1)
     waves = 1;
-  size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS(NG);
+  size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
   long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
   long long nblk = (long long)ncu * per_cu;
   if(nblk > (ngroups + waves - 1) / waves)
     nblk = (ngroups + waves - 1) / waves;
   if(nblk < 1)
     nblk = 1;
-  if(c->walk_stack.ensure((size_t)nblk * waves * (GW_STACK + GW2_ITEMS)) || c->walk_counters.ensure(32))
+  if(c->walk_stack.ensure((size_t)nblk * waves * (GW_STACK + (size_t)NG * GW2_ITEMS)) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kern = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 0>;
@@ -2202,12 +2260,14 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
   const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
-  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS(NG));
-  if(waves > GW_MAXWAVES)
-    waves = GW_MAXWAVES;
+  int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
+  if(waves > GW2_MAXWAVES)
+    waves = GW2_MAXWAVES;   // register-limited: 4 waves per SIMD (__launch_bounds__), one workgroup per CU
+  if(getenv("NGRAVS_WALK_WAVES") && atoi(getenv("NGRAVS_WALK_WAVES")) > 0 && atoi(getenv("NGRAVS_WALK_WAVES")) < waves)
+    waves = atoi(getenv("NGRAVS_WALK_WAVES"));   // tuning knob: fewer waves per evaluation workgroup
   if(waves < 1)
     waves = 1;
-  const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS(NG);
+  const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
   const long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
   long long batch = 131072;
   if(getenv("NGRAVS_WALK_BATCH") && atoll(getenv("NGRAVS_WALK_BATCH")) > 0)
@@ -2216,9 +2276,9 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     batch = ngroups;
   if(batch < 1)
     batch = 1;
-  if(c->walk_stack.ensure((size_t)batch * (GW3_REGION + 3)) || c->walk_counters.ensure(32))
+  if(c->walk_stack.ensure((size_t)batch * (GW3_REGION(NG) + NG + 2)) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
-  int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * GW3_REGION;
+  int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * GW3_REGION(NG);
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
   auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
