@@ -541,7 +541,9 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
 #define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x NLEAF items
 #define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
-#define GW2_WAVE_LDS ((sizeof(double4) + sizeof(double)) * 128)   // one pool: the species are evaluated one after the other
+// one pool per wave (the species are evaluated one after the other): 128 x (double4 pos/mass, double h, 3 floats = position
+// relative to the group's box centre for the packed-fp32 reach pre-test)
+#define GW2_WAVE_LDS ((sizeof(double4) + sizeof(double) + 3 * sizeof(float)) * 128)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -1230,6 +1232,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
   unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
   double4 *lpos = reinterpret_cast<double4 *>(wbase);
   double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE);
+  float *lfx = reinterpret_cast<float *>(wbase + (sizeof(double4) + sizeof(double)) * 2 * WAVE);
+  float *lfy = lfx + 2 * WAVE, *lfz = lfx + 4 * WAVE;
   if(MODE != 1)
     {
       if(threadIdx.x < 32)
@@ -1357,6 +1361,17 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
                            (wp.boxhalf - bhmax) > 0;
       const bool lanewrap = wp.periodic && !prewrap;
+      // packed-fp32 reach pre-test (PM, no per-pair wrapping): positions relative to the box centre in fp32, threshold
+      // widened by the worst-case rounding so that no true hit is lost; the force loop re-tests in fp64 (in[k])
+      typedef float f2v __attribute__((ext_vector_type(2)));
+      const bool fastmask = PM && !lanewrap;
+      const float tfx = (float)(px - bcx), tfy = (float)(py - bcy), tfz = (float)(pz - bcz);
+      float nthr32;
+      {
+        const double rl = __builtin_sqrt(wp.reach2);
+        const double dl = 4.76837158203125e-07 * (bhmax + rl);   // 2^-21 x the largest relative coordinate
+        nthr32 = -(float)((wp.reach2 + 4.0 * rl * dl) * (1.0 + 2e-6));
+      }
 
       double ax = 0, ay = 0, az = 0;
       int nint = 0;
@@ -1581,6 +1596,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 const int o = npool + lane_prefix(lm);
                 pp[o] = q;
                 ph[o] = hs;
+                lfx[o] = (float)ex;
+                lfy[o] = (float)ey;
+                lfz[o] = (float)ez;
               }
             npool += __popcll(lm);
             wave_sync();
@@ -1590,7 +1608,39 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
                 //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
                 unsigned int mlo = 0, mhi = 0;
-                if(!(wp.dbg & 1))
+                if(fastmask && !(wp.dbg & 1))
+                  {
+                    // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
+                    // (v_alignbit), highest entry first so that entry j ends up in bit j
+                    const f2v p_x = {tfx, tfx}, p_y = {tfy, tfy}, p_z = {tfz, tfz}, n2 = {nthr32, nthr32};
+#pragma unroll
+                    for(int w = 0; w < 2; w++)
+                      {
+                        unsigned int word = 0;
+#pragma unroll
+                        for(int b = 15; b >= 0; b--)
+                          {
+                            const f2v e_x = *reinterpret_cast<const f2v *>(lfx + 32 * w + 2 * b);
+                            const f2v e_y = *reinterpret_cast<const f2v *>(lfy + 32 * w + 2 * b);
+                            const f2v e_z = *reinterpret_cast<const f2v *>(lfz + 32 * w + 2 * b);
+                            const f2v dx = e_x - p_x, dy = e_y - p_y, dz = e_z - p_z;
+                            f2v r = __builtin_elementwise_fma(dx, dx, n2);
+                            r = __builtin_elementwise_fma(dy, dy, r);
+                            r = __builtin_elementwise_fma(dz, dz, r);
+                            word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.y), 31);
+                            word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.x), 31);
+                          }
+                        if(w == 0)
+                          mlo = word;
+                        else
+                          mhi = word;
+                      }
+                    // entries beyond nc are stale; inactive lanes take nothing
+                    const unsigned long long okm = !valid ? 0ull : (nc >= 64 ? ~0ull : ((1ull << nc) - 1ull));
+                    mlo &= (unsigned int)okm;
+                    mhi &= (unsigned int)(okm >> 32);
+                  }
+                else if(!(wp.dbg & 1))
                   {
 #pragma unroll
                     for(int w = 0; w < 2; w++)
@@ -1652,17 +1702,24 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 const int rem = npool - nc;
                 double4 tq;
                 double th = 0;
+                float t0 = 0, t1 = 0, t2 = 0;
                 tq.x = tq.y = tq.z = tq.w = 0;
                 if(lane < rem)
                   {
                     tq = pp[WAVE + lane];
                     th = ph[WAVE + lane];
+                    t0 = lfx[WAVE + lane];
+                    t1 = lfy[WAVE + lane];
+                    t2 = lfz[WAVE + lane];
                   }
                 wave_sync();
                 if(lane < rem)
                   {
                     pp[lane] = tq;
                     ph[lane] = th;
+                    lfx[lane] = t0;
+                    lfy[lane] = t1;
+                    lfz[lane] = t2;
                   }
                 npool = rem;
                 wave_sync();
