@@ -1252,6 +1252,16 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       __syncthreads();
     }
   const double *tabp = (PM && TAB_LDS) ? tab_s : table;
+  if(MODE != 1 && lane == 0)
+    {
+      // the pool never holds more than 63 + 64 entries: slot 127 is free for the NULL entry (far away, massless, unsoftened)
+      double4 z;
+      z.x = z.y = z.z = 1e10;
+      z.w = 0.0;
+      lpos[127] = z;
+      lh[127] = 0.0;
+      lfx[127] = lfy[127] = lfz[127] = 1e10f;
+    }
   // item lists, one per source species: per-wave scratch (fused) or the group's region (split)
   int *stack = nullptr, *lists[NG];
   constexpr int LIST_CAP = MODE == 0 ? GW2_ITEMS : GW3_LIST;
@@ -1380,11 +1390,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       // FOUR list entries against this lane's target, written as four independent straight-line streams
       // (no branch on the common path) so that the scheduler overlaps their v_rsq / LDS-table latencies:
       // only 2 waves per SIMD fit beside the LDS tables, the ILP has to come from here.
+      // Inactive slots (a lane whose mask is exhausted) point at the pool's NULL entry (index 127: far away, mass 0), so the
+      // common path needs no per-slot masking at all; the rare slot that passed the fp32 pre-test but fails the exact
+      // r2 < reach2 test is removed under a wave-level branch.
       auto eval4 = [&](auto lw_tag, const int g, const double4 (&e)[4], const double (&hs)[4], const bool (&act)[4]) {
         constexpr bool LW = decltype(lw_tag)::value;
-        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4];
-        bool in[4];
-        bool anyin = false;
+        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4], mw[4];
+        bool fpos = false;
 #pragma unroll
         for(int k = 0; k < 4; k++)
           {
@@ -1398,18 +1410,27 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 dz[k] = nearest(dz[k], wp.box, wp.boxhalf);
               }
             r2[k] = dx[k] * dx[k] + dy[k] * dy[k] + dz[k] * dz[k];
-            in[k] = act[k] && (PM ? (r2[k] < wp.reach2) : true);
-            anyin |= in[k];
+            mw[k] = e[k].w;
+            if(PM)
+              fpos |= act[k] && !(r2[k] < wp.reach2);
           }
-        if(!__any(anyin ? 1 : 0))
-          return;                                                       // none of the four reaches any target
+        if(PM && __any(fpos ? 1 : 0))                                     // rare: beyond the exact cut
+          {
+#pragma unroll
+            for(int k = 0; k < 4; k++)
+              {
+                const bool out = act[k] && !(r2[k] < wp.reach2);
+                mw[k] = out ? 0.0 : mw[k];
+                nint -= out ? 1 : 0;
+              }
+          }
         bool anysoft = false;
         bool soft[4];
         double h[4];
 #pragma unroll
         for(int k = 0; k < 4; k++)
           {
-            // self / coincident pairs stay finite (d = 0 kills them); masked lanes are clamped at the table index
+            // self / coincident pairs stay finite (d = 0 kills them)
             const double q2 = r2[k] + 1e-290;
             double ri = __builtin_amdgcn_rsq(q2);
             ri = ri * (1.5 - 0.5 * q2 * ri * ri);                         // one Newton step: ~2^-51
@@ -1422,13 +1443,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               f += cYg * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
             if(PM)
               {
-                int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
-                tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
+                int tab = (int)(wp.asmthfac * rr);                        // saturating conversion, then clamped
+                tab = tab < NTAB - 1 ? tab : NTAB - 1;
                 f -= wp.utor2wpi * trow[tab];
               }
-            fac[k] = f * e[k].w * ri;
-            h[k] = hT > hs[k] ? hT : hs[k];
-            soft[k] = in[k] && rr < h[k];
+            fac[k] = f * mw[k] * ri;
+            h[k] = __builtin_fmax(hT, hs[k]);
+            soft[k] = rr < h[k];
             anysoft |= soft[k];
           }
         if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
@@ -1440,28 +1461,26 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
                                      : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
                                         0.066666666667 / (u * u * u));
-                double fs = cSg * e[k].w * h_inv * h_inv * h_inv * v;
+                double fs = cSg * mw[k] * h_inv * h_inv * h_inv * v;
                 fac[k] = soft[k] ? fs : fac[k];
               }
           }
 #pragma unroll
         for(int k = 0; k < 4; k++)
           {
-            const double f = in[k] ? fac[k] : 0.0;
-            ax = __builtin_fma(dx[k], f, ax);
-            ay = __builtin_fma(dy[k], f, ay);
-            az = __builtin_fma(dz[k], f, az);
-            nint += in[k] ? 1 : 0;
+            ax = __builtin_fma(dx[k], fac[k], ax);
+            ay = __builtin_fma(dy[k], fac[k], ay);
+            az = __builtin_fma(dz[k], fac[k], az);
             if(LATT)
               {
                 // periodic tree-only: every source also contributes its infinite lattice of images (forcetree.c:1605-1607);
                 // here on the SAME (finer) interaction list as the nearest-image force
                 double fx, fy, fz;
-                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, dx[k], dy[k], dz[k], fx, fy, fz);
-                const double mk = in[k] ? e[k].w : 0.0;
-                ax = __builtin_fma(mk, fx, ax);
-                ay = __builtin_fma(mk, fy, ay);
-                az = __builtin_fma(mk, fz, az);
+                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, act[k] ? dx[k] : 0.0, act[k] ? dy[k] : 0.0,
+                           act[k] ? dz[k] : 0.0, fx, fy, fz);
+                ax = __builtin_fma(mw[k], fx, ax);
+                ay = __builtin_fma(mw[k], fy, ay);
+                az = __builtin_fma(mw[k], fz, az);
               }
           }
       };
@@ -1673,11 +1692,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   }
                 // ---- force loop: every lane walks its own bits, four per trip
                 unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
-                if(wp.dbg & 4)   // debug: masks are built but not evaluated
-                  {
-                    nint += __popcll(m);
-                    m = 0;
-                  }
+                nint += __popcll(m);   // eval4 takes the (rare) slots beyond the exact cut off again
+                if(wp.dbg & 4)         // debug: masks are built but not evaluated
+                  m = 0;
                 while(__any(m != 0 ? 1 : 0))
                   {
                     st_iters += 4;
@@ -1687,7 +1704,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     for(int k = 0; k < 4; k++)
                       {
                         act[k] = m != 0;
-                        jj[k] = act[k] ? __builtin_ctzll(m) : 0;
+                        jj[k] = act[k] ? __builtin_ctzll(m) : 127;   // 127: the NULL entry
                         m &= m - 1;
                       }
                     const double4 e[4] = {pp[jj[0]], pp[jj[1]], pp[jj[2]], pp[jj[3]]};
