@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 //  golden-ratio stride order, so every chunk of 64 items is an even sample of the whole neighbourhood of the
 //  group instead of one corner of it; each lane tests the 64 chunk entries (LDS broadcast) against ITS OWN
 //  target and keeps a 64-bit hit mask per source species; the force loop then lets every lane walk its own
-//  bits (four per trip).  Per-lane lists remove the bounding-box waste of shared lists (a target needs ~375 of
+//  bits (ES per trip).  Per-lane lists remove the bounding-box waste of shared lists (a target needs ~375 of
 //  the ~1600 entries its group collects) and the stride order balances the lanes: the force loop runs ~400
 //  trips per group instead of ~1100 (sub-group lists) / ~1900 (one shared list).
 // =============================================================================================
@@ -1211,6 +1211,9 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 #define GW3_LIST 4096        // split walk: item ints per group and source species
 #define GW3_STK 4096         // split walk: pending-node LIFO ints per group
 #define GW3_REGION(NG) ((NG) * GW3_LIST + GW3_STK)
+#ifndef GW2_ES
+#define GW2_ES 2
+#endif
 #define GW2_MAXWAVES 16      // evaluation kernel: 4 waves per SIMD (128 VGPRs), 5 KB of LDS each beside the tables
 #define GW3_TBLOCK 256       // traversal kernel: 4 groups per workgroup
 
@@ -1222,6 +1225,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint,
     int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt)
 {
+  constexpr int ES = GW2_ES;   // entries per force-loop trip (independent instruction streams)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [tables (if TAB_LDS)] [exp table 32] [per wave: chunk pool 64 x (double4 pos/mass, double h, uchar species)]
   double *tab_s = reinterpret_cast<double *>(smem);
@@ -1387,18 +1391,18 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       int nint = 0;
       int st_entries = 0, st_nodes = 0, st_batches = 0;   // walk statistics (per group, wave-uniform)
 
-      // FOUR list entries against this lane's target, written as four independent straight-line streams
-      // (no branch on the common path) so that the scheduler overlaps their v_rsq / LDS-table latencies:
-      // only 2 waves per SIMD fit beside the LDS tables, the ILP has to come from here.
+      // ES list entries against this lane's target as ES independent straight-line streams (no branch on the common
+      // path).  Measured: with 4 waves per SIMD the latencies are hidden by the other waves, and ES = 2 beats 4 (fewer
+      // registers -> no spills in the loop, and a trip only rounds the longest lane's hit count up to a multiple of 2).
       // Inactive slots (a lane whose mask is exhausted) point at the pool's NULL entry (index 127: far away, mass 0), so the
       // common path needs no per-slot masking at all; the rare slot that passed the fp32 pre-test but fails the exact
       // r2 < reach2 test is removed under a wave-level branch.
-      auto eval4 = [&](auto lw_tag, const int g, const double4 (&e)[4], const double (&hs)[4], const bool (&act)[4]) {
+      auto evalN = [&](auto lw_tag, const int g, const double4 (&e)[ES], const double (&hs)[ES], const bool (&act)[ES]) {
         constexpr bool LW = decltype(lw_tag)::value;
-        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4], mw[4];
+        double dx[ES], dy[ES], dz[ES], r2[ES], rinv[ES], r[ES], fac[ES], mw[ES];
         bool fpos = false;
 #pragma unroll
-        for(int k = 0; k < 4; k++)
+        for(int k = 0; k < ES; k++)
           {
             dx[k] = e[k].x - px;
             dy[k] = e[k].y - py;
@@ -1417,7 +1421,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         if(PM && __any(fpos ? 1 : 0))                                     // rare: beyond the exact cut
           {
 #pragma unroll
-            for(int k = 0; k < 4; k++)
+            for(int k = 0; k < ES; k++)
               {
                 const bool out = act[k] && !(r2[k] < wp.reach2);
                 mw[k] = out ? 0.0 : mw[k];
@@ -1425,10 +1429,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               }
           }
         bool anysoft = false;
-        bool soft[4];
-        double h[4];
+        bool soft[ES];
+        double h[ES];
 #pragma unroll
-        for(int k = 0; k < 4; k++)
+        for(int k = 0; k < ES; k++)
           {
             // self / coincident pairs stay finite (d = 0 kills them)
             const double q2 = r2[k] + 1e-290;
@@ -1455,7 +1459,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
           {
 #pragma unroll
-            for(int k = 0; k < 4; k++)
+            for(int k = 0; k < ES; k++)
               {
                 double h_inv = 1 / h[k], u = r[k] * h_inv;
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
@@ -1466,7 +1470,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               }
           }
 #pragma unroll
-        for(int k = 0; k < 4; k++)
+        for(int k = 0; k < ES; k++)
           {
             ax = __builtin_fma(dx[k], fac[k], ax);
             ay = __builtin_fma(dy[k], fac[k], ay);
@@ -1690,29 +1694,35 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                           mhi = word;
                       }
                   }
-                // ---- force loop: every lane walks its own bits, four per trip
+                // ---- force loop: every lane walks its own bits, ES per trip
                 unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
                 nint += __popcll(m);   // eval4 takes the (rare) slots beyond the exact cut off again
                 if(wp.dbg & 4)         // debug: masks are built but not evaluated
                   m = 0;
                 while(__any(m != 0 ? 1 : 0))
                   {
-                    st_iters += 4;
-                    bool act[4];
-                    int jj[4];
+                    st_iters += ES;
+                    bool act[ES];
+                    int jj[ES];
 #pragma unroll
-                    for(int k = 0; k < 4; k++)
+                    for(int k = 0; k < ES; k++)
                       {
                         act[k] = m != 0;
                         jj[k] = act[k] ? __builtin_ctzll(m) : 127;   // 127: the NULL entry
                         m &= m - 1;
                       }
-                    const double4 e[4] = {pp[jj[0]], pp[jj[1]], pp[jj[2]], pp[jj[3]]};
-                    const double hh[4] = {ph[jj[0]], ph[jj[1]], ph[jj[2]], ph[jj[3]]};
+                    double4 e[ES];
+                    double hh[ES];
+#pragma unroll
+                    for(int k = 0; k < ES; k++)
+                      {
+                        e[k] = pp[jj[k]];
+                        hh[k] = ph[jj[k]];
+                      }
                     if(lanewrap)
-                      eval4(std::true_type{}, g, e, hh, act);
+                      evalN(std::true_type{}, g, e, hh, act);
                     else
-                      eval4(std::false_type{}, g, e, hh, act);
+                      evalN(std::false_type{}, g, e, hh, act);
                   }
                 wave_sync();
                 // move the remainder to the front
