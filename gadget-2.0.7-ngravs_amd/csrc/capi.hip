@@ -292,6 +292,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->lat.release();
   c->walk_stack.release();
   c->walk_counters.release();
+  c->walk_ovf.release();
   c->r_acc.release();
   c->r_pm.release();
   c->r_oldacc.release();

@@ -139,7 +139,8 @@ struct ngravs_ctx
   DevBuf<double> lat;         // [ng][ng][3][65^3] Ewald / lattice-sum force corrections (periodic tree-only, periodic direct sum)
   bool lat_ready = false;
   DevBuf<int> walk_stack;     // per-wave scratch
-  DevBuf<int> walk_counters;  // [1] overflow flag, [2..5] walk statistics, [8..15] per-XCD group counters
+  DevBuf<int> walk_ovf;       // split walk: groups left to the fused kernel (lists or LIFO outgrew their region)
+  DevBuf<int> walk_counters;  // [1] overflow flag, [2] groups in walk_ovf, [3] of them by the LIFO, [8..15] per-XCD group counters, [16..23] 64-bit walk statistics
   DevBuf<double> r_acc, r_pm, r_oldacc;
   DevBuf<int> r_nint;
   // pm
@@ -156,6 +157,8 @@ struct ngravs_ctx
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evk0 = nullptr, evk1 = nullptr;
   std::vector<hipEvent_t> ev_batch;   // split walk: 3 events per batch (before traversal, between, after evaluation)
   int walk_batches = 0;               // batches of the last split walk (0: fused kernel)
+  int walk_lcap = 0;                  // split walk: item-list capacity per group and species (grown on overflow)
+  int walk_scap = 0;                  // split walk: LIFO capacity per group (grown on overflow)
   std::string last_error;
 };
 

@@ -1206,11 +1206,12 @@ __global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
 
 // MODE 0: fused (traversal + evaluation per group, per-wave scratch).  MODE 1: traversal only -- one wave per group of the
 // batch [g_first, g_first+g_cnt), no LDS, few registers, so that many waves hide the dependent node fetches; the item list
-// of group k and source species g goes to region_base + k*GW3_REGION(NG) + g*GW3_LIST (the pending-node LIFO sits behind
+// of group k and source species g goes to region_base + k*(NG*lcap+scap) + g*lcap (the pending-node LIFO sits behind
 // the lists) and its length to gcount[k*NG+g].  MODE 2: evaluation only -- persistent workgroups with the tables in LDS run phase 2 over those lists.
-#define GW3_LIST 4096        // split walk: item ints per group and source species
-#define GW3_STK 4096         // split walk: pending-node LIFO ints per group
-#define GW3_REGION(NG) ((NG) * GW3_LIST + GW3_STK)
+#define GW3_LIST_MIN 4096     // split walk: item ints per group and source species (lcap; grown by the host after an overflow)
+#define GW3_LIST_MAX 65536
+#define GW3_STK_MIN 4096      // split walk: pending-node LIFO ints per group (scap; grown likewise)
+#define GW3_STK_MAX 65536
 #ifndef GW2_ES
 #define GW2_ES 2
 #endif
@@ -1223,7 +1224,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
     int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint,
-    int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt)
+    int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt, int lcap, int scap,
+    int *__restrict__ glist, int spread)
 {
   constexpr int ES = GW2_ES;   // entries per force-loop trip (independent instruction streams)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1268,8 +1270,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     }
   // item lists, one per source species: per-wave scratch (fused) or the group's region (split)
   int *stack = nullptr, *lists[NG];
-  constexpr int LIST_CAP = MODE == 0 ? GW2_ITEMS : GW3_LIST;
-  constexpr int STK_CAP = MODE == 0 ? GW_STACK : GW3_STK;
+  const int LIST_CAP = MODE == 0 ? GW2_ITEMS : lcap;
+  const int STK_CAP = MODE == 0 ? GW_STACK : scap;
 #pragma unroll
   for(int g = 0; g < NG; g++)
     lists[g] = nullptr;
@@ -1281,7 +1283,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         lists[g] = stack + GW_STACK + g * GW2_ITEMS;
     }
   // MODE 0 walks all groups of the shard; the split kernels one batch of them
-  const long long ngroups = MODE == 0 ? (t_count + WAVE - 1) / WAVE : g_cnt;
+  // glist: MODE 1 appends the groups whose lists or LIFO outgrew their region (counter[2] = how many, counter[3] = how many
+  // of them by the LIFO); MODE 0 with a glist walks exactly those groups, each spread over `spread` waves that take
+  // 64/spread of its targets (these are widely scattered targets: a smaller sub-group has a far smaller box, down to one
+  // target per wave, where the conservative group tests become the reference's own per-target tests)
+  const long long ngroups = (MODE == 0 && !glist) ? (t_count + WAVE - 1) / WAVE : (MODE == 0 ? g_cnt * spread : g_cnt);
   const long long gbase = MODE == 0 ? 0 : g_first;
   const double BIG = 1e300;
 
@@ -1329,17 +1335,24 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         }
       if(grp < 0)
         break;
+      bool mine = true;
+      if(MODE == 0 && glist)
+        {
+          const int sub = (int)(grp % spread), per = WAVE / spread;
+          grp = glist[grp / spread];
+          mine = lane >= sub * per && lane < (sub + 1) * per;
+        }
       if(MODE != 0)
         {
-          int *base = region_base + (size_t)grp * GW3_REGION(NG);
+          int *base = region_base + (size_t)grp * ((size_t)NG * lcap + scap);
 #pragma unroll
           for(int g = 0; g < NG; g++)
-            lists[g] = base + g * GW3_LIST;
-          stack = base + NG * GW3_LIST;
+            lists[g] = base + (size_t)g * lcap;
+          stack = base + (size_t)NG * lcap;
         }
       grp += gbase;
       const long long ti = t_first + grp * WAVE + lane;
-      const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
+      const bool valid = mine && (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
       if(!__any(valid ? 1 : 0))
         {
           if(MODE == 1 && lane < NG)
@@ -1504,7 +1517,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       else if(lane == 0)
         STK(0) = 0;
       wave_sync();
-      bool overflow = false;
+      bool overflow = false, stk_overflow = false;   // a list or the LIFO is full
       if(MODE == 2 && bad)   // the traversal kernel overflowed this group's region (error flag already set)
         continue;
 
@@ -1923,7 +1936,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     {
                       int npush = __popcll(mask);
                       if(sp + npush > STK_CAP)
-                        overflow = true;
+                        {
+                          overflow = true;
+                          stk_overflow = true;
+                        }
                       else
                         {
                           if(isnode)
@@ -2023,7 +2039,16 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       if(overflow)
         {
           if(lane == 0)
-            atomicExch(err_flag, 1);
+            {
+              if(MODE == 1)
+                {
+                  glist[atomicAdd(&counter[2], 1)] = (int)grp;   // finished by the fused kernel in the same step
+                  if(stk_overflow)
+                    atomicAdd(&counter[3], 1);
+                }
+              else
+                atomicOr(err_flag, stk_overflow ? 2 : 1);
+            }
           continue;
         }
       if(MODE != 1 && valid)
@@ -2302,7 +2327,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   return NGRAVS_OK;
 }
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp)
+template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
+static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nullptr, int nlist = 0)
 {
   int ncu = 256;
   hipDeviceProp_t prop;
@@ -2317,7 +2343,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   if(waves < 1)
     waves = 1;
   size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
-  long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  const int spread = !glist ? 1 : (nlist <= 4096 ? 64 : (nlist <= 65536 ? 8 : 1));
+  long long ngroups = glist ? (long long)nlist * spread : (c->shard_count + WAVE - 1) / WAVE;
   long long nblk = (long long)ncu * per_cu;
   if(nblk > (ngroups + waves - 1) / waves)
     nblk = (ngroups + waves - 1) / waves;
@@ -2325,13 +2352,16 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     nblk = 1;
   if(c->walk_stack.ensure((size_t)nblk * waves * (GW_STACK + (size_t)NG * GW2_ITEMS)) || c->walk_counters.ensure(32))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
+  if(glist)   // second pass of a split walk: keep its statistics, restart the per-XCD group counters
+    HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
+  else
+    HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kern = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 0>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                      (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
-                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, 0ll);
+                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, glist ? (long long)nlist : 0ll, 0, 0, glist, spread);
   return NGRAVS_OK;
 }
 
@@ -2353,16 +2383,31 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     waves = 1;
   const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
   const long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  // per-group region: NG item lists of lcap ints + the LIFO.  lcap starts small and is doubled (persistently) by walk_run
+  // when a list overflows; the batch shrinks so that the scratch stays within ~8 GB
+  if(c->walk_lcap < 1024)
+    {
+      c->walk_lcap = NG == 1 ? 2 * GW3_LIST_MIN : GW3_LIST_MIN;
+      if(getenv("NGRAVS_WALK_LCAP") && atoi(getenv("NGRAVS_WALK_LCAP")) >= 1024)   // test knob: small lists force the leftover pass
+        c->walk_lcap = atoi(getenv("NGRAVS_WALK_LCAP"));
+    }
+  if(c->walk_scap < GW3_STK_MIN)
+    c->walk_scap = GW3_STK_MIN;
+  const int lcap = c->walk_lcap, scap = c->walk_scap;
+  const size_t region_ints = (size_t)NG * lcap + scap;
   long long batch = 131072;
   if(getenv("NGRAVS_WALK_BATCH") && atoll(getenv("NGRAVS_WALK_BATCH")) > 0)
     batch = atoll(getenv("NGRAVS_WALK_BATCH"));
+  while(batch > 8192 && (size_t)batch * region_ints * sizeof(int) > ((size_t)8 << 30))
+    batch /= 2;
   if(batch > ngroups)
     batch = ngroups;
   if(batch < 1)
     batch = 1;
-  if(c->walk_stack.ensure((size_t)batch * (GW3_REGION(NG) + NG + 2)) || c->walk_counters.ensure(32))
+  if(c->walk_stack.ensure((size_t)batch * (region_ints + NG + 2)) || c->walk_counters.ensure(32) ||
+     c->walk_ovf.ensure((size_t)ngroups))
     return NGRAVS_ERR_NOMEM;
-  int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * GW3_REGION(NG);
+  int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * region_ints;
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
   auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
@@ -2384,7 +2429,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
       hipLaunchKernelGGL(kt, dim3((unsigned)tblk), dim3(GW3_TBLOCK), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb);
+                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, 1);
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 1], c->stream));
       if(g0 > 0)
         HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
@@ -2394,16 +2439,18 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
       hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb);
+                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, 1);
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 2], c->stream));
     }
   return NGRAVS_OK;
 }
 
-template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, bool *used_split)
+template <int NG>
+static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, bool *used_split, int *glist = nullptr, int nlist = 0)
 {
   *used_split = false;
-  c->walk_batches = 0;
+  if(!glist)
+    c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables do not fit beside the lists -> read through L1/L2
   const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
@@ -2416,7 +2463,7 @@ template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp, b
       return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
     }
   const bool v2 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 2;   // fused second-generation kernel
-  if(allow_split && !v2)
+  if(allow_split && !v2 && !glist)
     {
       *used_split = true;
       if(pm)
@@ -2426,10 +2473,13 @@ template <int NG> static int launch_group(ngravs_ctx *c, const WalkParams &wp, b
       return yuk ? launch_group3_t<NG, false, true, false, false>(c, wp) : launch_group3_t<NG, false, false, false, false>(c, wp);
     }
   if(pm)
-    return yuk ? launch_group2_t<NG, true, true, TL, false>(c, wp) : launch_group2_t<NG, true, false, TL, false>(c, wp);
+    return yuk ? launch_group2_t<NG, true, true, TL, false>(c, wp, glist, nlist)
+               : launch_group2_t<NG, true, false, TL, false>(c, wp, glist, nlist);
   if(c->cfg.periodic)
-    return yuk ? launch_group2_t<NG, false, true, false, true>(c, wp) : launch_group2_t<NG, false, false, false, true>(c, wp);
-  return yuk ? launch_group2_t<NG, false, true, false, false>(c, wp) : launch_group2_t<NG, false, false, false, false>(c, wp);
+    return yuk ? launch_group2_t<NG, false, true, false, true>(c, wp, glist, nlist)
+               : launch_group2_t<NG, false, false, false, true>(c, wp, glist, nlist);
+  return yuk ? launch_group2_t<NG, false, true, false, false>(c, wp, glist, nlist)
+             : launch_group2_t<NG, false, false, false, false>(c, wp, glist, nlist);
 }
 
 int walk_run(ngravs_ctx *c)
@@ -2454,34 +2504,43 @@ int walk_run(ngravs_ctx *c)
   HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
   int rc = NGRAVS_OK;
   bool used_split = false;
-  auto group_launch = [&](bool allow_split) -> int {
+  auto group_launch = [&](bool allow_split, int *glist, int nlist) -> int {
+    bool us = false;
+    int r;
     switch(c->cfg.n_gravs)
       {
       case 1:
-        return launch_group<1>(c, wp, allow_split, &used_split);
+        r = launch_group<1>(c, wp, allow_split, &us, glist, nlist);
+        break;
       case 2:
-        return launch_group<2>(c, wp, allow_split, &used_split);
+        r = launch_group<2>(c, wp, allow_split, &us, glist, nlist);
+        break;
       default:
-        return launch_group<3>(c, wp, allow_split, &used_split);
+        r = launch_group<3>(c, wp, allow_split, &us, glist, nlist);
+        break;
+      }
+    if(!glist)
+      used_split = us;
+    return r;
+  };
+  auto strict_launch = [&]() {
+    switch(c->cfg.n_gravs)
+      {
+      case 1:
+        pm ? launch_strict<1, true, false>(c, wp, li) : (latt ? launch_strict<1, false, true>(c, wp, li) : launch_strict<1, false, false>(c, wp, li));
+        break;
+      case 2:
+        pm ? launch_strict<2, true, false>(c, wp, li) : (latt ? launch_strict<2, false, true>(c, wp, li) : launch_strict<2, false, false>(c, wp, li));
+        break;
+      default:
+        pm ? launch_strict<3, true, false>(c, wp, li) : (latt ? launch_strict<3, false, true>(c, wp, li) : launch_strict<3, false, false>(c, wp, li));
+        break;
       }
   };
   if(c->cfg.walk_mode == NGRAVS_WALK_STRICT)
-    {
-      switch(c->cfg.n_gravs)
-        {
-        case 1:
-          pm ? launch_strict<1, true, false>(c, wp, li) : (latt ? launch_strict<1, false, true>(c, wp, li) : launch_strict<1, false, false>(c, wp, li));
-          break;
-        case 2:
-          pm ? launch_strict<2, true, false>(c, wp, li) : (latt ? launch_strict<2, false, true>(c, wp, li) : launch_strict<2, false, false>(c, wp, li));
-          break;
-        default:
-          pm ? launch_strict<3, true, false>(c, wp, li) : (latt ? launch_strict<3, false, true>(c, wp, li) : launch_strict<3, false, false>(c, wp, li));
-          break;
-        }
-    }
+    strict_launch();
   else
-    rc = group_launch(true);
+    rc = group_launch(true, nullptr, 0);
   if(rc != NGRAVS_OK)
     return rc;
   HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
@@ -2493,21 +2552,34 @@ int walk_run(ngravs_ctx *c)
       HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if(flag && used_split)
+      if(used_split)
         {
-          // a group's item list outgrew its region of the split walk: redo the step with the fused kernel, which evaluates
-          // early instead (results are complete either way; rare, very clustered inputs only)
-          HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
-          HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
-          HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
-          rc = group_launch(false);
-          if(rc != NGRAVS_OK)
-            return rc;
-          HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
-          HIP_TRY(c, hipGetLastError());
-          HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-          HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-          HIP_TRY(c, hipStreamSynchronize(c->stream));
+          // groups whose item lists or LIFO outgrew their region of the split walk were skipped by the evaluation kernel.
+          // They are the sparse outskirts, where 64 Peano-contiguous targets span a box so large that the conservative
+          // group tests open most of the tree: exactly those groups are redone by the fused kernel in sub-groups (one
+          // target per wave if they are few: the box is then the target itself and every test the reference's own).
+          // If they are many the regions grow for the following steps.
+          int ovf[2] = {0, 0};
+          HIP_TRY(c, hipMemcpy(ovf, c->walk_counters.p + 2, 2 * sizeof(int), hipMemcpyDeviceToHost));
+          if(ovf[0] > 0)
+            {
+              rc = group_launch(false, c->walk_ovf.p, ovf[0]);
+              if(rc != NGRAVS_OK)
+                return rc;
+              HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
+              HIP_TRY(c, hipGetLastError());
+              HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+              HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+              HIP_TRY(c, hipStreamSynchronize(c->stream));
+              const long long ng = (c->shard_count + WAVE - 1) / WAVE;
+              if((long long)ovf[0] * 256 > ng)
+                {
+                  if(2 * ovf[1] > ovf[0])
+                    c->walk_scap = c->walk_scap < GW3_STK_MAX ? 2 * c->walk_scap : c->walk_scap;
+                  else
+                    c->walk_lcap = c->walk_lcap < GW3_LIST_MAX ? 2 * c->walk_lcap : c->walk_lcap;
+                }
+            }
         }
       double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
       c->stats.reserved[0] = st64[0] / ngroups;   // pool entries per group

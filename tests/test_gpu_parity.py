@@ -159,6 +159,46 @@ def test_group_walk_tree_only_accuracy(pkg, O):
     eng.close()
 
 
+def test_group_walk_leftover_groups(pkg, O, monkeypatch):
+    """split walk with item lists far too short (NGRAVS_WALK_LCAP): most groups are left over by the traversal kernel
+    and redone in sub-groups (down to one target per wave = the reference's own per-target tests) by the fused kernel.
+    Every target must still get a complete force: accuracy against direct summation between the normal group walk's and
+    the reference tree's, same interaction-count scale, and the regions grow for the next step."""
+    n = 40000
+    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=7)
+    cfg = pkg.make_config(n_gravs=1, G=1.0, theta=0.5, softening=[0.01] * 6, walk_mode=pkg.WALK_GROUP)
+    idx = np.arange(0, n, 40, dtype=np.int32)
+
+    def run():
+        eng = _engine(pkg, cfg, pos, mass, typ)
+        eng.compute_accelerations(pm_step=False)
+        _, old, _ = eng.get_accel()
+        eng.set_opening(0.0, 0.005)
+        eng.set_old_acc(old)
+        eng.gravity_tree()
+        acc, _, cost = eng.get_accel()
+        eng.gravity_tree()                      # second step: grown regions, same input
+        acc_b, _, _ = eng.get_accel()
+        direct = eng.direct_sum(idx)
+        eng.close()
+        return acc, acc_b, cost, direct, old
+
+    acc_n, _, cost_n, direct, old = run()
+    monkeypatch.setenv("NGRAVS_WALK_LCAP", "1024")
+    acc_s, acc_s2, cost_s, _, _ = run()
+    cfg_s = pkg.make_config(n_gravs=1, G=1.0, theta=0.0, softening=[0.01] * 6)
+    a_o, _ = O.Tree(cfg_s, pos, mass, typ).walk(old_acc=old)
+    e_ref = rel_err(O.finish(cfg_s, a_o)[0][idx], direct)
+    e_n, e_s, e_s2 = rel_err(acc_n[idx], direct), rel_err(acc_s[idx], direct), rel_err(acc_s2[idx], direct)
+    rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
+    print("normal rms %.2e | short lists rms %.2e, next step %.2e | reference tree %.2e | ia/particle %.1f vs %.1f" %
+          (rms(e_n), rms(e_s), rms(e_s2), rms(e_ref), cost_n.mean(), cost_s.mean()))
+    assert np.all(np.isfinite(acc_s)) and np.all(cost_s > 0)
+    assert rms(e_s) <= rms(e_ref) * 1.05 and e_s.max() < 0.03
+    assert rms(e_s2) <= rms(e_ref) * 1.05 and e_s2.max() < 0.03
+    assert 0.25 < cost_s.mean() / cost_n.mean() < 2.0   # per-target tests need fewer interactions than conservative group tests
+
+
 @pytest.mark.parametrize("wiring,ng", [("newton", 1), ("c4", 2)])
 @pytest.mark.parametrize("reach", [0.0, 6.0])
 def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
