@@ -293,6 +293,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->walk_stack.release();
   c->walk_counters.release();
   c->walk_ovf.release();
+  c->lvl_table.release();
   c->r_acc.release();
   c->r_pm.release();
   c->r_oldacc.release();

@@ -89,6 +89,10 @@ struct TreeView
   const int *first, *count, *child, *flags;
   const double4 *geo, *mom;
   int nnodes;
+  // start table of the group walk (TreePM only): node index of every cell of one complete tree level, [ix][iy][iz]
+  const int *ltab;
+  int ltab_level;          // 0: none, walks start at the root
+  double ltab_corner[3], ltab_cl;
 };
 
 struct ngravs_ctx
@@ -127,6 +131,8 @@ struct ngravs_ctx
   // tree
   int64_t max_nodes = 0, nnodes = 0;
   int nlevels = 0;
+  DevBuf<int> lvl_table;      // see TreeView::ltab
+  int lvl_table_level = 0;
   int64_t level_start[MAX_LEVELS + 2];
   DevBuf<int> n_first, n_count, n_child, n_flags, n_nchild;
   DevBuf<double4> n_geo, n_mom;

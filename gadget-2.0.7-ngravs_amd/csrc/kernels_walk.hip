@@ -1514,8 +1514,78 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       auto STK = [&](int i) -> int & { return stack[i]; };
       if(MODE == 2)
         sp = 0;
-      else if(lane == 0)
-        STK(0) = 0;
+      else
+        {
+          bool from_root = true;
+          if(PM && tv.ltab_level > 0 && wp.periodic)
+            {
+              // the cells of the start level that overlap [box - reach, box + reach], per axis (wave-uniform): sample the
+              // interval every half cell, wrap into the periodic box, keep each new cell index (at most 4 per axis)
+              const double rl = __builtin_sqrt(wp.reach2), cl = tv.ltab_cl, inv_cl = 1.0 / cl;
+              const int nc = 1 << tv.ltab_level;
+              const double blo[3] = {bcx - bhx - rl, bcy - bhy - rl, bcz - bhz - rl};
+              const double bhi[3] = {bcx + bhx + rl, bcy + bhy + rl, bcz + bhz + rl};
+              int cidx[3][4], cn[3];
+              bool ok = true;
+#pragma unroll
+              for(int a = 0; a < 3; a++)
+                {
+                  cn[a] = 0;
+#pragma unroll
+                  for(int q = 0; q < 4; q++)
+                    cidx[a][q] = 0;
+                  if(!(bhi[a] - blo[a] < 3.0 * cl) || !(bhi[a] - blo[a] < wp.boxhalf))
+                    ok = false;
+                  int last = -1;
+#pragma unroll
+                  for(int sidx = 0; sidx <= 7; sidx++)
+                    {
+                      double x = blo[a] + 0.5 * cl * sidx;
+                      if(sidx == 7 || x > bhi[a])
+                        x = bhi[a];
+                      x -= wp.box * __builtin_floor(x / wp.box);
+                      int ci = (int)((x - tv.ltab_corner[a]) * inv_cl);
+                      ci = ci < 0 ? 0 : (ci >= nc ? nc - 1 : ci);
+                      if(ci != last)
+                        {
+                          if(cn[a] < 4)
+                            {
+#pragma unroll
+                              for(int q = 0; q < 4; q++)
+                                if(q == cn[a])
+                                  cidx[a][q] = ci;
+                              cn[a]++;
+                            }
+                          else
+                            ok = false;
+                          last = ci;
+                        }
+                    }
+                }
+              const int total = cn[0] * cn[1] * cn[2];
+              if(ok && total <= WAVE)
+                {
+                  from_root = false;
+                  if(lane < total)
+                    {
+                      const int i0 = lane / (cn[1] * cn[2]), rem_ = lane - i0 * (cn[1] * cn[2]);
+                      const int i1 = rem_ / cn[2], i2 = rem_ - i1 * cn[2];
+                      int c0 = cidx[0][0], c1 = cidx[1][0], c2 = cidx[2][0];
+#pragma unroll
+                      for(int q = 1; q < 4; q++)
+                        {
+                          c0 = i0 == q ? cidx[0][q] : c0;
+                          c1 = i1 == q ? cidx[1][q] : c1;
+                          c2 = i2 == q ? cidx[2][q] : c2;
+                        }
+                      STK(lane) = tv.ltab[((size_t)c0 * nc + c1) * nc + c2];
+                    }
+                  sp = total;
+                }
+            }
+          if(from_root && lane == 0)
+            STK(0) = 0;
+        }
       wave_sync();
       bool overflow = false, stk_overflow = false;   // a list or the LIFO is full
       if(MODE == 2 && bad)   // the traversal kernel overflowed this group's region (error flag already set)
@@ -2246,7 +2316,58 @@ static TreeView tree_view(ngravs_ctx *c)
   tv.geo = c->n_geo.p;
   tv.mom = c->n_mom.p;
   tv.nnodes = (int)c->nnodes;
+  tv.ltab = c->lvl_table.p;
+  tv.ltab_level = c->lvl_table_level;
+  tv.ltab_cl = c->lvl_table_level ? c->dom[6] / (double)(1 << c->lvl_table_level) : 0.0;
+  for(int j = 0; j < 3; j++)
+    tv.ltab_corner[j] = c->dom[j];
   return tv;
+}
+
+// ---- start table: the TreePM group walk only ever uses nodes within the short-range reach of a group's box, so instead of
+// re-descending the same top levels for every group (a third of the traversal's batches) it starts from the cells of one
+// tree level that overlap that region.  Valid when the level is complete (all 8^L cells are nodes: then no particle hangs
+// directly below a shallower node) -- the deepest such level whose cells are still at least two reaches wide.
+__global__ void k_level_table(const double4 *__restrict__ geo, int node0, int cnt, double cx, double cy, double cz, double inv_cl,
+                              int nc, int *__restrict__ tab)
+{
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if(k >= cnt)
+    return;
+  const double4 g = geo[node0 + k];
+  int ix = (int)((g.x - cx) * inv_cl), iy = (int)((g.y - cy) * inv_cl), iz = (int)((g.z - cz) * inv_cl);
+  ix = ix < 0 ? 0 : (ix >= nc ? nc - 1 : ix);
+  iy = iy < 0 ? 0 : (iy >= nc ? nc - 1 : iy);
+  iz = iz < 0 ? 0 : (iz >= nc ? nc - 1 : iz);
+  tab[((size_t)ix * nc + iy) * nc + iz] = node0 + k;
+}
+
+static int ensure_level_table(ngravs_ctx *c, double reach)
+{
+  c->lvl_table_level = 0;
+  if(!c->cfg.pmgrid || !c->cfg.periodic || (getenv("NGRAVS_WALK_ROOT") && atoi(getenv("NGRAVS_WALK_ROOT"))))
+    return NGRAVS_OK;
+  int best = 0;
+  for(int l = 2; l <= 6 && l < c->nlevels; l++)
+    {
+      const long long have = c->level_start[l + 1] - c->level_start[l];
+      if(have != (1ll << (3 * l)))
+        break;
+      if(c->dom[6] / (double)(1 << l) >= 2.0 * reach)
+        best = l;
+    }
+  if(!best)
+    return NGRAVS_OK;
+  const int nc = 1 << best;
+  const long long cnt = 1ll << (3 * best);
+  if(c->lvl_table.ensure((size_t)cnt))
+    return NGRAVS_ERR_NOMEM;
+  hipLaunchKernelGGL(k_level_table, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, c->n_geo.p,
+                     (int)c->level_start[best], (int)cnt, c->dom[0], c->dom[1], c->dom[2], (double)nc / c->dom[6], nc,
+                     c->lvl_table.p);
+  HIP_TRY(c, hipGetLastError());
+  c->lvl_table_level = best;
+  return NGRAVS_OK;
 }
 
 // lattice_init: one Ewald / lattice sum per distinct law, replicated into the [target][source] slots
@@ -2498,6 +2619,12 @@ int walk_run(ngravs_ctx *c)
   make_walk_params(c, &wp);
   LawIds li;
   make_law_ids(c, &li);
+  if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
+    {
+      int rct = ensure_level_table(c, sqrt(wp.reach2));
+      if(rct)
+        return rct;
+    }
   HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
   const bool pm = c->cfg.pmgrid != 0;
