@@ -39,7 +39,6 @@ __device__ __forceinline__ double nearest(double x, double box, double boxhalf)
 {
   return (x > boxhalf) ? (x - box) : ((x < -boxhalf) ? (x + box) : x);   // NEAREST, forcetree.c:43
 }
-
 // ---------------------------------------------------------------------------------------------
 // force laws, reference formulation (strict walk, direct sum)
 // ---------------------------------------------------------------------------------------------
@@ -1890,35 +1889,12 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
           if(my >= 0)
             {
+              // The kernels are bound by the number of scattered lane-loads (the other waves hide the latency), so the
+              // record is fetched in stages: geometry first, the multipole moments only if the cell is within reach, the child
+              // links only if the node is opened.
               const double4 geo = tv.geo[my];
               const int fl = tv.flags[my];
-              // fetched with the record, not after the decision: one dependent memory round trip less per batch
-              first = tv.first[my];
-              count = tv.count[my];
-              {
-                const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
-                ch_lo = cp[0];
-                ch_hi = cp[1];
-              }
-              const double len = geo.w;
-              double r2min = BIG, summass = 0;
-#pragma unroll
-              for(int g = 0; g < NG; g++)
-                {
-                  const double4 mom = tv.mom[(long long)my * NG + g];
-                  summass += mom.w;
-                  massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
-                  double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
-                  if(wp.periodic)
-                    {
-                      dx = nearest(dx, wp.box, wp.boxhalf);
-                      dy = nearest(dy, wp.box, wp.boxhalf);
-                      dz = nearest(dz, wp.box, wp.boxhalf);
-                    }
-                  double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
-                  double r2g = a0 * a0 + a1 * a1 + a2 * a2;
-                  r2min = r2g < r2min ? r2g : r2min;
-                }
+              const double len = geo.w, half = 0.5 * len;
               double cx = geo.x - bcx, cy = geo.y - bcy, cz = geo.z - bcz;   // plain (inside-cell test has no NEAREST)
               double wx = cx, wy = cy, wz = cz;
               if(wp.periodic)
@@ -1932,39 +1908,67 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               if(PM && !drop)
                 {
                   // (i) nothing inside the cell can be within the cut of any target
-                  double half = 0.5 * len;
                   double q0 = fmax(0.0, fabs(wx) - bhx - half), q1 = fmax(0.0, fabs(wy) - bhy - half),
                          q2 = fmax(0.0, fabs(wz) - bhz - half);
                   if(q0 * q0 + q1 * q1 + q2 * q2 >= wp.reach2)
                     drop = true;
+                }
+              if(!drop)
+                {
+                  first = tv.first[my];
+                  count = tv.count[my];
+                  double r2min = BIG, summass = 0;
+#pragma unroll
+                  for(int g = 0; g < NG; g++)
+                    {
+                      const double4 mom = tv.mom[(long long)my * NG + g];
+                      summass += mom.w;
+                      massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
+                      double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
+                      if(wp.periodic)
+                        {
+                          dx = nearest(dx, wp.box, wp.boxhalf);
+                          dy = nearest(dy, wp.box, wp.boxhalf);
+                          dz = nearest(dz, wp.box, wp.boxhalf);
+                        }
+                      double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
+                      double r2g = a0 * a0 + a1 * a1 + a2 * a2;
+                      r2min = r2g < r2min ? r2g : r2min;
+                    }
                   // (ii) the reference's own cut (forcetree.c:1828-1862) holds for every target
-                  if(!drop && r2min > wp.rcut2)
+                  if(PM && r2min > wp.rcut2)
                     {
                       double eff = wp.rcut + half;
                       if(fabs(wx) - bhx > eff || fabs(wy) - bhy > eff || fabs(wz) - bhz > eff)
                         drop = true;
                     }
-                }
-              if(!drop)
-                {
-                  bool open;
-                  if(wp.use_theta)
-                    open = len * len > r2min * wp.theta2;
-                  else
+                  if(!drop)
                     {
-                      open = summass * len * len > r2min * r2min * aold_min;
-                      if(!open)
-                        open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
-                               (fabs(cz) - bhz < 0.60 * len);
+                      bool open;
+                      if(wp.use_theta)
+                        open = len * len > r2min * wp.theta2;
+                      else
+                        {
+                          open = summass * len * len > r2min * r2min * aold_min;
+                          if(!open)
+                            open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
+                                   (fabs(cz) - bhz < 0.60 * len);
+                        }
+                      const double hs_node = wp.fsoft[mst];
+                      if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
+                        open = true;
+                      if(open)
+                        dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
+                      else
+                        dec = 1;
                     }
-                  const double hs_node = wp.fsoft[mst];
-                  if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
-                    open = true;
-                  if(open)
-                    dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
-                  else
-                    dec = 1;
                 }
+            }
+          if(dec == 2)
+            {
+              const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
+              ch_lo = cp[0];
+              ch_hi = cp[1];
             }
           // record the items of this batch (appended in traversal order; phase 2 reads them in stride order)
 #pragma unroll
