@@ -2577,7 +2577,7 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
   if(!glist)
     c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
-  constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables do not fit beside the lists -> read through L1/L2
+  constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables beside the pools would leave 9 waves; measured equal to 16 waves reading them through L1/L2
   const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
   if(v1)
     {
