@@ -300,6 +300,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->r_nint.release();
   c->pm_rho.release();
   c->pm_phi.release();
+  c->pm_force.release();
   c->pm_orig.release();
   c->out_tmp.release();
   c->out_tmpf.release();

@@ -153,6 +153,7 @@ struct ngravs_ctx
   int pm_plan_n = 0;
   void *fft_fwd = nullptr, *fft_inv = nullptr;   // hipfftHandle (int) boxed
   DevBuf<double> pm_rho;      // [ng][N][N][N+2] real / complex in place
+  DevBuf<double> pm_force;     // [N][N][N][3]: finite-difference force mesh of one target species (two-pass gather)
   DevBuf<double> pm_phi;      // [ng][N][N][N+2]
   DevBuf<double> pm_orig;     // GravPM in caller order (persists between PM steps)
   // staging for results

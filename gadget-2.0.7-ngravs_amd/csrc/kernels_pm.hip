@@ -162,6 +162,67 @@ __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsign
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Two-pass gather, per target species: (1) the 4-point finite-difference force of every mesh cell, 3 doubles per cell,
+// streamed; (2) the CIC gather of 8 cell forces per particle (8 x 24 contiguous bytes instead of 96 scattered potential
+// reads).  Same expressions and the same corner order as k_gradient_gather, hence identical results.
+// ---------------------------------------------------------------------------------------------------
+__global__ void k_force_mesh(const double *__restrict__ grid, int N, double fac, double *__restrict__ fm)
+{
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long NN = (long long)N * N * N;
+  if(idx >= NN)
+    return;
+  const int z = (int)(idx % N), y = (int)((idx / N) % N), x = (int)(idx / ((long long)N * N));
+  const long long NZ = N + 2;
+  auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
+  auto at = [&](int xx, int yy, int zz) { return grid[((long long)xx * N + yy) * NZ + zz]; };
+  fm[3 * idx + 0] = fac * ((4.0 / 3) * (at(wrap(x - 1), y, z) - at(wrap(x + 1), y, z)) -
+                           (1.0 / 6) * (at(wrap(x - 2), y, z) - at(wrap(x + 2), y, z)));
+  fm[3 * idx + 1] = fac * ((4.0 / 3) * (at(x, wrap(y - 1), z) - at(x, wrap(y + 1), z)) -
+                           (1.0 / 6) * (at(x, wrap(y - 2), z) - at(x, wrap(y + 2), z)));
+  fm[3 * idx + 2] = fac * ((4.0 / 3) * (at(x, y, wrap(z - 1)) - at(x, y, wrap(z + 1))) -
+                           (1.0 / 6) * (at(x, y, wrap(z - 2)) - at(x, y, wrap(z + 2))));
+}
+
+__global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                               const unsigned char *__restrict__ s_flag, long long first, long long n, double to_slab, int N,
+                               const int *__restrict__ t2g_tab, int species, const double *__restrict__ fm,
+                               double *__restrict__ r_pm)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  i += first;
+  if(s_flag[i] & 2)
+    {
+      if(species == 0)
+        r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
+      return;
+    }
+  if(t2g_tab[s_type[i]] != species)
+    return;
+  const double4 p = s_pm[i];
+  double dx, dy, dz;
+  int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
+  double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+  double acc[3] = {0, 0, 0};
+  auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
+  const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+  for(int c = 0; c < 8; c++)
+    {
+      const int x = wrap(sx + ox[c]), y = wrap(sy + oy[c]), z = wrap(sz + oz[c]);
+      const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
+      const double *f = fm + 3 * (((long long)x * N + y) * N + z);
+      acc[0] += f[0] * w;
+      acc[1] += f[1] * w;
+      acc[2] += f[2] * w;
+    }
+  r_pm[3 * i + 0] = acc[0];
+  r_pm[3 * i + 1] = acc[1];
+  r_pm[3 * i + 2] = acc[2];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Tiled variants.  The particles are Peano-sorted and the tree node of a level-Lt cell owns one contiguous
 // particle range, so one workgroup per node can deposit into / gather from an LDS copy of the mesh patch
 // the cell touches: the 8 scattered fp64 global atomics per particle (64 lanes -> 64 rows, the slow atomic
@@ -565,6 +626,22 @@ int pm_finish(ngravs_ctx *c)
         hipLaunchKernelGGL(k_gradient_gather_loose, dim3((unsigned)((8 * gl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
                            c->s_type.p, c->s_active.p, c->n_child.p, (int)gl0, (long long)c->shard_first, (long long)c->shard_count,
                            to_slab, N, c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
+    }
+  else if(nbg > 0 && c->cfg.world_size <= 2 && !(getenv("NGRAVS_PM_FUSED_GATHER") && atoi(getenv("NGRAVS_PM_FUSED_GATHER"))))
+    {
+      // two passes per target species (see k_force_mesh); with many tasks the (replicated) force-mesh pass would cost more
+      // than the sharded fused gather below
+      const long long NN = (long long)N * N * N;
+      if(c->pm_force.ensure((size_t)(3 * NN)))
+        return NGRAVS_ERR_NOMEM;
+      for(int b = 0; b < ng; b++)
+        {
+          hipLaunchKernelGGL(k_force_mesh, dim3((unsigned)((NN + bs - 1) / bs)), dim3(bs), 0, c->stream, c->pm_phi.p + real_elems * b, N,
+                             fac, c->pm_force.p);
+          hipLaunchKernelGGL(k_gather_force, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
+                             (long long)c->shard_first, (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, b, c->pm_force.p,
+                             c->r_pm.p);
+        }
     }
   else if(nbg > 0)
     hipLaunchKernelGGL(k_gradient_gather, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, (long long)c->shard_first,
