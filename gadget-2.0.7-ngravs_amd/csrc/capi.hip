@@ -263,6 +263,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->in_type.release();
   c->in_active.release();
   c->in_key.release();
+  c->in_rec.release();
   c->in_id.release();
   c->dd_mask.release();
   c->dd_counts.release();

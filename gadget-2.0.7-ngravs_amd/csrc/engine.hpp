@@ -114,6 +114,7 @@ struct ngravs_ctx
   DevBuf<double> in_pos, in_mass, in_oldacc;
   DevBuf<int> in_type;
   DevBuf<unsigned char> in_active;
+  DevBuf<double2> in_rec;      // packed 48-byte records of the caller-order columns (dom_keys_and_sort)
   DevBuf<unsigned long long> in_key;
   DevBuf<long long> in_id;
   // multi-task decomposition scratch

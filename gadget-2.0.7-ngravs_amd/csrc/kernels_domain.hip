@@ -102,9 +102,14 @@ __device__ __forceinline__ long long ph_key_dev(const unsigned short (*step)[8],
 }
 
 // one thread per particle: key at `bits` bits per dimension.  fac_scaled = DomainFac * 2^(bits-18)
+// With `rec` it also packs the particle's columns into one 48-byte record {x, y, z, mass, oldacc, type | active << 8}
+// (streamed, coalesced), so that the permutation into Peano order gathers ONE record per particle instead of five
+// scattered column reads.
 __global__ void k_keys(const double *__restrict__ pos, long long n, double cx, double cy, double cz,
                        double fac_scaled, int bits, unsigned long long *__restrict__ keys,
-                       unsigned int *__restrict__ iota)
+                       unsigned int *__restrict__ iota, const double *__restrict__ mass = nullptr,
+                       const int *__restrict__ type = nullptr, const double *__restrict__ oldacc = nullptr,
+                       const unsigned char *__restrict__ active = nullptr, double2 *__restrict__ rec = nullptr)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
@@ -120,28 +125,41 @@ __global__ void k_keys(const double *__restrict__ pos, long long n, double cx, d
   keys[i] = (unsigned long long)ph_key_dev(step, x, y, z, bits);
   if(iota)
     iota[i] = (unsigned int)i;
+  if(rec)
+    {
+      double2 a, b, d;
+      a.x = pos[3 * i + 0];
+      a.y = pos[3 * i + 1];
+      b.x = pos[3 * i + 2];
+      b.y = mass[i];
+      d.x = oldacc[i];
+      d.y = __longlong_as_double((long long)(type[i] & 255) | ((long long)active[i] << 8));
+      rec[3 * i + 0] = a;
+      rec[3 * i + 1] = b;
+      rec[3 * i + 2] = d;
+    }
 }
 
 // gather the caller-order columns into Peano order
-__global__ void k_gather(const unsigned int *__restrict__ idx, long long n, const double *__restrict__ pos,
-                         const double *__restrict__ mass, const int *__restrict__ type,
-                         const double *__restrict__ oldacc, const unsigned char *__restrict__ active,
+__global__ void k_gather(const unsigned int *__restrict__ idx, long long n, const double2 *__restrict__ rec,
                          double4 *__restrict__ s_pm, unsigned char *__restrict__ s_type,
                          double *__restrict__ s_oldacc, unsigned char *__restrict__ s_active)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  unsigned int j = idx[i];
+  const long long j = idx[i];
+  const double2 a = rec[3 * j + 0], b = rec[3 * j + 1], d = rec[3 * j + 2];
   double4 v;
-  v.x = pos[3 * (long long)j + 0];
-  v.y = pos[3 * (long long)j + 1];
-  v.z = pos[3 * (long long)j + 2];
-  v.w = mass[j];
+  v.x = a.x;
+  v.y = a.y;
+  v.z = b.x;
+  v.w = b.y;
   s_pm[i] = v;
-  s_type[i] = (unsigned char)type[j];
-  s_oldacc[i] = oldacc[j];
-  s_active[i] = active[j];
+  const long long meta = __double_as_longlong(d.y);
+  s_type[i] = (unsigned char)(meta & 255);
+  s_oldacc[i] = d.x;
+  s_active[i] = (unsigned char)((meta >> 8) & 255);
 }
 
 int dom_keys_and_sort(ngravs_ctx *c)
@@ -149,12 +167,13 @@ int dom_keys_and_sort(ngravs_ctx *c)
   const long long n = c->n;
   const int bs = 256;
   const unsigned nb = (unsigned)((n + bs - 1) / bs);
-  if(c->in_key.ensure(n) || c->idx_iota.ensure(n) || c->s_key.ensure(n) || c->s_idx.ensure(n) ||
+  if(c->in_key.ensure(n) || c->idx_iota.ensure(n) || c->s_key.ensure(n) || c->s_idx.ensure(n) || c->in_rec.ensure(3 * n) ||
      c->s_pm.ensure(n) || c->s_type.ensure(n) || c->s_oldacc.ensure(n) || c->s_active.ensure(n))
     return NGRAVS_ERR_NOMEM;
   double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));   // exact power-of-2 scaling
   hipLaunchKernelGGL(k_keys, dim3(nb), dim3(bs), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2],
-                     fac21, TREE_BITS, c->in_key.p, c->idx_iota.p);
+                     fac21, TREE_BITS, c->in_key.p, c->idx_iota.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p,
+                     c->in_rec.p);
   size_t tmp_bytes = 0;
   hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p, c->s_idx.p, (int)n, 0,
                                      3 * TREE_BITS, c->stream);
@@ -162,9 +181,8 @@ int dom_keys_and_sort(ngravs_ctx *c)
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
                                                 c->s_idx.p, (int)n, 0, 3 * TREE_BITS, c->stream));
-  hipLaunchKernelGGL(k_gather, dim3(nb), dim3(bs), 0, c->stream, c->s_idx.p, n, c->in_pos.p, c->in_mass.p,
-                     c->in_type.p, c->in_oldacc.p, c->in_active.p, c->s_pm.p, c->s_type.p, c->s_oldacc.p,
-                     c->s_active.p);
+  hipLaunchKernelGGL(k_gather, dim3(nb), dim3(bs), 0, c->stream, c->s_idx.p, n, c->in_rec.p, c->s_pm.p, c->s_type.p,
+                     c->s_oldacc.p, c->s_active.p);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }
@@ -175,7 +193,8 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
   const int bs = 256;
   const unsigned nb = (unsigned)((n + bs - 1) / bs);
   hipLaunchKernelGGL(k_keys, dim3(nb), dim3(bs), 0, c->stream, d_pos, (long long)n, corner[0], corner[1], corner[2],
-                     fac, bits, (unsigned long long *)d_keys, (unsigned int *)nullptr);
+                     fac, bits, (unsigned long long *)d_keys, (unsigned int *)nullptr, (const double *)nullptr, (const int *)nullptr,
+                     (const double *)nullptr, (const unsigned char *)nullptr, (double2 *)nullptr);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }
