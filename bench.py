@@ -47,7 +47,7 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
 def walk_traffic(args, n, world):
     """HBM-side bytes per launch of the walk kernel from the committed rocprofv3 --pmc passes (profiles/), only when
     the run IS that workload (PMC counters cannot be collected inside this process)"""
-    path = os.path.join(ROOT, "profiles", "r01d_walk_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01e_walk_traffic.json")
     if args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and os.path.exists(path):
         with open(path) as f:
             return json.load(f)["traffic_bytes_per_launch"]
