@@ -26,7 +26,8 @@ _LIB = None
 EXPORTS = [
     "ngravs_abi_version", "ngravs_build_info", "ngravs_config_default", "ngravs_create", "ngravs_destroy",
     "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_particles",
-    "ngravs_set_old_acc", "ngravs_domain_decomposition", "ngravs_force_treebuild", "ngravs_gravity_tree",
+    "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition",
+    "ngravs_force_treebuild", "ngravs_gravity_tree",
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
@@ -179,6 +180,33 @@ class Engine:
         self._keep = keep
         self.n = p.n
         self._check(lib().ngravs_set_particles(self._h, C.byref(p)), "ngravs_set_particles")
+
+    def update_particles(self, pos, mass, ptype, old_acc=None, active=None):
+        """same particles, new positions / OldAcc / active flags: the decomposition and the tree topology are kept
+        (drifted tree, TreeDomainUpdateFrequency > 0); gravity_tree() / pmforce_periodic() refit the nodes first"""
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        ptype = np.ascontiguousarray(ptype, dtype=np.int32)
+        p = Particles()
+        p.n = len(pos)
+        p.pos, p.pos_stride = pos.ctypes.data, 24
+        p.mass, p.mass_stride = mass.ctypes.data, 8
+        p.type, p.type_stride = ptype.ctypes.data, 4
+        keep = [pos, mass, ptype]
+        if old_acc is not None:
+            old_acc = np.ascontiguousarray(old_acc, dtype=np.float64)
+            p.old_acc, p.old_acc_stride = old_acc.ctypes.data, 8
+            keep.append(old_acc)
+        if active is not None:
+            active = np.ascontiguousarray(active, dtype=np.uint8)
+            p.active, p.active_stride = active.ctypes.data, 1
+            keep.append(active)
+        p.on_device = 0
+        self._keep = keep
+        self._check(lib().ngravs_update_particles(self._h, C.byref(p)), "ngravs_update_particles")
+
+    def force_update_tree(self):
+        self._check(lib().ngravs_force_update_tree(self._h), "ngravs_force_update_tree")
 
     def set_particles_device(self, n, pos_ptr, mass_ptr, type_ptr, old_acc_ptr=None, active_ptr=None):
         """HIP device pointers (e.g. torch tensors' data_ptr()): zero-copy hand-over."""

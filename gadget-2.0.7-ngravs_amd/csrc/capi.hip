@@ -365,10 +365,17 @@ static int upload_column_f64(ngravs_ctx *c, const void *src, int64_t stride, int
   return NGRAVS_OK;
 }
 
-extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p)
+static double ev_ms(ngravs_ctx *c);
+
+static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool keep_tree)
 {
   if(!c || !p || p->n <= 0 || !p->pos || !p->mass || !p->type)
     return NGRAVS_ERR_ARG;
+  if(keep_tree && (!c->have_order || !c->have_tree || p->n != c->n || c->n_local != c->n))
+    {
+      ngravs_report(c, NGRAVS_ERR_STATE, "ngravs_update_particles: needs a built tree over the same particles (no halo copies)");
+      return NGRAVS_ERR_STATE;
+    }
   if(p->n >= (1ll << 31) - 64)
     {
       ngravs_report(c, NGRAVS_ERR_ARG, "int particle indices (reference All.MaxPart is int): n must be < 2^31");
@@ -384,7 +391,7 @@ extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p)
   c->n = n;
   c->n_local = n;
   int rc;
-  if((rc = dd_fill_ids(c)))
+  if(!keep_tree && (rc = dd_fill_ids(c)))
     return rc;
   if((rc = upload_column_f64(c, p->pos, p->pos_stride, 3, n, p->on_device, c->in_pos.p)))
     return rc;
@@ -435,7 +442,35 @@ extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p)
     hipLaunchKernelGGL(k_fill_u8, GRID1(n), 0, c->stream, c->in_active.p, (long long)n, (unsigned char)1);
   HIP_TRY(c, hipGetLastError());
   c->have_particles = true;
-  c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over
+  if(keep_tree)
+    c->tree_stale = true;    // same order and topology; columns and moments are refreshed by ngravs_force_update_tree
+  else
+    c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_set_particles(ngravs_ctx *c, const ngravs_particles_t *p) { return set_particles_impl(c, p, false); }
+
+extern "C" int ngravs_update_particles(ngravs_ctx *c, const ngravs_particles_t *p) { return set_particles_impl(c, p, true); }
+
+// the drifted tree of predict.c:79-91 + force_update_len(): same decomposition and topology, fresh columns, recomputed
+// moments and grown cell sides
+extern "C" int ngravs_force_update_tree(ngravs_ctx *c)
+{
+  if(!c || !c->have_order || !c->have_tree)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  int rc = dom_regather(c);
+  if(rc)
+    return rc;
+  if((rc = tree_moments(c, true)))
+    return rc;
+  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+  c->stats.t_treebuild = ev_ms(c) * 1e-3;
+  c->stats.t_domain = c->stats.t_peano = 0;
+  c->tree_stale = false;
+  c->tree_refit = true;
   return NGRAVS_OK;
 }
 
@@ -499,6 +534,7 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
   c->shard_count = hi - lo;
   c->have_order = true;
   c->have_tree = false;   // TreeReconstructFlag = 1 (domain.c:84)
+  c->tree_stale = false;
   if(c->have_pm)
     {
       if(c->r_pm.ensure(3 * c->n))
@@ -525,6 +561,7 @@ extern "C" int64_t ngravs_force_treebuild(ngravs_ctx *c)
     return NGRAVS_ERR_NO_DEVICE;
   c->stats.t_treebuild = ev_ms(c) * 1e-3;
   c->have_tree = true;
+  c->tree_refit = false;
   return c->nnodes;
 }
 
@@ -555,6 +592,8 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
       if(nn < 0)
         return (int)nn;
     }
+  else if(c->tree_stale && (rc = ngravs_force_update_tree(c)))   // drifted tree: refresh columns and moments first
+    return rc;
   if((rc = ensure_table(c)))
     return rc;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
@@ -597,6 +636,8 @@ extern "C" int ngravs_pmforce_periodic(ngravs_ctx *c)
       if(nn < 0)
         return (int)nn;
     }
+  else if(c->tree_stale && (rc = ngravs_force_update_tree(c)))
+    return rc;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   if((rc = pm_run(c)))
     return rc;

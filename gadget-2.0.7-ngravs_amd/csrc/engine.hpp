@@ -131,6 +131,8 @@ struct ngravs_ctx
   DevBuf<double> red_tmp;
   // tree
   int64_t max_nodes = 0, nnodes = 0;
+  bool tree_refit = false;    // the tree was refit since it was built (cells may have grown)
+  bool tree_stale = false;    // ngravs_update_particles was called: the columns of the sorted set are out of date
   int nlevels = 0;
   DevBuf<int> lvl_table;      // see TreeView::ltab
   int lvl_table_level = 0;
@@ -185,6 +187,8 @@ int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
 // ---- kernels_tree.hip
 int tree_build(ngravs_ctx *c);
+int tree_moments(ngravs_ctx *c, bool refit);
+int dom_regather(ngravs_ctx *c);
 // ---- kernels_walk.hip
 void make_walk_params(const ngravs_ctx *c, WalkParams *wp);
 int walk_run(ngravs_ctx *c);

@@ -187,6 +187,23 @@ int dom_keys_and_sort(ngravs_ctx *c)
   return NGRAVS_OK;
 }
 
+// drifted tree: same Peano order, fresh columns (positions, OldAcc, active flags) -- pack + gather without the sort
+int dom_regather(ngravs_ctx *c)
+{
+  const long long n = c->n;
+  const int bs = 256;
+  const unsigned nb = (unsigned)((n + bs - 1) / bs);
+  if(c->in_rec.ensure(3 * n))
+    return NGRAVS_ERR_NOMEM;
+  double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
+  hipLaunchKernelGGL(k_keys, dim3(nb), dim3(bs), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, TREE_BITS,
+                     c->in_key.p, (unsigned int *)nullptr, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_rec.p);
+  hipLaunchKernelGGL(k_gather, dim3(nb), dim3(bs), 0, c->stream, c->s_idx.p, n, c->in_rec.p, c->s_pm.p, c->s_type.p,
+                     c->s_oldacc.p, c->s_active.p);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
 int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double corner[3], double fac, int bits,
                   long long *d_keys)
 {

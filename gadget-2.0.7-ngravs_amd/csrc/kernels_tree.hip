@@ -165,7 +165,7 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
                           const int *__restrict__ n_first, const int *__restrict__ n_count,
                           const int *__restrict__ n_child, const double4 *__restrict__ n_geo,
                           double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level,
-                          WalkParams wp)
+                          WalkParams wp, double4 *__restrict__ geo_rw = nullptr)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
@@ -179,8 +179,14 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
   sa.maxsofttype = 7;
   sa.diff = 0;
   int fl = n_flags[node];
+  // refit of a drifted tree (geo_rw != 0): the node keeps its centre but its side grows to enclose whatever its particles
+  // and (already grown) child cells now reach, the role of force_update_len() (forcetree.c:1005-1122)
+  const double4 geo0 = n_geo[node];
+  double need = 0;
   auto add_particle = [&](int p) {
     double4 v = s_pm[p];
+    if(geo_rw)
+      need = fmax(need, fmax(fabs(v.x - geo0.x), fmax(fabs(v.y - geo0.y), fabs(v.z - geo0.z))));
     int ty = s_type[p];
     int gg = wp.t2g[ty];
 #pragma unroll
@@ -222,10 +228,20 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
                 }
               int cf = n_flags[c];
               soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
+              if(geo_rw)
+                {
+                  const double4 cg = n_geo[c];
+                  need = fmax(need, fmax(fabs(cg.x - geo0.x), fmax(fabs(cg.y - geo0.y), fabs(cg.z - geo0.z))) + 0.5 * cg.w);
+                }
             }
         }
     }
-  double4 geo = n_geo[node];
+  double4 geo = geo0;
+  if(geo_rw && 2.0 * need > geo.w)
+    {
+      geo.w = 2.0 * need;
+      geo_rw[node] = geo;
+    }
 #pragma unroll
   for(int g = 0; g < NG; g++)
     {
@@ -246,6 +262,40 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
       n_mom[(long long)node * NG + g] = o;
     }
   n_flags[node] = (fl & FLAG_BUCKET) | (4 * sa.maxsofttype + 32 * sa.diff);
+}
+
+// multipole moments, softening flags (and, for a refit, grown cell sides) of all nodes, bottom-up, one launch per level
+int tree_moments(ngravs_ctx *c, bool refit)
+{
+  const int ng = c->cfg.n_gravs;
+  const int bs = 128;
+  double4 *grw = refit ? c->n_geo.p : nullptr;
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  for(int l = c->nlevels - 1; l >= 0; l--)
+    {
+      long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
+      if(lc <= 0)
+        continue;
+      unsigned nb = (unsigned)((lc + bs - 1) / bs);
+      switch(ng)
+        {
+        case 1:
+          hipLaunchKernelGGL(k_moments<1>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+          break;
+        case 2:
+          hipLaunchKernelGGL(k_moments<2>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+          break;
+        default:
+          hipLaunchKernelGGL(k_moments<3>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+          break;
+        }
+    }
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
 }
 
 int tree_build(ngravs_ctx *c)
@@ -309,30 +359,9 @@ int tree_build(ngravs_ctx *c)
   c->nlevels = level + (cnt > 0 ? 1 : 0);
   c->nnodes = node0 + cnt;
   c->level_start[c->nlevels] = c->nnodes;
-  WalkParams wp;
-  make_walk_params(c, &wp);
-  for(int l = c->nlevels - 1; l >= 0; l--)
-    {
-      long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
-      if(lc <= 0)
-        continue;
-      unsigned nb = (unsigned)((lc + bs - 1) / bs);
-      switch(ng)
-        {
-        case 1:
-          hipLaunchKernelGGL(k_moments<1>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
-          break;
-        case 2:
-          hipLaunchKernelGGL(k_moments<2>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
-          break;
-        default:
-          hipLaunchKernelGGL(k_moments<3>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp);
-          break;
-        }
-    }
+  int rcm = tree_moments(c, false);
+  if(rcm)
+    return rcm;
   HIP_TRY(c, hipGetLastError());
   c->stats.n_nodes = c->nnodes;
   return NGRAVS_OK;

@@ -2349,7 +2349,9 @@ __global__ void k_level_table(const double4 *__restrict__ geo, int node0, int cn
 static int ensure_level_table(ngravs_ctx *c, double reach)
 {
   c->lvl_table_level = 0;
-  if(!c->cfg.pmgrid || !c->cfg.periodic || (getenv("NGRAVS_WALK_ROOT") && atoi(getenv("NGRAVS_WALK_ROOT"))))
+  // a refit (drifted) tree keeps its cell centres but particles may have left their cells (the sides grow to enclose
+  // them): the regular cell grid no longer tells which nodes reach into a region, so such walks start at the root
+  if(!c->cfg.pmgrid || !c->cfg.periodic || c->tree_refit || (getenv("NGRAVS_WALK_ROOT") && atoi(getenv("NGRAVS_WALK_ROOT"))))
     return NGRAVS_OK;
   int best = 0;
   for(int l = 2; l <= 6 && l < c->nlevels; l++)

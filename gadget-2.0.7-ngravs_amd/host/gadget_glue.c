@@ -11,8 +11,11 @@
  * image lacks); gadget-2.0.7-ngravs_amd/host/host_shim_test.c exercises the same call sequence
  * against a stand-alone copy of the fields used here, and tests/test_host_glue.py runs it.
  *
- * Neutralise the tree-internal couplings of timestep.c:331-344 / predict.c:79-91 by running with
- * `TreeDomainUpdateFrequency 0.0`: every step re-decomposes and rebuilds.
+ * TreeDomainUpdateFrequency: with 0.0 every step re-decomposes and rebuilds.  With a value > 0 the
+ * reference keeps decomposition and tree while fewer than TreeDomainUpdateFrequency*TotNumPart forces have been computed
+ * (domain.c:76) and drifts/kicks the node moments instead (predict.c:79-91, timestep.c:331-344); here those steps hand the
+ * drifted positions over with ngravs_update_particles() and the library refits the nodes (ngravs_force_update_tree),
+ * so force_kick_node()/the node drift loop become no-ops (provided below).
  */
 #ifdef NGRAVS_BUILD_INSIDE_REFERENCE
 
@@ -111,7 +114,7 @@ static void ensure_ctx(void)
 
 static unsigned char *ActiveFlag;
 
-static void push_particles(void)
+static void push_particles(int keep_tree)
 {
   ngravs_particles_t p;
   int i;
@@ -130,38 +133,66 @@ static void push_particles(void)
   p.old_acc_stride = sizeof(struct particle_data);
   p.active = ActiveFlag;
   p.active_stride = 1;
-  ngravs_set_particles(Ctx, &p);
+  if(keep_tree)
+    ngravs_update_particles(Ctx, &p);
+  else
+    ngravs_set_particles(Ctx, &p);
 }
 
 /* proto.h:36 */
 void domain_Decomposition(void)
 {
   ensure_ctx();
-#ifdef PERIODIC
-  do_box_wrapping();
+#ifdef PMGRID
+  if(All.PM_Ti_endstep == All.Ti_Current)	/* domain.c:66-73: PM steps always re-decompose (particles get wrapped) */
+    All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart * All.TreeDomainUpdateFrequency;
 #endif
-  push_particles();
-  ngravs_domain_decomposition(Ctx);
-  ngravs_get_domain(Ctx, &DomainCorner[0]);	/* DomainCorner[3],DomainCenter[3],DomainLen,DomainFac are contiguous in allvars.c */
-  All.NumForcesSinceLastDomainDecomp = 0;
-  TreeReconstructFlag = 1;
+  if(All.NumForcesSinceLastDomainDecomp > All.TotNumPart * All.TreeDomainUpdateFrequency)	/* domain.c:76 */
+    {
+#ifdef PERIODIC
+      do_box_wrapping();
+#endif
+      push_particles(0);
+      ngravs_domain_decomposition(Ctx);
+      ngravs_get_domain(Ctx, &DomainCorner[0]);	/* DomainCorner[3],DomainCenter[3],DomainLen,DomainFac are contiguous in allvars.c */
+      All.NumForcesSinceLastDomainDecomp = 0;
+      TreeReconstructFlag = 1;
+    }
+  else
+    push_particles(1);		/* drifted tree: gravity_tree() refits it (ngravs_force_update_tree) */
+}
+
+/* proto.h:89, :96 -- the library recomputes node moments and cell sides from the particles (ngravs_force_update_tree);
+ * the host-side node loops of predict.c:83-86 and timestep.c:331-344 run empty because Numnodestree stays 0 and
+ * Father[] stays -1 (force_treeallocate below) */
+void force_update_len(void)
+{
+}
+void force_update_pseudoparticles(void)
+{
 }
 
 /* proto.h:78 */
 int force_treebuild(int npart)
 {
   (void)npart;
-  return (int)ngravs_force_treebuild(Ctx);
+  return (int)ngravs_force_treebuild(Ctx);	/* the node count is only reported; Numnodestree (host-side nodes) stays 0 */
 }
 
 /* proto.h:77, :86 -- the device library owns the tree memory */
 void force_treeallocate(int maxnodes, int maxpart)
 {
+  int i;
   (void)maxnodes;
-  (void)maxpart;
+  Father = malloc(sizeof(int) * (maxpart > 0 ? maxpart : 1));	/* timestep.c:333 reads Father[i]: no host-side parents */
+  for(i = 0; i < maxpart; i++)
+    Father[i] = -1;
+  Numnodestree = 0;		/* predict.c:83: no host-side nodes to drift */
 }
 void force_treefree(void)
 {
+  free(Father);
+  Father = NULL;
 }
 
 /* proto.h:114 */

@@ -163,6 +163,11 @@ int ngravs_set_walk_mode(ngravs_ctx *ctx, int walk_mode);
 /* ---- data hand-over ---------------------------------------------------------------------- */
 /* Replace the engine's particle set (the role of P[] + NumPart). */
 int ngravs_set_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
+/* Drifted tree (TreeDomainUpdateFrequency > 0: domain.c:76, predict.c:79-91): the same particles (same n, same order
+ * in the caller's arrays) with new positions / OldAcc / active flags.  Keeps the last decomposition and tree topology;
+ * the sorted columns and the nodes are refreshed by ngravs_force_update_tree(), which ngravs_gravity_tree() and
+ * ngravs_pmforce_periodic() call by themselves when needed.  NGRAVS_ERR_STATE without a built tree. */
+int ngravs_update_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
 /* Update OldAcc only (second pass of accel.c:48-52 without re-uploading positions). */
 int ngravs_set_old_acc(ngravs_ctx *ctx, const double *old_acc, int64_t stride, int on_device);
 
@@ -172,6 +177,11 @@ int ngravs_set_old_acc(ngravs_ctx *ctx, const double *old_acc, int64_t stride, i
 int ngravs_domain_decomposition(ngravs_ctx *ctx);
 /* force_treebuild(): returns the number of tree nodes (>0) or a negative status. */
 int64_t ngravs_force_treebuild(ngravs_ctx *ctx);
+/* The dynamic tree update between rebuilds (predict.c:79-91 node drift + force_update_len(), forcetree.c:1005-1122,
+ * and the node kicks of timestep.c:331-344), done as a refit: every node's per-species mass and centre of mass are
+ * recomputed bottom-up from the current particle positions (exact, where the reference extrapolates them with node
+ * velocities), softening flags likewise, and a cell's side grows to enclose what its particles now reach. */
+int ngravs_force_update_tree(ngravs_ctx *ctx);
 /* gravity_tree(): walk for all active targets, OldAcc update, xG (gravtree.c:102-341). */
 int ngravs_gravity_tree(ngravs_ctx *ctx);
 /* pmforce_periodic(): GravPM for all particles (pm_periodic.c:204-790). */

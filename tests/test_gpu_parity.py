@@ -354,3 +354,63 @@ def test_pm_persists_between_pm_steps_and_multi_shard(pkg, O):
         merged[o] = a[o]
     assert np.array_equal(merged, acc)
     eng.close()
+
+
+def test_dynamic_tree_update_refit(pkg, O):
+    """ngravs_update_particles + ngravs_force_update_tree (the drifted tree of TreeDomainUpdateFrequency > 0):
+    (a) unchanged positions: the refit tree gives bit-identical forces to the freshly built one;
+    (b) drifted positions (a fraction of the mean spacing): forces on the refit tree agree with a full re-decomposition
+        + rebuild at the level of the walk's own error, for the strict and the group walk, and the total stays as
+        accurate against the periodic direct sum;
+    (c) without a tree the call is refused (NGRAVS_ERR_STATE)."""
+    n, L, ng = 40000, 1.0, 2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=77)
+    eps = L / (40 * n ** (1 / 3))
+    kw = dict(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4")
+    rng = np.random.default_rng(3)
+    drift = 0.3 * L / n ** (1 / 3) * rng.standard_normal((n, 3))
+    # between decompositions the reference does NOT wrap particles back into the box (do_box_wrapping() runs in
+    # domain_Decomposition only): drifted positions may leave [0, L) slightly, NEAREST takes care of the images
+    pos2 = (pos + drift).astype(np.float32).astype(np.float64)
+    pos2w = np.mod(pos2, L)
+    pos2w[pos2w >= L] = 0.0
+    idx = np.arange(0, n, 100, dtype=np.int32)
+    for mode in (pkg.WALK_STRICT, pkg.WALK_GROUP):
+        eng = pkg.Engine(pkg.make_config(walk_mode=mode, **kw))
+        with pytest.raises(pkg.NgravsError):
+            eng.set_particles(pos, mass, typ)
+            eng.update_particles(pos, mass, typ)            # (c) no tree yet
+        eng.set_particles(pos, mass, typ)
+        eng.compute_accelerations(pm_step=True)
+        a0, old, c0, pm0 = eng.get_accel(want_pm=True)
+        eng.set_opening(0.0, 0.005)
+        eng.set_old_acc(old)
+        eng.gravity_tree()
+        a1, _, c1 = eng.get_accel()
+        # (a) same positions
+        eng.update_particles(pos, mass, typ, old_acc=old)
+        eng.gravity_tree()
+        a1b, _, c1b = eng.get_accel()
+        assert np.array_equal(a1, a1b) and np.array_equal(c1, c1b)
+        # (b) drifted positions on the old tree
+        nodes_before = eng.stats().n_nodes
+        eng.update_particles(pos2, mass, typ, old_acc=old)
+        eng.gravity_tree()                                          # GravPM is kept between PM steps
+        a2, _, c2, pm2 = eng.get_accel(want_pm=True)
+        assert eng.stats().n_nodes == nodes_before and np.array_equal(pm2, pm0)
+        truth = eng.direct_sum(idx)
+        eng.close()
+        ref = pkg.Engine(pkg.make_config(walk_mode=mode, **kw))
+        ref.set_particles(pos2w, mass, typ, old_acc=old)
+        ref.set_opening(0.0, 0.005)
+        ref.compute_accelerations(pm_step=True)
+        a3, _, c3, pm3 = ref.get_accel(want_pm=True)
+        ref.close()
+        d = rel_err(a2 + pm3, a3 + pm3)                             # same (fresh) long-range part on both sides
+        e_refit, e_fresh = rel_err((a2 + pm3)[idx], truth), rel_err((a3 + pm3)[idx], truth)
+        rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
+        print("mode %d: refit vs rebuild median %.1e p99 %.1e | vs periodic direct sum: refit rms %.2e, rebuild rms %.2e | ia %.0f vs %.0f"
+              % (mode, np.median(d), np.percentile(d, 99), rms(e_refit), rms(e_fresh), c2.mean(), c3.mean()))
+        assert np.median(d) < 1e-2 and np.percentile(d, 99) < 0.1    # two valid approximations (walk error ~1e-2 at this size)
+        assert rms(e_refit) < 1.3 * rms(e_fresh) + 1e-3
