@@ -294,6 +294,8 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->walk_stack.release();
   c->walk_counters.release();
   c->walk_ovf.release();
+  c->walk_tlist.release();
+  c->walk_tmp.release();
   c->lvl_table.release();
   c->r_acc.release();
   c->r_pm.release();
@@ -424,6 +426,7 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
       HIP_TRY(c, hipMemcpyAsync(c->in_type.p, h, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+  c->all_active = p->active == nullptr;
   if(p->active)
     {
       if(p->on_device)

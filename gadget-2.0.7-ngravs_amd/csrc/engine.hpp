@@ -148,6 +148,11 @@ struct ngravs_ctx
   DevBuf<double> lat;         // [ng][ng][3][65^3] Ewald / lattice-sum force corrections (periodic tree-only, periodic direct sum)
   bool lat_ready = false;
   DevBuf<int> walk_stack;     // per-wave scratch
+  DevBuf<int> walk_tlist;     // compacted active targets of the shard (individual timesteps), Peano order
+  DevBuf<unsigned char> walk_tmp;
+  long long walk_ntargets = -1;   // >= 0: the group walk runs over walk_tlist[0..walk_ntargets)
+  int walk_spread = 0;        // > 1: every group of 64 targets is walked as `spread` sub-groups by the fused kernel
+  bool all_active = true;     // the caller passed no active flags
   DevBuf<int> walk_ovf;       // split walk: groups left to the fused kernel (lists or LIFO outgrew their region)
   DevBuf<int> walk_counters;  // [1] overflow flag, [2] groups in walk_ovf, [3] of them by the LIFO, [8..15] per-XCD group counters, [16..23] 64-bit walk statistics
   DevBuf<double> r_acc, r_pm, r_oldacc;

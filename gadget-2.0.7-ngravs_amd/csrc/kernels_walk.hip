@@ -30,6 +30,7 @@
 // lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,
 // neg_newtonian, yukawa, coloyuk) and kernels are compiled per N_GRAVS and per "has Yukawa".
 #include "engine.hpp"
+#include <hipcub/hipcub.hpp>
 #include <type_traits>
 
 #define FLAG_BUCKET 64
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
     int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint,
     int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt, int lcap, int scap,
-    int *__restrict__ glist, int spread)
+    int *__restrict__ glist, int S, int G0, const int *__restrict__ tlist)
 {
   constexpr int ES = GW2_ES;   // entries per force-loop trip (independent instruction streams)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1282,11 +1283,22 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         lists[g] = stack + GW_STACK + g * GW2_ITEMS;
     }
   // MODE 0 walks all groups of the shard; the split kernels one batch of them
+  // S lanes share one target (S = 1: 64 targets per wave).  With S > 1 a wave walks G = 64/S targets -- scattered targets
+  // (sparse active sets, the outskirts) whose 64-target box would be far wider than the short-range reach -- and the S lanes
+  // of a target split the pool entries among them (entry j goes to lane j mod S), so all 64 lanes keep evaluating; their
+  // partial sums are added at the end.  S = 64 is one target per wave: the box is the target itself and every group test
+  // the reference's own per-target test.
   // glist: MODE 1 appends the groups whose lists or LIFO outgrew their region (counter[2] = how many, counter[3] = how many
-  // of them by the LIFO); MODE 0 with a glist walks exactly those groups, each spread over `spread` waves that take
-  // 64/spread of its targets (these are widely scattered targets: a smaller sub-group has a far smaller box, down to one
-  // target per wave, where the conservative group tests become the reference's own per-target tests)
-  const long long ngroups = (MODE == 0 && !glist) ? (t_count + WAVE - 1) / WAVE : (MODE == 0 ? g_cnt * spread : g_cnt);
+  // of them by the LIFO); MODE 0 with a glist walks exactly those groups (of G0 targets each) again in sub-groups of G.
+  const int G = WAVE / S;
+  const long long ngroups = (MODE == 0 && !glist) ? (t_count + G - 1) / G : (MODE == 0 ? g_cnt * (G0 / G) : g_cnt);
+  unsigned long long lane_pat = ~0ull;   // the pool entries this lane evaluates
+  if(S > 1)
+    {
+      lane_pat = 0;
+      for(int j = lane & (S - 1); j < WAVE; j += S)
+        lane_pat |= 1ull << j;
+    }
   const long long gbase = MODE == 0 ? 0 : g_first;
   const double BIG = 1e300;
 
@@ -1334,12 +1346,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         }
       if(grp < 0)
         break;
-      bool mine = true;
+      long long tk_base = -1;
       if(MODE == 0 && glist)
         {
-          const int sub = (int)(grp % spread), per = WAVE / spread;
-          grp = glist[grp / spread];
-          mine = lane >= sub * per && lane < (sub + 1) * per;
+          const int R = G0 / G;
+          const long long w = grp;
+          grp = glist[w / R];
+          tk_base = grp * G0 + (w % R) * G;
         }
       if(MODE != 0)
         {
@@ -1350,8 +1363,12 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           stack = base + (size_t)NG * lcap;
         }
       grp += gbase;
-      const long long ti = t_first + grp * WAVE + lane;
-      const bool valid = mine && (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
+      // targets: the shard's Peano-ordered particles, or (individual timesteps: few active particles) the compacted list of
+      // its active ones, so that a wave works for 64 active targets instead of the few a 64-particle stretch contains
+      const long long tk = (tk_base >= 0 ? tk_base : grp * G) + lane / S;
+      const bool in_range = tk < t_count;
+      const long long ti = tlist ? (in_range ? (long long)tlist[tk] : 0ll) : t_first + tk;
+      const bool valid = in_range && (tlist != nullptr || (s_active[ti] & 1) != 0);
       if(!__any(valid ? 1 : 0))
         {
           if(MODE == 1 && lane < NG)
@@ -1777,7 +1794,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       }
                   }
                 // ---- force loop: every lane walks its own bits, ES per trip
-                unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+                unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & lane_pat;
                 nint += __popcll(m);   // eval4 takes the (rare) slots beyond the exact cut off again
                 if(wp.dbg & 4)         // debug: masks are built but not evaluated
                   m = 0;
@@ -2125,7 +2142,17 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             }
           continue;
         }
-      if(MODE != 1 && valid)
+      if(MODE != 1 && S > 1)
+        {
+          for(int off = 1; off < S; off <<= 1)   // the S lanes of a target hold partial sums
+            {
+              ax += __shfl_xor(ax, off);
+              ay += __shfl_xor(ay, off);
+              az += __shfl_xor(az, off);
+              nint += __shfl_xor(nint, off);
+            }
+        }
+      if(MODE != 1 && valid && (lane & (S - 1)) == 0)
         {
           r_acc[3 * ti + 0] = ax;
           r_acc[3 * ti + 1] = ay;
@@ -2454,9 +2481,52 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   return NGRAVS_OK;
 }
 
+// targets of the group walk: all particles of the shard, or the compacted active ones (walk_select_targets)
+static inline long long walk_tcount(const ngravs_ctx *c) { return c->walk_ntargets >= 0 ? c->walk_ntargets : c->shard_count; }
+static inline const int *walk_tlist(const ngravs_ctx *c) { return c->walk_ntargets >= 0 ? c->walk_tlist.p : nullptr; }
+
+struct ActiveFlag
+{
+  __host__ __device__ __forceinline__ bool operator()(const unsigned char &a) const { return (a & 1) != 0; }
+};
+
+// individual timesteps (gravtree.c:113: only particles with Ti_endstep == Ti_Current are walked): when the caller marked
+// less than 3/4 of the shard active, the active indices are compacted (Peano order is kept) and the walk groups those
+static int walk_select_targets(ngravs_ctx *c)
+{
+  c->walk_ntargets = -1;
+  if(c->all_active || c->shard_count <= 0 || (getenv("NGRAVS_WALK_COMPACT") && !atoi(getenv("NGRAVS_WALK_COMPACT"))))
+    return NGRAVS_OK;
+  const int n = (int)c->shard_count;
+  if(c->walk_tlist.ensure((size_t)n) || c->walk_counters.ensure(32))
+    return NGRAVS_ERR_NOMEM;
+  hipcub::CountingInputIterator<int> idx((int)c->shard_first);
+  hipcub::TransformInputIterator<bool, ActiveFlag, const unsigned char *> flags(c->s_active.p + c->shard_first, ActiveFlag());
+  size_t bytes = 0;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(nullptr, bytes, idx, flags, c->walk_tlist.p, c->walk_counters.p + 24, n, c->stream));
+  if(c->walk_tmp.ensure(bytes))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipcub::DeviceSelect::Flagged(c->walk_tmp.p, bytes, idx, flags, c->walk_tlist.p, c->walk_counters.p + 24, n, c->stream));
+  int cnt = 0;
+  HIP_TRY(c, hipMemcpyAsync(&cnt, c->walk_counters.p + 24, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if(4ll * cnt < 3ll * n)
+    c->walk_ntargets = cnt;
+  return NGRAVS_OK;
+}
+
 template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
 static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nullptr, int nlist = 0)
 {
+  // lanes per target: the walk's own S, or for the leftover pass (glist) enough to give the few scattered groups many waves
+  const int S0 = c->walk_spread > 1 ? c->walk_spread : 1, G0 = WAVE / S0;
+  int S = S0;
+  if(glist)
+    {
+      const int want = nlist <= 4096 ? 64 : (nlist <= 65536 ? 8 : 1);
+      S = want > S0 ? want : S0;
+    }
+  const int G = WAVE / S;
   int ncu = 256;
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -2470,8 +2540,7 @@ static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nul
   if(waves < 1)
     waves = 1;
   size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
-  const int spread = !glist ? 1 : (nlist <= 4096 ? 64 : (nlist <= 65536 ? 8 : 1));
-  long long ngroups = glist ? (long long)nlist * spread : (c->shard_count + WAVE - 1) / WAVE;
+  long long ngroups = glist ? (long long)nlist * (G0 / G) : (walk_tcount(c) + G - 1) / G;
   long long nblk = (long long)ncu * per_cu;
   if(nblk > (ngroups + waves - 1) / waves)
     nblk = (ngroups + waves - 1) / waves;
@@ -2487,8 +2556,8 @@ static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nul
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
-                     (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
-                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, glist ? (long long)nlist : 0ll, 0, 0, glist, spread);
+                     walk_tcount(c), c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
+                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, glist ? (long long)nlist : 0ll, 0, 0, glist, S, G0, walk_tlist(c));
   return NGRAVS_OK;
 }
 
@@ -2509,7 +2578,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   if(waves < 1)
     waves = 1;
   const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
-  const long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
+  const int S = c->walk_spread > 1 ? c->walk_spread : 1, G = WAVE / S;
+  const long long ngroups = (walk_tcount(c) + G - 1) / G;
   // per-group region: NG item lists of lcap ints + the LIFO.  lcap starts small and is doubled (persistently) by walk_run
   // when a list overflows; the batch shrinks so that the scratch stays within ~8 GB
   if(c->walk_lcap < 1024)
@@ -2555,8 +2625,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
       const long long tblk = 8 * (((nb + GW3_TBLOCK / 64 - 1) / (GW3_TBLOCK / 64) + 7) / 8);
       hipLaunchKernelGGL(kt, dim3((unsigned)tblk), dim3(GW3_TBLOCK), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
-                         (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, 1);
+                         walk_tcount(c), c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
+                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c));
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 1], c->stream));
       if(g0 > 0)
         HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
@@ -2565,8 +2635,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
         nblk = (nb + waves - 1) / waves;
       hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
-                         (long long)c->shard_count, c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, 1);
+                         walk_tcount(c), c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
+                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c));
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 2], c->stream));
     }
   return NGRAVS_OK;
@@ -2625,10 +2695,14 @@ int walk_run(ngravs_ctx *c)
   make_walk_params(c, &wp);
   LawIds li;
   make_law_ids(c, &li);
+  c->walk_ntargets = -1;
   if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
     {
       int rct = ensure_level_table(c, sqrt(wp.reach2));
       if(rct)
+        return rct;
+      const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;
+      if(!v1 && (rct = walk_select_targets(c)))
         return rct;
     }
   HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
@@ -2673,7 +2747,29 @@ int walk_run(ngravs_ctx *c)
   if(c->cfg.walk_mode == NGRAVS_WALK_STRICT)
     strict_launch();
   else
-    rc = group_launch(true, nullptr, 0);
+    {
+      // sparse active sets: 64 compacted targets span a box much wider than the short-range reach, so the conservative
+      // group tests would collect (and then mostly discard) huge lists; walk them in sub-groups of 64/S targets, S lanes
+      // per target (k_walk_group2).
+      c->walk_spread = 0;
+      if(c->walk_ntargets >= 0 && pm && c->cfg.box_size > 0)
+        {
+          const double vol_per_target = pow(c->cfg.box_size, 3) * (double)c->shard_count / ((double)c->n * (double)(c->walk_ntargets > 0 ? c->walk_ntargets : 1));
+          // measured (16 M particles, 10 % / 1 % / 0.1 % active): S = 1 wins while 64 targets span less than ~2.5 reaches,
+          // beyond that one target per wave does (intermediate S multiply the traversals without shrinking the lists enough)
+          const int sp = cbrt(vol_per_target * 64.0) > 2.5 * sqrt(wp.reach2) ? 64 : 1;
+          c->walk_spread = sp;
+          if(getenv("NGRAVS_WALK_SPREAD"))   // test / tuning knob: 1, 2, 4 ... 64 lanes per target
+            {
+              const int e = atoi(getenv("NGRAVS_WALK_SPREAD"));
+              if(e >= 1 && e <= 64 && (e & (e - 1)) == 0)
+                c->walk_spread = e;
+            }
+          if(c->walk_spread <= 1)
+            c->walk_spread = 0;
+        }
+      rc = group_launch(true, nullptr, 0);
+    }
   if(rc != NGRAVS_OK)
     return rc;
   HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
@@ -2704,7 +2800,8 @@ int walk_run(ngravs_ctx *c)
               HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
               HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
               HIP_TRY(c, hipStreamSynchronize(c->stream));
-              const long long ng = (c->shard_count + WAVE - 1) / WAVE;
+              const int Gs = WAVE / (c->walk_spread > 1 ? c->walk_spread : 1);
+              const long long ng = (walk_tcount(c) + Gs - 1) / Gs;
               if((long long)ovf[0] * 256 > ng)
                 {
                   if(2 * ovf[1] > ovf[0])
@@ -2714,7 +2811,8 @@ int walk_run(ngravs_ctx *c)
                 }
             }
         }
-      double ngroups = (double)((c->shard_count + WAVE - 1) / WAVE);
+      const int Gn = WAVE / (c->walk_spread > 1 ? c->walk_spread : 1);
+      double ngroups = (double)((walk_tcount(c) + Gn - 1) / Gn);
       c->stats.reserved[0] = st64[0] / ngroups;   // pool entries per group
       c->stats.reserved[1] = st64[1] / ngroups;   // nodes tested per group
       c->stats.reserved[2] = st64[2] / ngroups;   // traversal batches per group

@@ -230,6 +230,53 @@ def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
     eng.close()
 
 
+def test_group_walk_sparse_active_set_vs_ewald(pkg, O):
+    """individual timesteps: only ~3 % of the particles are active (gravtree.c:113).  The group walk compacts the active
+    targets of the Peano order into groups of 64 (boxes ~3x wider than a 64-particle stretch); accuracy against the Ewald
+    golden stays in the reference band, inactive particles are not written, Nf is the active count, and the result agrees
+    with the uncompacted walk (NGRAVS_WALK_COMPACT=0) at the level of the walk error."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    from make_ewald_golden import N, L, SEED, case_config
+    wiring, ng = "c4", 2
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ewald_truth_%s.npz" % wiring))
+    pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=ng, seed=SEED)
+    idx, truth = gold["idx"], gold["truth"]
+    active = (np.random.default_rng(1).uniform(size=N) < 0.02).astype(np.uint8)
+    active[idx] = 1
+    cfg, eps = case_config(pkg, wiring, ng, walk_mode=pkg.WALK_GROUP, group_reach=0.0)
+    rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
+    res = {}
+    for compact in ("1", "0", "S8", "S64"):      # S8 / S64: compacted, 8 / 64 lanes per target (sub-groups of 8 / 1 targets)
+        os.environ["NGRAVS_WALK_COMPACT"] = "0" if compact == "0" else "1"
+        if compact.startswith("S"):
+            os.environ["NGRAVS_WALK_SPREAD"] = compact[1:]
+        try:
+            eng = _engine(pkg, cfg, pos, mass, typ, old_acc=gold["old_acc"], active=active)
+            eng.set_opening(0.0, 0.005)
+            eng.compute_accelerations(pm_step=True)
+            acc, _, cost, gpm = eng.get_accel(want_pm=True)
+            st = eng.stats()
+            eng.close()
+        finally:
+            del os.environ["NGRAVS_WALK_COMPACT"]
+            os.environ.pop("NGRAVS_WALK_SPREAD", None)
+        assert st.n_active == int(active.sum())
+        assert np.all(acc[active == 0] == 0) and np.all(cost[active == 0] == 0)
+        res[compact] = (acc, cost, rms(rel_err((acc + gpm)[idx], truth)))
+    e_ref = rms(rel_err(gold["ref_total"], truth))
+    d = rel_err(res["1"][0][active == 1], res["0"][0][active == 1])
+    print("sparse active set (%d of %d): compacted rms %.2e (ia %.0f), uncompacted rms %.2e (ia %.0f), reference walk %.2e; "
+          "compacted vs uncompacted median %.1e" % (active.sum(), N, res["1"][2], res["1"][1][active == 1].mean(), res["0"][2],
+                                                   res["0"][1][active == 1].mean(), e_ref, np.median(d)))
+    print("  lanes per target 8: rms %.2e (ia %.0f); 64: rms %.2e (ia %.0f)" %
+          (res["S8"][2], res["S8"][1][active == 1].mean(), res["S64"][2], res["S64"][1][active == 1].mean()))
+    for k in res:
+        assert res[k][2] <= e_ref * 1.05, k
+    assert np.median(d) < 5e-3
+
+
 def test_group_walk_three_species(pkg, O):
     """N_GRAVS=3 (the C5 wiring: Newton diagonal, Newton+Yukawa off-diagonal; short-range tables read through L1/L2
     instead of LDS): the group walk stays within the reference walk's own error band of the strict result"""
