@@ -535,12 +535,8 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 // =============================================================================================
 //  group walk
 // =============================================================================================
-#define GW_MAXWAVES 12      // waves per persistent workgroup: as many as fit beside the LDS tables (launch_group_t)
-#define GW_POOL 128         // interaction pool per wave: entries shared by the 8 sub-group lists (flushed when < 64 free)
-#define GW_SUBS 8           // sub-groups of 8 consecutive targets, each with its own (index) list into the pool
-#define GW_STACK 8192       // pending-node LIFO per wave (global scratch)
-#define GW_PQ 640           // pending item queue per wave (LDS): < 64 carried over + 64 nodes x NLEAF items
-#define GW_WAVE_LDS(NG) ((sizeof(double4) + sizeof(double)) * GW_POOL + sizeof(double) * GW_SUBS * 6 + sizeof(int) * GW_PQ + (size_t)(NG) * GW_SUBS * GW_POOL)
+#define GW_MAXWAVES 12      // fused kernel: waves per persistent workgroup (3 per SIMD at 168 VGPRs)
+#define GW_STACK 8192       // fused kernel: pending-node LIFO per wave (global scratch)
 // one pool per wave (the species are evaluated one after the other): 128 x (double4 pos/mass, double h, 3 floats = position
 // relative to the group's box centre for the packed-fp32 reach pre-test)
 #define GW2_WAVE_LDS ((sizeof(double4) + sizeof(double) + 3 * sizeof(float)) * 128)
@@ -596,611 +592,17 @@ __device__ __forceinline__ double wave_max(double v)
   return v;
 }
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
-__global__ __launch_bounds__(GW_MAXWAVES * 64) void k_walk_group(
-    TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
-    const double *__restrict__ s_oldacc, const unsigned char *__restrict__ s_active,
-    const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
-    int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint)
-{
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // LDS: [table NG*NG*NTAB doubles (if TAB_LDS)] [lists: per wave NG*CAP double4 | NG*CAP double] [exp table 32]
-  //      [item queue: per wave GW_PQ ints]
-  double *tab_s = reinterpret_cast<double *>(smem);
-  // symmetric wiring (Newton's third law, checked by ngravs_create): NG(NG+1)/2 distinct tables are staged
-  constexpr int NTABS = NG * (NG + 1) / 2;
-  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  // per wave: pool (positions+mass, source softening), sub-group bounding boxes, index lists, item queue
-  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW_WAVE_LDS(NG);
-  double *expT = reinterpret_cast<double *>(smem + tab_bytes);
-  double4 *lpos = reinterpret_cast<double4 *>(wbase);
-  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * GW_POOL);
-  double *sbb = lh + GW_POOL;                                        // [GW_SUBS][6]: centre xyz, half-width xyz
-  int *pq = reinterpret_cast<int *>(sbb + GW_SUBS * 6);
-  unsigned char *sl = reinterpret_cast<unsigned char *>(pq + GW_PQ);   // [NG][GW_SUBS][GW_POOL] pool indices
-  if(threadIdx.x < 32)
-    expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
-  if(PM && TAB_LDS)
-    for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
-      {
-        // unique pair index u -> (a <= b):  u = a*NG - a(a-1)/2 + (b-a)
-        int u = t / NTAB, a = 0;
-        while(u >= NG - a)
-          {
-            u -= NG - a;
-            a++;
-          }
-        tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
-      }
-  __syncthreads();
-  const double *tabp = (PM && TAB_LDS) ? tab_s : table;
-  int *stack = stack_base + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * GW_STACK;
-  const long long ngroups = (t_count + WAVE - 1) / WAVE;
-  const double BIG = 1e300;
-
-  // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
-  // workgroup pulls groups from the segment of the XCD it runs on (neighbouring groups share most of their
-  // tree nodes and sources); an exhausted segment steals from the others.  Placement only affects speed.
-  unsigned xcc = 0;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  xcc &= 7u;
-  const long long seg = (ngroups + 7) / 8;
-  int steal = 0;
-  for(;;)
-    {
-      long long grp = -1;
-      while(steal < 8)
-        {
-          const int sx = (int)((xcc + steal) & 7u);
-          int k = 0;
-          if(lane == 0)
-            k = atomicAdd(&counter[8 + sx], 1);
-          k = __builtin_amdgcn_readfirstlane(k);
-          const long long g0 = seg * sx + k;
-          if(k < seg && g0 < ngroups)
-            {
-              grp = g0;
-              break;
-            }
-          steal++;
-        }
-      if(grp < 0)
-        break;
-      const long long ti = t_first + grp * WAVE + lane;
-      const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti] & 1) != 0;
-      if(!__any(valid ? 1 : 0))
-        continue;
-      double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
-      int tg = 0;
-      if(valid)
-        {
-          double4 p = s_pm[ti];
-          px = p.x;
-          py = p.y;
-          pz = p.z;
-          int ptype = s_type[ti];
-          tg = wp.t2g[ptype];
-          hT = wp.fsoft[ptype];
-          aold = wp.errtol_acc * s_oldacc[ti];
-        }
-      // per-lane law coefficients against each source species
-      double cN[NG], cY[NG], cS[NG];
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-        {
-          cN[g] = wp.cN[tg][g];
-          cY[g] = wp.cY[tg][g];
-          cS[g] = wp.cS[tg][g];
-        }
-      // this lane's table rows, one per source species
-      const double *tabrow[NG];
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-        {
-          if(PM && TAB_LDS)
-            {
-              const int a = tg < g ? tg : g, b = tg < g ? g : tg;
-              tabrow[g] = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
-            }
-          else
-            tabrow[g] = tabp + ((size_t)tg * NG + g) * NTAB;
-        }
-      // group bounding box and the conservative scalars
-      double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
-      double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
-      double loz = wave_min(valid ? pz : BIG), hiz = wave_max(valid ? pz : -BIG);
-      const double bcx = 0.5 * (lox + hix), bcy = 0.5 * (loy + hiy), bcz = 0.5 * (loz + hiz);
-      const double bhx = 0.5 * (hix - lox), bhy = 0.5 * (hiy - loy), bhz = 0.5 * (hiz - loz);
-      const double aold_min = wave_min(valid ? aold : BIG);
-      const double hT_min = wave_min(valid ? hT : BIG);
-      // may sources be wrapped once per group (relative to the box centre) instead of per pair?
-      const double bhmax = fmax(bhx, fmax(bhy, bhz));
-      const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
-                           (wp.boxhalf - bhmax) > 0;
-      const bool lanewrap = wp.periodic && !prewrap;
-
-      double ax = 0, ay = 0, az = 0;
-      int nint = 0;
-      int cnt[NG][GW_SUBS];   // wave-uniform lengths of the sub-group lists
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-#pragma unroll
-        for(int u = 0; u < GW_SUBS; u++)
-          cnt[g][u] = 0;
-      int npool = 0;
-      const int mysub = lane >> 3;
-      // bounding boxes of the 8 sub-groups (8 consecutive Peano targets each): what each list is culled against
-      {
-        double slx = valid ? px : BIG, shx = valid ? px : -BIG, sly = valid ? py : BIG, shy = valid ? py : -BIG,
-               slz = valid ? pz : BIG, shz = valid ? pz : -BIG;
-        for(int off = 4; off > 0; off >>= 1)
-          {
-            slx = fmin(slx, __shfl_xor(slx, off));
-            shx = fmax(shx, __shfl_xor(shx, off));
-            sly = fmin(sly, __shfl_xor(sly, off));
-            shy = fmax(shy, __shfl_xor(shy, off));
-            slz = fmin(slz, __shfl_xor(slz, off));
-            shz = fmax(shz, __shfl_xor(shz, off));
-          }
-        if((lane & 7) == 0)
-          {
-            const bool any = shx >= slx;                               // sub-group with no active target: unreachable box
-            sbb[mysub * 6 + 0] = any ? 0.5 * (slx + shx) : bcx;
-            sbb[mysub * 6 + 1] = any ? 0.5 * (sly + shy) : bcy;
-            sbb[mysub * 6 + 2] = any ? 0.5 * (slz + shz) : bcz;
-            sbb[mysub * 6 + 3] = any ? 0.5 * (shx - slx) : -BIG;
-            sbb[mysub * 6 + 4] = any ? 0.5 * (shy - sly) : -BIG;
-            sbb[mysub * 6 + 5] = any ? 0.5 * (shz - slz) : -BIG;
-          }
-      }
-      int st_entries = 0, st_nodes = 0, st_batches = 0, st_iters = 0;   // walk statistics (per group, wave-uniform)
-
-      // FOUR list entries against this lane's target, written as four independent straight-line streams
-      // (no branch on the common path) so that the scheduler overlaps their v_rsq / LDS-table latencies:
-      // only 2 waves per SIMD fit beside the LDS tables, the ILP has to come from here.
-      auto eval4 = [&](auto lw_tag, const int g, const double4 (&e)[4], const double (&hs)[4], const bool (&act)[4]) {
-        constexpr bool LW = decltype(lw_tag)::value;
-        double dx[4], dy[4], dz[4], r2[4], rinv[4], r[4], fac[4];
-        bool in[4];
-        bool anyin = false;
-#pragma unroll
-        for(int k = 0; k < 4; k++)
-          {
-            dx[k] = e[k].x - px;
-            dy[k] = e[k].y - py;
-            dz[k] = e[k].z - pz;
-            if(LW)
-              {
-                dx[k] = nearest(dx[k], wp.box, wp.boxhalf);
-                dy[k] = nearest(dy[k], wp.box, wp.boxhalf);
-                dz[k] = nearest(dz[k], wp.box, wp.boxhalf);
-              }
-            r2[k] = dx[k] * dx[k] + dy[k] * dy[k] + dz[k] * dz[k];
-            in[k] = act[k] && (PM ? (r2[k] < wp.reach2) : true);
-            anyin |= in[k];
-          }
-        if(!__any(anyin ? 1 : 0))
-          return;                                                       // none of the four reaches any target
-        bool anysoft = false;
-        bool soft[4];
-        double h[4];
-#pragma unroll
-        for(int k = 0; k < 4; k++)
-          {
-            // self / coincident pairs stay finite (d = 0 kills them); masked lanes are clamped at the table index
-            const double q2 = r2[k] + 1e-290;
-            double ri = __builtin_amdgcn_rsq(q2);
-            ri = ri * (1.5 - 0.5 * q2 * ri * ri);                         // one Newton step: ~2^-51
-            const double rr = q2 * ri;                                    // sqrt(r2) to ~2^-51
-            rinv[k] = ri;
-            r[k] = rr;
-            const double ri2 = ri * ri;
-            double f = cN[g] * ri2;
-            if(YUK)
-              f += cY[g] * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
-            if(PM)
-              {
-                int tab = (int)(wp.asmthfac * (in[k] ? rr : 0.0));
-                tab = tab < NTAB - 1 ? tab : NTAB - 1;                    // r < cut <= 6 asmth: only rounding can hit NTAB
-                f -= wp.utor2wpi * tabrow[g][tab];
-              }
-            fac[k] = f * e[k].w * ri;
-            h[k] = hT > hs[k] ? hT : hs[k];
-            soft[k] = in[k] && rr < h[k];
-            anysoft |= soft[k];
-          }
-        if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
-          {
-#pragma unroll
-            for(int k = 0; k < 4; k++)
-              {
-                double h_inv = 1 / h[k], u = r[k] * h_inv;
-                double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
-                                     : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
-                                        0.066666666667 / (u * u * u));
-                double fs = cS[g] * e[k].w * h_inv * h_inv * h_inv * v;
-                fac[k] = soft[k] ? fs : fac[k];
-              }
-          }
-#pragma unroll
-        for(int k = 0; k < 4; k++)
-          {
-            const double f = in[k] ? fac[k] : 0.0;
-            ax = __builtin_fma(dx[k], f, ax);
-            ay = __builtin_fma(dy[k], f, ay);
-            az = __builtin_fma(dz[k], f, az);
-            nint += in[k] ? 1 : 0;
-            if(LATT)
-              {
-                // periodic tree-only: every source also contributes its infinite lattice of images (forcetree.c:1605-1607);
-                // here on the SAME (finer) interaction list as the nearest-image force
-                double fx, fy, fz;
-                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, dx[k], dy[k], dz[k], fx, fy, fz);
-                const double mk = in[k] ? e[k].w : 0.0;
-                ax = __builtin_fma(mk, fx, ax);
-                ay = __builtin_fma(mk, fy, ay);
-                az = __builtin_fma(mk, fz, az);
-              }
-          }
-      };
-
-      // ---- state machine: ONE flush site, ONE materialise site, ONE node-test site -------------------
-      //   items (LDS queue): p >= 0 particle p;  -1-(node*NG+g) monopole of species g of a node
-      int qn = 0, sp = 1;
-      if(lane == 0)
-        stack[0] = 0;
-      wave_sync();
-      bool overflow = false, done = false;
-      while(!done)
-        {
-          const bool want_mat = (qn >= WAVE) || (sp == 0 && qn > 0);
-          const bool finished = (sp == 0 && qn == 0);
-          const bool full = npool + WAVE > GW_POOL;
-          if(finished || (want_mat && full))
-            {
-              // ---------------- flush: every sub-group streams ITS list through the force law ----------------
-              wave_sync();
-              st_entries += npool;
-#pragma unroll
-              for(int g = 0; g < NG; g++)
-                {
-                  int mycnt = 0, n = 0;
-#pragma unroll
-                  for(int u = 0; u < GW_SUBS; u++)
-                    {
-                      mycnt = (mysub == u) ? cnt[g][u] : mycnt;
-                      n = cnt[g][u] > n ? cnt[g][u] : n;
-                    }
-                  if(wp.dbg & 1)
-                    n = 0;
-                  st_iters += n;
-                  if(wp.dbg & 2)
-                    {
-                      int tot = 0;
-#pragma unroll
-                      for(int u = 0; u < GW_SUBS; u++)
-                        tot += cnt[g][u];
-                      st_batches += tot;   // debug: overloads the batches statistic with the sum of sub-list lengths
-                    }
-                  const unsigned char *myl = sl + ((size_t)g * GW_SUBS + mysub) * GW_POOL;
-                  // four entries per trip: one 32-bit read brings four pool indices, the four entries are
-                  // fetched together, then evaluated -- the LDS latency of trip j+1 hides under trip j's math
-                  const unsigned int *myl4 = reinterpret_cast<const unsigned int *>(myl);
-                  for(int j = 0; j < n; j += 4)
-                    {
-                      const unsigned int w = (j < mycnt) ? myl4[j >> 2] : 0u;
-                      const bool act[4] = {j < mycnt, j + 1 < mycnt, j + 2 < mycnt, j + 3 < mycnt};
-                      const int i0 = act[0] ? (int)(w & 255u) : 0, i1 = act[1] ? (int)((w >> 8) & 255u) : 0,
-                                i2 = act[2] ? (int)((w >> 16) & 255u) : 0, i3 = act[3] ? (int)(w >> 24) : 0;
-                      const double4 e[4] = {lpos[i0], lpos[i1], lpos[i2], lpos[i3]};
-                      const double hh[4] = {lh[i0], lh[i1], lh[i2], lh[i3]};
-                      if(lanewrap)
-                        eval4(std::true_type{}, g, e, hh, act);
-                      else
-                        eval4(std::false_type{}, g, e, hh, act);
-                    }
-#pragma unroll
-                  for(int u = 0; u < GW_SUBS; u++)
-                    cnt[g][u] = 0;
-                }
-              npool = 0;
-              wave_sync();
-              if(finished)
-                done = true;
-              continue;
-            }
-          if(want_mat)
-            {
-              // ---------------- materialise up to 64 queued items into the pool + sub-group lists ----------------
-              wave_sync();
-              const int take = qn < WAVE ? qn : WAVE;
-              const bool have = lane < take;
-              const int item = have ? pq[qn - take + lane] : 0;
-              qn -= take;
-              double4 q;
-              q.x = q.y = q.z = q.w = 0;
-              int sg = 0;
-              double hs = 0;
-              if(have)
-                {
-                  if(item >= 0)
-                    {
-                      q = s_pm[item];
-                      int qt = s_type[item];
-                      sg = wp.t2g[qt];
-                      hs = wp.fsoft[qt];
-                    }
-                  else
-                    {
-                      int k = -1 - item;
-                      q = tv.mom[k];
-                      int nd = k / NG;
-                      sg = k - nd * NG;
-                      hs = wp.fsoft[(tv.flags[nd] >> 2) & 7];
-                    }
-                }
-              const bool live = have && q.w != 0.0;
-              double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
-              if(wp.periodic)
-                {
-                  ex = nearest(ex, wp.box, wp.boxhalf);
-                  ey = nearest(ey, wp.box, wp.boxhalf);
-                  ez = nearest(ez, wp.box, wp.boxhalf);
-                }
-              // which sub-groups can this source reach?  (tree-only: all of them)
-              unsigned hits = 0;
-#pragma unroll
-              for(int u = 0; u < GW_SUBS; u++)
-                {
-                  bool hit = live;
-                  if(PM)
-                    {
-                      // offset from the sub-box centre = offset from the group centre - (sub centre - group centre)
-                      double b0 = fmax(0.0, fabs(ex - (sbb[u * 6 + 0] - bcx)) - sbb[u * 6 + 3]);
-                      double b1 = fmax(0.0, fabs(ey - (sbb[u * 6 + 1] - bcy)) - sbb[u * 6 + 4]);
-                      double b2 = fmax(0.0, fabs(ez - (sbb[u * 6 + 2] - bcz)) - sbb[u * 6 + 5]);
-                      hit = hit && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
-                    }
-                  hits |= hit ? (1u << u) : 0u;
-                }
-              const bool pred = hits != 0;
-              const unsigned long long amask = __ballot(pred ? 1 : 0);
-              const int slot = npool + lane_prefix(amask);
-              if(pred)
-                {
-                  if(prewrap)
-                    {
-                      q.x = bcx + ex;
-                      q.y = bcy + ey;
-                      q.z = bcz + ez;
-                    }
-                  lpos[slot] = q;
-                  lh[slot] = hs;
-                }
-              npool += __popcll(amask);
-#pragma unroll
-              for(int g = 0; g < NG; g++)
-#pragma unroll
-                for(int u = 0; u < GW_SUBS; u++)
-                  {
-                    const bool pg = ((hits >> u) & 1u) && sg == g;
-                    const unsigned long long mask = __ballot(pg ? 1 : 0);
-                    if(pg)
-                      sl[((size_t)g * GW_SUBS + u) * GW_POOL + cnt[g][u] + lane_prefix(mask)] = (unsigned char)slot;
-                    cnt[g][u] += __popcll(mask);
-                  }
-              wave_sync();
-              continue;
-            }
-          // ---------------- test up to 64 pending nodes against the group's bounding box ----------------
-          const int nb = sp < WAVE ? sp : WAVE;
-          sp -= nb;
-          st_nodes += nb;
-          st_batches++;
-          const int my = lane < nb ? stack[sp + lane] : -1;
-          wave_sync();
-          // decision: 0 drop, 1 accept (monopoles), 2 open (children), 3 open as a leaf (all particles of the range)
-          int dec = 0;
-          int first = 0, count = 0;
-          unsigned massmask = 0;
-          int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
-          if(my >= 0)
-            {
-              const double4 geo = tv.geo[my];
-              const int fl = tv.flags[my];
-              // fetched with the record, not after the decision: one dependent memory round trip less per batch
-              first = tv.first[my];
-              count = tv.count[my];
-              {
-                const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
-                ch_lo = cp[0];
-                ch_hi = cp[1];
-              }
-              const double len = geo.w;
-              double r2min = BIG, summass = 0;
-#pragma unroll
-              for(int g = 0; g < NG; g++)
-                {
-                  const double4 mom = tv.mom[(long long)my * NG + g];
-                  summass += mom.w;
-                  massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
-                  double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
-                  if(wp.periodic)
-                    {
-                      dx = nearest(dx, wp.box, wp.boxhalf);
-                      dy = nearest(dy, wp.box, wp.boxhalf);
-                      dz = nearest(dz, wp.box, wp.boxhalf);
-                    }
-                  double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
-                  double r2g = a0 * a0 + a1 * a1 + a2 * a2;
-                  r2min = r2g < r2min ? r2g : r2min;
-                }
-              double cx = geo.x - bcx, cy = geo.y - bcy, cz = geo.z - bcz;   // plain (inside-cell test has no NEAREST)
-              double wx = cx, wy = cy, wz = cz;
-              if(wp.periodic)
-                {
-                  wx = nearest(cx, wp.box, wp.boxhalf);
-                  wy = nearest(cy, wp.box, wp.boxhalf);
-                  wz = nearest(cz, wp.box, wp.boxhalf);
-                }
-              const int mst = (fl >> 2) & 7;
-              bool drop = (mst == 7);   // empty
-              if(PM && !drop)
-                {
-                  // (i) nothing inside the cell can be within the cut of any target
-                  double half = 0.5 * len;
-                  double q0 = fmax(0.0, fabs(wx) - bhx - half), q1 = fmax(0.0, fabs(wy) - bhy - half),
-                         q2 = fmax(0.0, fabs(wz) - bhz - half);
-                  if(q0 * q0 + q1 * q1 + q2 * q2 >= wp.reach2)
-                    drop = true;
-                  // (ii) the reference's own cut (forcetree.c:1828-1862) holds for every target
-                  if(!drop && r2min > wp.rcut2)
-                    {
-                      double eff = wp.rcut + half;
-                      if(fabs(wx) - bhx > eff || fabs(wy) - bhy > eff || fabs(wz) - bhz > eff)
-                        drop = true;
-                    }
-                }
-              if(!drop)
-                {
-                  bool open;
-                  if(wp.use_theta)
-                    open = len * len > r2min * wp.theta2;
-                  else
-                    {
-                      open = summass * len * len > r2min * r2min * aold_min;
-                      if(!open)
-                        open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
-                               (fabs(cz) - bhz < 0.60 * len);
-                    }
-                  const double hs_node = wp.fsoft[mst];
-                  if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
-                    open = true;
-                  if(open)
-                    dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
-                  else
-                    dec = 1;
-                }
-            }
-          // every tested node queues at most 8 items, and qn < 64 here: qn + 8*64 <= GW_PQ always holds
-          // accepted nodes: one monopole item per species with mass
-#pragma unroll
-          for(int g = 0; g < NG; g++)
-            {
-              const bool pg = dec == 1 && ((massmask >> g) & 1u);
-              unsigned long long mask = __ballot(pg ? 1 : 0);
-              if(pg)
-                pq[qn + lane_prefix(mask)] = -1 - (my * NG + g);
-              qn += __popcll(mask);
-            }
-          // opened nodes: node children back on the LIFO, particle children into the queue
-          if(__any(dec == 2))
-            {
-              const int chv[8] = {ch_lo.x, ch_lo.y, ch_lo.z, ch_lo.w, ch_hi.x, ch_hi.y, ch_hi.z, ch_hi.w};
-#pragma unroll
-              for(int slot = 0; slot < 8; slot++)
-                {
-                  const int ch = (dec == 2) ? chv[slot] : -1;
-                  const bool isnode = ch >= 0;
-                  unsigned long long mask = __ballot(isnode ? 1 : 0);
-                  if(mask)
-                    {
-                      int npush = __popcll(mask);
-                      if(sp + npush > GW_STACK)
-                        overflow = true;
-                      else
-                        {
-                          if(isnode)
-                            stack[sp + lane_prefix(mask)] = ch;
-                          sp += npush;
-                        }
-                    }
-                  const bool ispart = ch <= -2;
-                  unsigned long long pmask = __ballot(ispart ? 1 : 0);
-                  if(ispart)
-                    pq[qn + lane_prefix(pmask)] = -2 - ch;
-                  qn += __popcll(pmask);
-                }
-            }
-          // small or coincident-key nodes: all particles of the contiguous range (first GW_NLEAF here, buckets below)
-          if(__any(dec == 3))
-            {
-#pragma unroll
-              for(int k = 0; k < GW_NLEAF; k++)
-                {
-                  const bool more = (dec == 3) && k < count;
-                  unsigned long long pmask = __ballot(more ? 1 : 0);
-                  if(more)
-                    pq[qn + lane_prefix(pmask)] = first + k;
-                  qn += __popcll(pmask);
-                }
-              // a bucket (coincident keys at the deepest level) may hold more than NLEAF particles: re-queue
-              // the remainder as a node test of its own is impossible, so feed it through the LIFO as
-              // (negative) range markers -- rare path, handled one wave-step at a time
-              bool big = (dec == 3) && count > GW_NLEAF;
-              while(__any(big ? 1 : 0))
-                {
-                  // serialise: the first such lane streams its remaining particles 64 at a time via the queue
-                  int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(__ballot(big ? 1 : 0)));
-                  int bf = __shfl(first, src), bc = __shfl(count, src);
-                  for(int k0 = GW_NLEAF; k0 < bc; k0 += WAVE)
-                    {
-                      if(qn + WAVE > GW_PQ)
-                        {
-                          overflow = true;   // cannot happen for sane inputs (needs > GW_PQ coincident particles)
-                          break;
-                        }
-                      bool m2 = k0 + lane < bc;
-                      unsigned long long pm2 = __ballot(m2 ? 1 : 0);
-                      if(m2)
-                        pq[qn + lane_prefix(pm2)] = bf + k0 + lane;
-                      qn += __popcll(pm2);
-                    }
-                  if(lane == src)
-                    big = false;
-                }
-            }
-          if(overflow)
-            break;
-          wave_sync();
-        }
-      if(lane == 0)
-        {
-          // 64-bit statistics behind the per-XCD counters (walk_counters[16..23]): entries, nodes, batches, force trips
-          unsigned long long *st64 = reinterpret_cast<unsigned long long *>(counter + 16);
-          atomicAdd(&st64[0], (unsigned long long)st_entries);
-          atomicAdd(&st64[1], (unsigned long long)st_nodes);
-          atomicAdd(&st64[2], (unsigned long long)st_batches);
-          atomicAdd(&st64[3], (unsigned long long)st_iters);
-        }
-      if(overflow)
-        {
-          if(lane == 0)
-            atomicExch(err_flag, 1);
-          continue;
-        }
-      if(valid)
-        {
-          r_acc[3 * ti + 0] = ax;
-          r_acc[3 * ti + 1] = ay;
-          r_acc[3 * ti + 2] = az;
-          r_nint[ti] = nint;
-        }
-    }
-}
-
 // =============================================================================================
-//  group walk, second generation: traversal and force evaluation are separate phases per group.
+//  group walk: traversal and force evaluation are separate phases per group (and, by default, separate kernels).
 //
-//  Phase 1 is the same cooperative traversal as k_walk_group, but accepted monopoles / particle leaves are
-//  only recorded as item indices in a per-wave global scratch list.  Phase 2 visits that list in a
+//  Phase 1 is a cooperative traversal (64 pending nodes tested per round, one per lane); accepted monopoles / particle
+//  leaves are only recorded as item indices in a global scratch list.  Phase 2 visits that list in a
 //  golden-ratio stride order, so every chunk of 64 items is an even sample of the whole neighbourhood of the
 //  group instead of one corner of it; each lane tests the 64 chunk entries (LDS broadcast) against ITS OWN
 //  target and keeps a 64-bit hit mask per source species; the force loop then lets every lane walk its own
 //  bits (ES per trip).  Per-lane lists remove the bounding-box waste of shared lists (a target needs ~375 of
-//  the ~1600 entries its group collects) and the stride order balances the lanes: the force loop runs ~400
-//  trips per group instead of ~1100 (sub-group lists) / ~1900 (one shared list).
+//  the ~2550 entries its group collects) and the stride order balances the lanes: the force loop runs ~545 slots per
+//  lane and group instead of ~1100 (eight sub-group lists, the first generation of this kernel) / ~1900 (one shared list).
 // =============================================================================================
 #define GW2_ITEMS 16384      // item scratch per wave and source species (global); phase 2 runs early if it would overflow
 
@@ -2445,42 +1847,6 @@ template <int NG, bool PM, bool LATT> static void launch_strict(ngravs_ctx *c, c
                      (long long)c->shard_count, c->r_acc.p, c->r_nint.p);
 }
 
-template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_group_t(ngravs_ctx *c, const WalkParams &wp)
-{
-  int ncu = 256;
-  hipDeviceProp_t prop;
-  if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
-    ncu = prop.multiProcessorCount;
-  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
-  // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
-  int waves = (int)((160 * 1024 - fixed) / GW_WAVE_LDS(NG));
-  int per_cu = 1;
-  if(waves > GW_MAXWAVES)
-    {
-      per_cu = waves / 8 > 4 ? 4 : waves / 8;
-      waves = 8;
-    }
-  if(waves < 1)
-    waves = 1;
-  size_t lds = fixed + (size_t)waves * GW_WAVE_LDS(NG);
-  long long ngroups = (c->shard_count + WAVE - 1) / WAVE;
-  long long nblk = (long long)ncu * per_cu;
-  if(nblk > (ngroups + waves - 1) / waves)
-    nblk = (ngroups + waves - 1) / waves;
-  if(nblk < 1)
-    nblk = 1;
-  if(c->walk_stack.ensure((size_t)nblk * waves * GW_STACK) || c->walk_counters.ensure(32))
-    return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
-  auto kern = k_walk_group<NG, PM, YUK, TAB_LDS, LATT>;
-  HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
-                     c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
-                     (long long)c->shard_count, c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
-                     c->r_nint.p);
-  return NGRAVS_OK;
-}
-
 // targets of the group walk: all particles of the shard, or the compacted active ones (walk_select_targets)
 static inline long long walk_tcount(const ngravs_ctx *c) { return c->walk_ntargets >= 0 ? c->walk_ntargets : c->shard_count; }
 static inline const int *walk_tlist(const ngravs_ctx *c) { return c->walk_ntargets >= 0 ? c->walk_tlist.p : nullptr; }
@@ -2650,16 +2016,7 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
     c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables beside the pools would leave 9 waves; measured equal to 16 waves reading them through L1/L2
-  const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;   // first-generation kernel (sub-group lists)
-  if(v1)
-    {
-      if(pm)
-        return yuk ? launch_group_t<NG, true, true, TL, false>(c, wp) : launch_group_t<NG, true, false, TL, false>(c, wp);
-      if(c->cfg.periodic)
-        return yuk ? launch_group_t<NG, false, true, false, true>(c, wp) : launch_group_t<NG, false, false, false, true>(c, wp);
-      return yuk ? launch_group_t<NG, false, true, false, false>(c, wp) : launch_group_t<NG, false, false, false, false>(c, wp);
-    }
-  const bool v2 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 2;   // fused second-generation kernel
+  const bool v2 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 2;   // fused kernel for the whole walk
   if(allow_split && !v2 && !glist)
     {
       *used_split = true;
@@ -2701,8 +2058,7 @@ int walk_run(ngravs_ctx *c)
       int rct = ensure_level_table(c, sqrt(wp.reach2));
       if(rct)
         return rct;
-      const bool v1 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 1;
-      if(!v1 && (rct = walk_select_targets(c)))
+      if((rct = walk_select_targets(c)))
         return rct;
     }
   HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
