@@ -1958,10 +1958,28 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     c->walk_scap = GW3_STK_MIN;
   const int lcap = c->walk_lcap, scap = c->walk_scap;
   const size_t region_ints = (size_t)NG * lcap + scap;
-  long long batch = 131072;
+  // batches as large as memory comfortably allows (every traversal/evaluation launch pair costs ~0.4 ms of ramp and tail:
+  // 16 / 8 / 1 launches per step at C4 measured 114 / 107 / 104 ms of evaluation): a quarter of the free device memory, at
+  // least 8 GB and at most 64 GB, unless NGRAVS_WALK_BATCH fixes the group count
+  long long batch = 1 << 20;
+  size_t cap_bytes = (size_t)8 << 30;
+  {
+    size_t free_b = 0, total_b = 0;
+    if(hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      {
+        free_b += c->walk_stack.cap * sizeof(int);   // what this scratch already holds counts as available
+        if(free_b / 4 > cap_bytes)
+          cap_bytes = free_b / 4;
+        if(cap_bytes > ((size_t)64 << 30))
+          cap_bytes = (size_t)64 << 30;
+      }
+  }
   if(getenv("NGRAVS_WALK_BATCH") && atoll(getenv("NGRAVS_WALK_BATCH")) > 0)
-    batch = atoll(getenv("NGRAVS_WALK_BATCH"));
-  while(batch > 8192 && (size_t)batch * region_ints * sizeof(int) > ((size_t)8 << 30))
+    {
+      batch = atoll(getenv("NGRAVS_WALK_BATCH"));
+      cap_bytes = (size_t)64 << 30;
+    }
+  while(batch > 8192 && (size_t)batch * region_ints * sizeof(int) > cap_bytes)
     batch /= 2;
   if(batch > ngroups)
     batch = ngroups;
