@@ -703,6 +703,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     }
   const long long gbase = MODE == 0 ? 0 : g_first;
   const double BIG = 1e300;
+  double h2max = 0;   // square of the largest softening length of any particle type (wave-uniform)
+#pragma unroll
+  for(int q = 0; q < NGRAVS_NTYPES; q++)
+    h2max = fmax(h2max, wp.fsoft[q] * wp.fsoft[q]);
 
   // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
   // workgroup pulls groups from the segment of the XCD it runs on (neighbouring groups share most of their
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       // Inactive slots (a lane whose mask is exhausted) point at the pool's NULL entry (index 127: far away, mass 0), so the
       // common path needs no per-slot masking at all; the rare slot that passed the fp32 pre-test but fails the exact
       // r2 < reach2 test is removed under a wave-level branch.
-      auto evalN = [&](auto lw_tag, const int g, const double4 (&e)[ES], const double (&hs)[ES], const bool (&act)[ES]) {
+      auto evalN = [&](auto lw_tag, const int g, const double4 (&e)[ES], const int (&jj)[ES], const bool (&act)[ES]) {
         constexpr bool LW = decltype(lw_tag)::value;
         double dx[ES], dy[ES], dz[ES], r2[ES], rinv[ES], r[ES], fac[ES], mw[ES];
         bool fpos = false;
@@ -860,8 +864,6 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               }
           }
         bool anysoft = false;
-        bool soft[ES];
-        double h[ES];
 #pragma unroll
         for(int k = 0; k < ES; k++)
           {
@@ -883,21 +885,21 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 f -= wp.utor2wpi * trow[tab];
               }
             fac[k] = f * mw[k] * ri;
-            h[k] = __builtin_fmax(hT, hs[k]);
-            soft[k] = rr < h[k];
-            anysoft |= soft[k];
+            anysoft |= r2[k] < h2max;                                     // closer than the largest softening length at all?
           }
-        if(__any(anysoft ? 1 : 0))                                        // rare: inside the softening radius
+        if(__any(anysoft ? 1 : 0))                                        // rare: possibly inside the softening radius
           {
 #pragma unroll
             for(int k = 0; k < ES; k++)
               {
-                double h_inv = 1 / h[k], u = r[k] * h_inv;
+                const double h = __builtin_fmax(hT, lh[jj[k]]);           // the pair's softening (forcetree.c:1415-1417)
+                const bool soft = r[k] < h;
+                double h_inv = 1 / h, u = r[k] * h_inv;
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
                                      : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u -
                                         0.066666666667 / (u * u * u));
                 double fs = cSg * mw[k] * h_inv * h_inv * h_inv * v;
-                fac[k] = soft[k] ? fs : fac[k];
+                fac[k] = soft ? fs : fac[k];
               }
           }
 #pragma unroll
@@ -1213,17 +1215,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                         m &= m - 1;
                       }
                     double4 e[ES];
-                    double hh[ES];
 #pragma unroll
                     for(int k = 0; k < ES; k++)
-                      {
-                        e[k] = pp[jj[k]];
-                        hh[k] = ph[jj[k]];
-                      }
+                      e[k] = pp[jj[k]];
                     if(lanewrap)
-                      evalN(std::true_type{}, g, e, hh, act);
+                      evalN(std::true_type{}, g, e, jj, act);
                     else
-                      evalN(std::false_type{}, g, e, hh, act);
+                      evalN(std::false_type{}, g, e, jj, act);
                   }
                 wave_sync();
                 // move the remainder to the front
