@@ -1415,49 +1415,92 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     sp8 |= ((wp.t2g_packed >> (2 * s_type[pi])) & 3u) << (2 * q);
                 }
             }
-          if(__any(dec == 2))
+          // ---- append: every lane holds up to 8 things to record -- child nodes for the LIFO (dec 2) and particles for the
+          //      item lists (children of an opened node, or the first 8 particles of a small node's range, dec 3).  One packed
+          //      wave prefix sum (10 bits per field: at most 64 x 8 = 512 per kind) gives every lane its write offsets, and it
+          //      then writes its own items back to back: siblings stay adjacent on the LIFO (and in memory, when they are
+          //      popped and tested together), and the 8 x (1 + NG) ballot rounds of a slot-by-slot append are gone.
+          if(__any(dec >= 2))
             {
+              int itemv[8];
+              unsigned cnt_pack = 0;   // nodes | species-0 particles << 10 | species-1 particles << 20
+              unsigned cnt_g2 = 0;     // species-2 particles (N_GRAVS = 3)
 #pragma unroll
-              for(int slot = 0; slot < 8; slot++)
+              for(int q = 0; q < 8; q++)
                 {
-                  const int ch = (dec == 2) ? chv[slot] : -1;
-                  const bool isnode = ch >= 0;
-                  unsigned long long mask = __ballot(isnode ? 1 : 0);
-                  if(mask)
+                  int it = -1;   // >= 0: node for the LIFO; <= -2: particle (-2 - index); -1: nothing
+                  if(dec == 2)
+                    it = chv[q];
+                  else if(dec == 3 && q < count)
+                    it = -2 - (first + q);
+                  itemv[q] = it;
+                  const int sgq = (int)((sp8 >> (2 * q)) & 3u);
+                  if(it >= 0)
+                    cnt_pack += 1u;
+                  else if(it <= -2)
                     {
-                      int npush = __popcll(mask);
-                      if(sp + npush > STK_CAP)
-                        {
-                          overflow = true;
-                          stk_overflow = true;
-                        }
+                      if(sgq == 0)
+                        cnt_pack += 1u << 10;
+                      else if(sgq == 1)
+                        cnt_pack += 1u << 20;
                       else
-                        {
-                          if(isnode)
-                            STK(sp + lane_prefix(mask)) = ch;
-                          sp += npush;
-                        }
-                    }
-                  const bool ispart = ch <= -2;
-                  if(__any(ispart ? 1 : 0))
-                    {
-                      const int pi = -2 - ch;
-                      const int sgp = (int)((sp8 >> (2 * slot)) & 3u);
-#pragma unroll
-                      for(int g = 0; g < NG; g++)
-                        {
-                          const bool pg = ispart && sgp == g;
-                          unsigned long long pmask = __ballot(pg ? 1 : 0);
-                          if(pg)
-                            lists[g][n_items[g] + lane_prefix(pmask)] = pi;
-                          n_items[g] += __popcll(pmask);
-                        }
+                        cnt_g2 += 1u;
                     }
                 }
+              unsigned inc = cnt_pack, inc2 = cnt_g2;   // inclusive wave scans
+#pragma unroll
+              for(int off = 1; off < WAVE; off <<= 1)
+                {
+                  const unsigned y = __shfl_up(inc, off);
+                  inc += lane >= off ? y : 0u;
+                  if(NG > 2)
+                    {
+                      const unsigned y2 = __shfl_up(inc2, off);
+                      inc2 += lane >= off ? y2 : 0u;
+                    }
+                }
+              const unsigned tot = __shfl(inc, WAVE - 1), tot2 = NG > 2 ? __shfl(inc2, WAVE - 1) : 0u;
+              const unsigned exc = inc - cnt_pack, exc2 = inc2 - cnt_g2;
+              const int tn = (int)(tot & 1023u);
+              if(sp + tn > STK_CAP)
+                {
+                  overflow = true;
+                  stk_overflow = true;
+                }
+              else
+                {
+                  int on = sp + (int)(exc & 1023u);
+                  int op0 = n_items[0] + (int)((exc >> 10) & 1023u);
+                  int op1 = NG > 1 ? n_items[NG > 1 ? 1 : 0] + (int)((exc >> 20) & 1023u) : 0;
+                  int op2 = NG > 2 ? n_items[NG > 2 ? 2 : 0] + (int)exc2 : 0;
+#pragma unroll
+                  for(int q = 0; q < 8; q++)
+                    {
+                      const int it = itemv[q];
+                      const int sgq = (int)((sp8 >> (2 * q)) & 3u);
+                      if(it >= 0)
+                        STK(on++) = it;
+                      else if(it <= -2)
+                        {
+                          if(sgq == 0)
+                            lists[0][op0++] = -2 - it;
+                          else if(NG > 1 && sgq == 1)
+                            lists[NG > 1 ? 1 : 0][op1++] = -2 - it;
+                          else if(NG > 2)
+                            lists[NG > 2 ? 2 : 0][op2++] = -2 - it;
+                        }
+                    }
+                  sp += tn;
+                  n_items[0] += (int)((tot >> 10) & 1023u);
+                  if(NG > 1)
+                    n_items[NG > 1 ? 1 : 0] += (int)((tot >> 20) & 1023u);
+                  if(NG > 2)
+                    n_items[NG > 2 ? 2 : 0] += (int)tot2;
+                }
             }
-          if(__any(dec == 3))
+          // coincident-key buckets (more than 8 particles in one leaf): the rest of the range, 64 lanes x k-th particle
+          if(!overflow && __any(dec == 3 && count > 8))
             {
-              // small or coincident-key nodes: all particles of the contiguous range, 64 lanes x k-th particle
               int kmax = 0;
               {
                 int cmine = (dec == 3) ? count : 0;
@@ -1468,7 +1511,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   }
                 kmax = cmine;
               }
-              for(int k = 0; k < kmax; k++)
+              for(int k = 8; k < kmax; k++)
                 {
                   bool full = false;
 #pragma unroll
@@ -1480,9 +1523,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       break;
                     }
                   const bool more = (dec == 3) && k < count;
-                  int sgp = (int)((sp8 >> (2 * (k & 7))) & 3u);
-                  if(NG > 1 && k >= 8)   // coincident-key buckets only
-                    sgp = more ? (int)((wp.t2g_packed >> (2 * s_type[first + k])) & 3u) : 0;
+                  const int sgp = (NG > 1 && more) ? (int)((wp.t2g_packed >> (2 * s_type[first + k])) & 3u) : 0;
 #pragma unroll
                   for(int g = 0; g < NG; g++)
                     {
