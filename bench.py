@@ -44,13 +44,15 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
     return b
 
 
-def walk_traffic(args, n, world):
-    """HBM-side bytes per launch of the walk kernel from the committed rocprofv3 --pmc passes (profiles/), only when
-    the run IS that workload (PMC counters cannot be collected inside this process)"""
-    path = os.path.join(ROOT, "profiles", "r01e_walk_traffic.json")
+def walk_traffic(args, n, world, launches):
+    """HBM-side bytes per launch of the walk's evaluation kernel from the committed rocprofv3 --pmc passes (profiles/),
+    only when the run IS that workload (PMC counters cannot be collected inside this process); rescaled if the step is
+    cut into a different number of launches than when it was profiled"""
+    path = os.path.join(ROOT, "profiles", "r01f_walk_traffic.json")
     if args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and os.path.exists(path):
         with open(path) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+            d = json.load(f)
+        return d["traffic_bytes_per_launch"] * d.get("launches_per_step", 1) / max(1, launches)
     return None
 
 
@@ -313,7 +315,7 @@ def main():
                        "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle, pm=not treeonly) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": kname, "split_walk": split,
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": walk_traffic(args, n, world),
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": walk_traffic(args, n, world, split["launches_per_step"] if split else 1),
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
         }
         if not args.no_cpu_baseline and world == 1 and not treeonly:

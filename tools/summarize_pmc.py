@@ -63,6 +63,7 @@ def main():
         fb, wb = timed_mean(traffic.get("FETCH_SIZE", [0])), timed_mean(traffic.get("WRITE_SIZE", [0]))
         with open(out_json, "w") as f:
             json.dump({"kernel": "k_walk_group2<2,true,true,true,false,2> (evaluation)", "workload": "C4 64M",
+                       "launches_per_step": len(traffic.get("FETCH_SIZE", [0])) - len(traffic.get("FETCH_SIZE", [0])) // 2,
                        "fetch_bytes_reported": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the evaluation-kernel "
                                "launches of the timed relative-criterion step; FETCH_SIZE as reported (gather reads, "
