@@ -131,6 +131,23 @@ int main(void)
                                          P[i].GravAccel[2] * P[i].GravAccel[2])) > 1e-9 * sqrt(n2))
         bad++;
     }
+  /* a step that keeps the tree (TreeDomainUpdateFrequency > 0, domain.c:76 false): same P[], unchanged positions ->
+   * ngravs_update_particles + gravity_tree (which refits the kept tree) must reproduce the forces bit for bit */
+  {
+    double (*keep)[3] = malloc(sizeof(double[3]) * N);
+    for(i = 0; i < N; i++)
+      for(k = 0; k < 3; k++)
+        keep[i][k] = P[i].GravAccel[k];
+    if(ngravs_update_particles(ctx, &pp) || ngravs_gravity_tree(ctx))
+      return 6;
+    if(ngravs_get_accel(ctx, &P[0].GravAccel[0], sizeof(*P), NULL, 0, NULL, 0, NULL, 0, 0))
+      return 7;
+    for(i = 0; i < N; i++)
+      for(k = 0; k < 3; k++)
+        if(keep[i][k] != P[i].GravAccel[k])
+          bad++;
+    free(keep);
+  }
   ngravs_stats_t st;
   ngravs_get_stats(ctx, &st);
   printf("host_shim_test: N=%d active=%d (engine says %ld) mean err %.3e worst %.3e ia/part %.1f nodes %ld bad=%d\n", N, nact,
