@@ -88,7 +88,7 @@ def test_total_force_against_periodic_direct_sum(pkg, big):
     """tree + PM of the production path (relative criterion) against the periodic direct sum over ALL sources (nearest image
     + lattice correction tables, the reference's gravity_forcetest() path) for a sample of targets: the error stays in the
     reference TreePM band (rms 6.5e-3 ... 9.6e-3 at ErrTolForceAcc 0.005).  tools/accuracy_at_scale.py runs
-    the same check at the bench size (profiles/r01_accuracy_2p26.json: rms 7.1e-3 at 2^26 particles)."""
+    the same check at the bench size (profiles/r01_accuracy_2p26_ng2.json: rms 7.1e-3 at 2^26 particles)."""
     n, pos, mass, typ, kw = big
     eng = pkg.Engine(pkg.make_config(walk_mode=pkg.WALK_GROUP, **kw))
     eng.set_particles(pos, mass, typ)

@@ -25,16 +25,21 @@ def main():
     ap.add_argument("--log2n", type=int, default=26)
     ap.add_argument("--samples", type=int, default=256)
     ap.add_argument("--tag", default="r01")
+    ap.add_argument("--ngravs", type=int, default=2)
+    ap.add_argument("--wiring", default="c4")
+    ap.add_argument("--pmgrid", type=int, default=0)
     args = ap.parse_args()
     import torch
     pkg = ge.load_package()
-    n, L, ng = 1 << args.log2n, 1.0, 2
-    pmgrid = 16
-    while (pmgrid * 2) ** 3 <= 2 * n:
-        pmgrid *= 2
+    n, L, ng = 1 << args.log2n, 1.0, args.ngravs
+    pmgrid = args.pmgrid
+    if not pmgrid:
+        pmgrid = 16
+        while (pmgrid * 2) ** 3 <= 2 * n:
+            pmgrid *= 2
     eps = L / (40 * n ** (1 / 3))
     cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, err_tol_force_acc=0.005,
-                          softening=[eps] * 6, type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4",
+                          softening=[eps] * 6, type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=args.wiring,
                           walk_mode=pkg.WALK_GROUP)
     pos, mass, ptype = bench.make_box(pkg, n, L, ng, 12345)
     dev = torch.device("cuda", 0)
@@ -61,7 +66,7 @@ def main():
         truth[s:s + chunk] = eng.direct_sum(idx[s:s + chunk])
         print("direct sum %d/%d (%.0f s)" % (min(len(idx), s + chunk), len(idx), time.time() - t0), flush=True)
     e = np.linalg.norm(tot - truth, axis=1) / np.linalg.norm(truth, axis=1)
-    out = {"workload": "C4: %d particles, N_GRAVS=2 (c4), PMGRID=%d, ErrTolForceAcc=0.005, group walk" % (n, pmgrid),
+    out = {"workload": "%d particles, N_GRAVS=%d (%s wiring), PMGRID=%d, ErrTolForceAcc=0.005, group walk" % (n, ng, args.wiring, pmgrid),
            "samples": int(len(idx)), "truth": "periodic direct sum on the GPU (nearest image + lattice correction tables)",
            "rel_err_rms": float(np.sqrt(np.mean(e ** 2))), "rel_err_median": float(np.median(e)), "rel_err_p99": float(np.percentile(e, 99)),
            "rel_err_max": float(e.max()), "interactions_per_particle": ia,
@@ -71,7 +76,7 @@ def main():
     # gpurun only brings gpurun_out/ back from the GPU box; the file is then copied into profiles/
     for d in ("gpurun_out", "profiles"):
         os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-        with open(os.path.join(ROOT, d, "%s_accuracy_2p%d.json" % (args.tag, args.log2n)), "w") as f:
+        with open(os.path.join(ROOT, d, "%s_accuracy_2p%d_ng%d.json" % (args.tag, args.log2n, ng)), "w") as f:
             json.dump(out, f, indent=1)
     eng.close()
 
