@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
                 //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
                 unsigned int mlo = 0, mhi = 0;
-                if(fastmask && !(wp.dbg & 1))
+                if(fastmask && !(wp.dbg & (1 | 8)))   // NGRAVS_DEBUG bit 8: use the exact fp64 test below instead (tests)
                   {
                     // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
                     // (v_alignbit), highest entry first so that entry j ends up in bit j

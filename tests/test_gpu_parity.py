@@ -461,3 +461,30 @@ def test_dynamic_tree_update_refit(pkg, O):
               % (mode, np.median(d), np.percentile(d, 99), rms(e_refit), rms(e_fresh), c2.mean(), c3.mean()))
         assert np.median(d) < 1e-2 and np.percentile(d, 99) < 0.1    # two valid approximations (walk error ~1e-2 at this size)
         assert rms(e_refit) < 1.3 * rms(e_fresh) + 1e-3
+
+
+def test_reach_pretest_fp32_and_exact_paths_agree(pkg, O, monkeypatch):
+    """the evaluation kernel pre-selects pairs within reach in packed fp32 (threshold widened by the rounding bound) and
+    re-tests r2 < reach2 exactly in the force loop; with NGRAVS_DEBUG=8 the selection itself is done in fp64.  Forces and
+    interaction counts must be bit-identical (a pair the fp32 test lost would show up here)."""
+    n, L, ng = 60000, 1.0, 2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=9)
+    eps = L / (40 * n ** (1 / 3))
+    res = []
+    for dbg in (None, "8"):
+        if dbg:
+            monkeypatch.setenv("NGRAVS_DEBUG", dbg)
+        cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_GROUP)
+        eng = _engine(pkg, cfg, pos, mass, typ)
+        eng.compute_accelerations(pm_step=True)
+        acc, old, cost = eng.get_accel()
+        eng.set_opening(0.0, 0.005)
+        eng.set_old_acc(old)
+        eng.gravity_tree()
+        acc2, _, cost2 = eng.get_accel()
+        eng.close()
+        res.append((acc, cost, acc2, cost2))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert res[0][1].mean() > 100
