@@ -175,7 +175,7 @@ int dom_keys_and_sort(ngravs_ctx *c)
                      fac21, TREE_BITS, c->in_key.p, c->idx_iota.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p,
                      c->in_rec.p);
   size_t tmp_bytes = 0;
-  hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p, c->s_idx.p, (int)n, 0,
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p, c->s_idx.p, (int)n, 0,
                                      3 * TREE_BITS, c->stream);
   if(c->sort_tmp.ensure(tmp_bytes))
     return NGRAVS_ERR_NOMEM;

@@ -322,7 +322,7 @@ int tree_build(ngravs_ctx *c)
   HIP_TRY(c, hipMemcpyAsync(c->n_geo.p, &h_geo, sizeof(double4), hipMemcpyHostToDevice, c->stream));
   double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
   size_t scan_bytes = 0;
-  hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c->n_nchild.p, c->scan_out.p, (int)maxn, c->stream);
+  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c->n_nchild.p, c->scan_out.p, (int)maxn, c->stream);
   if(c->scan_tmp.ensure(scan_bytes))
     return NGRAVS_ERR_NOMEM;
   long long node0 = 0, cnt = 1;
