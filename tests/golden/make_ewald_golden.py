@@ -2,14 +2,14 @@
 """Generate tests/golden/ewald_truth_<wiring>.npz: Ewald-summed accelerations (tests/ewald.py, written
 from the textbook formulas) for a sample of targets of the seeded TreePM parity boxes, plus the oracle's
 (= reference algorithm's) TreePM result on the same targets.  CPU only; run from the repo root:
-    python tools/make_ewald_golden.py
+    python tests/golden/make_ewald_golden.py
 The GPU accuracy tests load these instead of spending minutes of GPU-box time in numpy."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge  # noqa: E402

@@ -15,7 +15,7 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import importlib
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -46,7 +46,7 @@ def _worker(rank, world, port, out_dir):
 
 def test_three_rank_domain_decomposition(pkg, tmp_path):
     import torch.multiprocessing as mp
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_ewald_golden import N, L, SEED, case_config
     world = 3
     port = 29600 + (os.getpid() % 2000)

@@ -203,12 +203,12 @@ def test_group_walk_leftover_groups(pkg, O, monkeypatch):
 @pytest.mark.parametrize("reach", [0.0, 6.0])
 def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
     """TreePM total (tree + PM) against an independent Ewald sum (tests/golden/ewald_truth_*.npz, made by
-    tools/make_ewald_golden.py): the group walk must be at least as accurate as the reference walk, whose
+    tests/golden/make_ewald_golden.py): the group walk must be at least as accurate as the reference walk, whose
     own error is rms 6.5e-3 .. 9.1e-3 here (7.8e-3 .. 9.6e-3).  The two walks differ at the
     1e-2 level of the (strongly cancelling) total force because the reference truncates at its rcut box
     (forcetree.c:1828-1862) while the group walk cuts on a sphere of radius group_reach * Asmth."""
     import os
-    sys_path = os.path.join(os.path.dirname(__file__), "..", "tools")
+    sys_path = os.path.join(os.path.dirname(__file__), "golden")
     import sys
     sys.path.insert(0, sys_path)
     from make_ewald_golden import N, L, SEED, case_config
@@ -237,7 +237,7 @@ def test_group_walk_sparse_active_set_vs_ewald(pkg, O):
     with the uncompacted walk (NGRAVS_WALK_COMPACT=0) at the level of the walk error."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_ewald_golden import N, L, SEED, case_config
     wiring, ng = "c4", 2
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ewald_truth_%s.npz" % wiring))

@@ -82,7 +82,7 @@ def test_gpu_periodic_direct_sum_is_the_treepm_truth(pkg):
     (gravtree_forcetest.c:297-311): the TreePM total must agree with it like it does with the Ewald golden"""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_ewald_golden import N, L, SEED, case_config
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ewald_truth_c4.npz"))
     pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=2, seed=SEED)

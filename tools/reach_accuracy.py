@@ -3,7 +3,7 @@
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import __graft_entry__ as ge
 from make_ewald_golden import N, L, SEED, CASES, case_config
 pkg = ge.load_package()
