@@ -488,3 +488,29 @@ def test_reach_pretest_fp32_and_exact_paths_agree(pkg, O, monkeypatch):
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
     assert res[0][1].mean() > 100
+
+
+def test_no_or_one_active_particle(pkg, O):
+    """degenerate active sets (a step on which nothing, or a single particle, ends its timestep): no launch with an empty
+    grid, nothing written for inactive particles, and the single target's force equals the all-active run's to walk accuracy"""
+    n, L, ng = 20000, 1.0, 2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=4)
+    eps = L / (40 * n ** (1 / 3))
+    kw = dict(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_GROUP)
+    full = _engine(pkg, pkg.make_config(**kw), pos, mass, typ)
+    full.compute_accelerations(pm_step=True)
+    a_full, _, _ = full.get_accel()
+    full.close()
+    for k in (0, 1):
+        active = np.zeros(n, dtype=np.uint8)
+        active[:k] = 1
+        eng = _engine(pkg, pkg.make_config(**kw), pos, mass, typ, active=active)
+        eng.compute_accelerations(pm_step=True)
+        acc, old, cost = eng.get_accel()
+        st = eng.stats()
+        eng.close()
+        assert st.n_active == k
+        assert np.all(acc[k:] == 0) and np.all(cost[k:] == 0)
+        if k:
+            assert rel_err(acc[:1], a_full[:1]).max() < 2e-2 and cost[0] > 0
