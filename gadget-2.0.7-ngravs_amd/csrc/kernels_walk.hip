@@ -2118,8 +2118,12 @@ int walk_run(ngravs_ctx *c)
       if((rct = walk_select_targets(c)))
         return rct;
     }
-  HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
+  // rows the walk does not write (inactive particles, other tasks' shards, halo copies) read as zero
+  if(!(c->all_active && c->cfg.world_size == 1 && c->n_local == c->n))
+    {
+      HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
+    }
   const bool pm = c->cfg.pmgrid != 0;
   HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
   int rc = NGRAVS_OK;
