@@ -1107,9 +1107,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
             if(wp.periodic)
               {
-                ex = nearest(ex, wp.box, wp.boxhalf);
-                ey = nearest(ey, wp.box, wp.boxhalf);
-                ez = nearest(ez, wp.box, wp.boxhalf);
+                ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
+                ey = nearest_abs(ey, wp.box, invbox);   // a tie (|ey| = box/2) is far beyond any reach
+                ez = nearest_abs(ez, wp.box, invbox);   // a tie (|ez| = box/2) is far beyond any reach
               }
             if(PM)
               {
