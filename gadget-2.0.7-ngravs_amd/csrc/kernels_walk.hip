@@ -14,17 +14,16 @@
 //      summation order per target equal the reference's (children are visited in Peano instead
 //      of Morton order, which only reorders the fp64 sum).
 //
-//  k_walk_group : the MI355X production walk.  The 64 lanes traverse cooperatively: a LIFO of
-//      pending nodes is popped 64 at a time, each lane tests ONE node against the group's
-//      bounding box with the conservative form of every reference test (a node is used only if
-//      every target would use it, dropped only if every target would drop it); accepted monopoles
-//      and particle leaves are queued as indices, fetched 64 at a time, culled against the bounding
-//      boxes of the 8 sub-groups (8 consecutive targets each) and stored once in an LDS pool, with a
-//      byte-index list per sub-group and species (ballot + mbcnt prefix compaction); every sub-group
-//      then streams ITS list through the force law (per-row LDS reads, four entries per trip as four
-//      independent straight-line streams).  The TreePM short-range tables (the distinct ones of the
-//      symmetric wiring) are staged in LDS once per persistent workgroup; workgroups pull groups
-//      from per-XCD atomic counters (XCD-aware Peano segments, stealing when exhausted).
+//  k_walk_group2 : the MI355X production walk, as a traversal kernel (MODE 1), an evaluation kernel (MODE 2) or both in
+//      one (MODE 0).  Traversal: the 64 lanes work cooperatively -- a LIFO of pending nodes is popped 64 at a time, each
+//      lane tests ONE node against the group's bounding box with the conservative form of every reference test (a node
+//      is used only if every target would use it, dropped only if every target would drop it); accepted monopoles and
+//      particle leaves are recorded as item indices per source species (one packed wave prefix sum per round).
+//      Evaluation: the items are visited in a golden-ratio stride order, culled against the box, compacted into an LDS
+//      pool; every lane builds its own 64-bit hit mask (packed-fp32 reach pre-test) and walks its own bits through the
+//      force law.  The TreePM short-range tables (the distinct ones of the symmetric wiring) are staged in LDS once per
+//      persistent evaluation workgroup; workgroups pull groups from per-XCD atomic counters (XCD-aware Peano segments,
+//      stealing when exhausted).  S lanes can share one target (sparse active sets, leftover groups).
 //
 // Force laws: the reference calls AccelFxns[tg][sg] through a pointer; here the wired table is
 // lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,
@@ -609,7 +608,7 @@ __device__ __forceinline__ double wave_max(double v)
 //  target and keeps a 64-bit hit mask per source species; the force loop then lets every lane walk its own
 //  bits (ES per trip).  Per-lane lists remove the bounding-box waste of shared lists (a target needs ~375 of
 //  the ~2550 entries its group collects) and the stride order balances the lanes: the force loop runs ~545 slots per
-//  lane and group instead of ~1100 (eight sub-group lists, the first generation of this kernel) / ~1900 (one shared list).
+//  lane and group instead of ~1100 (eight sub-group lists, an earlier version of this kernel) / ~1900 (one shared list).
 // =============================================================================================
 #define GW2_ITEMS 16384      // item scratch per wave and source species (global); phase 2 runs early if it would overflow
 
@@ -1207,7 +1206,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   }
                 // ---- force loop: every lane walks its own bits, ES per trip
                 unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & lane_pat;
-                nint += __popcll(m);   // eval4 takes the (rare) slots beyond the exact cut off again
+                nint += __popcll(m);   // evalN takes the (rare) slots beyond the exact cut off again
                 if(wp.dbg & 4)         // debug: masks are built but not evaluated
                   m = 0;
                 while(__any(m != 0 ? 1 : 0))
@@ -2241,7 +2240,7 @@ int walk_run(ngravs_ctx *c)
       c->stats.reserved[0] = st64[0] / ngroups;   // pool entries per group
       c->stats.reserved[1] = st64[1] / ngroups;   // nodes tested per group
       c->stats.reserved[2] = st64[2] / ngroups;   // traversal batches per group
-      c->stats.reserved[3] = st64[3] / ngroups;   // force-loop trips per group (max sub-group list length, summed)
+      c->stats.reserved[3] = st64[3] / ngroups;   // force-loop slots per lane and group
       // split walk: time of the evaluation / traversal kernels summed over the batches, and the batch count
       c->stats.reserved[4] = c->stats.reserved[5] = c->stats.reserved[6] = 0;
       for(int b = 0; b < c->walk_batches; b++)
