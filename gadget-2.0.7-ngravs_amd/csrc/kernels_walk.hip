@@ -711,9 +711,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
   const double BIG = 1e300;
   const double invbox = wp.box > 0 ? 1.0 / wp.box : 0.0;
   double h2max = 0;   // square of the largest softening length of any particle type (wave-uniform)
+  bool usoft = true;  // all types share one softening length
 #pragma unroll
   for(int q = 0; q < NGRAVS_NTYPES; q++)
-    h2max = fmax(h2max, wp.fsoft[q] * wp.fsoft[q]);
+    {
+      h2max = fmax(h2max, wp.fsoft[q] * wp.fsoft[q]);
+      usoft = usoft && wp.fsoft[q] == wp.fsoft[0];
+    }
 
   // XCD-aware group assignment: the Peano order is cut into 8 contiguous segments, one per XCD (own L2), and a
   // workgroup pulls groups from the segment of the XCD it runs on (neighbouring groups share most of their
@@ -1074,14 +1078,22 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           hs = 0;
           if(c0 + lane < n)
             {
-              if(item >= 0)
+              const int k = -1 - item;   // monopole: node * NG + g
+              if(usoft)
+                {
+                  // one softening length for all types: a single 32-byte gather per item, no type / flag bytes (each of
+                  // which would pull another cache line)
+                  const double4 *src = item >= 0 ? s_pm + item : tv.mom + k;
+                  q = *src;
+                  hs = wp.fsoft[0];
+                }
+              else if(item >= 0)
                 {
                   q = s_pm[item];
                   hs = wp.fsoft[s_type[item]];
                 }
               else
                 {
-                  const int k = -1 - item;   // node * NG + g
                   q = tv.mom[k];
                   hs = wp.fsoft[(tv.flags[k / NG] >> 2) & 7];
                 }
