@@ -1153,7 +1153,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
                 //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
                 unsigned int mlo = 0, mhi = 0;
-                if(fastmask && !(wp.dbg & (1 | 8)))   // NGRAVS_DEBUG bit 8: use the exact fp64 test below instead (tests)
+                const bool direct = !PM && S == 1 && !(wp.dbg & 5);   // tree-only: no masks at all (see the force loop)
+                if(direct)
+                  {
+                  }
+                else if(fastmask && !(wp.dbg & (1 | 8)))   // NGRAVS_DEBUG bit 8: use the exact fp64 test below instead (tests)
                   {
                     // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
                     // (v_alignbit), highest entry first so that entry j ends up in bit j
@@ -1218,9 +1222,39 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   }
                 // ---- force loop: every lane walks its own bits, ES per trip
                 unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & lane_pat;
-                nint += __popcll(m);   // evalN takes the (rare) slots beyond the exact cut off again
+                nint += direct ? (valid ? nc : 0) : __popcll(m);   // evalN takes the (rare) slots beyond the exact cut off again
                 if(wp.dbg & 4)         // debug: masks are built but not evaluated
                   m = 0;
+                if(direct)
+                  {
+                    // tree-only: every pool entry interacts with every target -- no masks to decode, all lanes read the
+                    // same entries (LDS broadcast)
+                    for(int j0 = 0; j0 < nc; j0 += ES)
+                      {
+                        st_iters += ES;
+                        bool act[ES];
+                        int jj[ES];
+                        double4 e[ES];
+#pragma unroll
+                        for(int k = 0; k < ES; k++)
+                          {
+                            act[k] = valid && j0 + k < nc;
+                            jj[k] = j0 + k < nc ? j0 + k : 127;   // 127: the NULL entry
+                            e[k] = pp[jj[k]];
+                          }
+                        if(!valid)   // a lane without a target must not accumulate
+                          {
+#pragma unroll
+                            for(int k = 0; k < ES; k++)
+                              e[k].w = 0.0;
+                          }
+                        if(lanewrap)
+                          evalN(std::true_type{}, g, e, jj, act);
+                        else
+                          evalN(std::false_type{}, g, e, jj, act);
+                      }
+                    m = 0;
+                  }
                 while(__any(m != 0 ? 1 : 0))
                   {
                     st_iters += ES;
