@@ -1488,17 +1488,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     it = -2 - (first + q);
                   itemv[q] = it;
                   const int sgq = (int)((sp8 >> (2 * q)) & 3u);
-                  if(it >= 0)
-                    cnt_pack += 1u;
-                  else if(it <= -2)
-                    {
-                      if(sgq == 0)
-                        cnt_pack += 1u << 10;
-                      else if(sgq == 1)
-                        cnt_pack += 1u << 20;
-                      else
-                        cnt_g2 += 1u;
-                    }
+                  const bool isp = it <= -2;
+                  cnt_pack += it >= 0 ? 1u : (isp && sgq < 2 ? (1u << 10) << (10 * sgq) : 0u);
+                  cnt_g2 += isp && sgq == 2 ? 1u : 0u;
                 }
               unsigned inc = cnt_pack, inc2 = cnt_g2;   // inclusive wave scans
 #pragma unroll
@@ -1522,26 +1514,30 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 }
               else
                 {
+                  // branch-free: the LIFO and the lists lie in one region, so every item is ONE predicated store to
+                  // rbase[offset], the offset picked by selects (a per-kind branch cascade costs four times the instructions)
+                  int *const rbase = stack;
+                  const int o_l0 = (int)(lists[0] - stack), o_l1 = NG > 1 ? (int)(lists[NG > 1 ? 1 : 0] - stack) : 0,
+                            o_l2 = NG > 2 ? (int)(lists[NG > 2 ? 2 : 0] - stack) : 0;
                   int on = sp + (int)(exc & 1023u);
-                  int op0 = n_items[0] + (int)((exc >> 10) & 1023u);
-                  int op1 = NG > 1 ? n_items[NG > 1 ? 1 : 0] + (int)((exc >> 20) & 1023u) : 0;
-                  int op2 = NG > 2 ? n_items[NG > 2 ? 2 : 0] + (int)exc2 : 0;
+                  int op0 = o_l0 + n_items[0] + (int)((exc >> 10) & 1023u);
+                  int op1 = NG > 1 ? o_l1 + n_items[NG > 1 ? 1 : 0] + (int)((exc >> 20) & 1023u) : 0;
+                  int op2 = NG > 2 ? o_l2 + n_items[NG > 2 ? 2 : 0] + (int)exc2 : 0;
 #pragma unroll
                   for(int q = 0; q < 8; q++)
                     {
                       const int it = itemv[q];
                       const int sgq = (int)((sp8 >> (2 * q)) & 3u);
-                      if(it >= 0)
-                        STK(on++) = it;
-                      else if(it <= -2)
-                        {
-                          if(sgq == 0)
-                            lists[0][op0++] = -2 - it;
-                          else if(NG > 1 && sgq == 1)
-                            lists[NG > 1 ? 1 : 0][op1++] = -2 - it;
-                          else if(NG > 2)
-                            lists[NG > 2 ? 2 : 0][op2++] = -2 - it;
-                        }
+                      const bool isn = it >= 0, isp = it <= -2;
+                      const bool p0 = isp && sgq == 0, p1 = NG > 1 && isp && sgq == 1, p2 = NG > 2 && isp && sgq == 2;
+                      const int off = isn ? on : (p0 ? op0 : (p1 ? op1 : op2));
+                      const int val = isn ? it : -2 - it;
+                      if(isn || isp)
+                        rbase[off] = val;
+                      on += isn ? 1 : 0;
+                      op0 += p0 ? 1 : 0;
+                      op1 += p1 ? 1 : 0;
+                      op2 += p2 ? 1 : 0;
                     }
                   sp += tn;
                   n_items[0] += (int)((tot >> 10) & 1023u);
