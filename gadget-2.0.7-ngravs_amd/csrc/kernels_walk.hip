@@ -1456,17 +1456,22 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           unsigned sp8 = 0;
           if(NG > 1)
             {
+              // unconditional loads (index 0 when there is nothing to look up): all eight are in flight before the first
+              // is used; a predicated load per slot made the compiler wait for each in turn
+              unsigned char ty8[8];
 #pragma unroll
               for(int q = 0; q < 8; q++)
                 {
-                  int pi = -1;
+                  int pi = 0;
                   if(dec == 2 && chv[q] <= -2)
                     pi = -2 - chv[q];
                   if(dec == 3 && q < count)
                     pi = first + q;
-                  if(pi >= 0)
-                    sp8 |= ((wp.t2g_packed >> (2 * s_type[pi])) & 3u) << (2 * q);
+                  ty8[q] = s_type[pi];
                 }
+#pragma unroll
+              for(int q = 0; q < 8; q++)
+                sp8 |= ((wp.t2g_packed >> (2 * ty8[q])) & 3u) << (2 * q);   // only the fields of real items are read later
             }
           // ---- append: every lane holds up to 8 things to record -- child nodes for the LIFO (dec 2) and particles for the
           //      item lists (children of an opened node, or the first 8 particles of a small node's range, dec 3).  One packed
