@@ -48,7 +48,7 @@ def walk_traffic(args, n, world, launches):
     """HBM-side bytes per launch of the walk's evaluation kernel from the committed rocprofv3 --pmc passes (profiles/),
     only when the run IS that workload (PMC counters cannot be collected inside this process); rescaled if the step is
     cut into a different number of launches than when it was profiled"""
-    path = os.path.join(ROOT, "profiles", "r01f_walk_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01h_walk_traffic.json")
     if args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and os.path.exists(path):
         with open(path) as f:
             d = json.load(f)
