@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                             open = (fabs(cx) - bhx < 0.60 * len) && (fabs(cy) - bhy < 0.60 * len) &&
                                    (fabs(cz) - bhz < 0.60 * len);
                         }
-                      const double hs_node = wp.fsoft[mst];
+                      const double hs_node = usoft ? wp.fsoft[0] : wp.fsoft[mst];   // no dependent table load when all types share one length
                       if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
                         open = true;
                       if(open)
