@@ -514,3 +514,36 @@ def test_no_or_one_active_particle(pkg, O):
         assert np.all(acc[k:] == 0) and np.all(cost[k:] == 0)
         if k:
             assert rel_err(acc[:1], a_full[:1]).max() < 2e-2 and cost[0] > 0
+
+
+def test_group_walk_unequal_softenings(pkg, O):
+    """UNEQUALSOFTENINGS with really different lengths per type (pair softening = max of the two, forcetree.c:1415-1417;
+    nodes with mixed softenings are opened inside the larger one, :1488-1499): the group walk's general paths (per-item
+    type / flag lookups, per-pair softening in the force loop) against the strict walk and the periodic direct sum"""
+    n, L, ng = 30000, 1.0, 2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=12)
+    sp = L / n ** (1 / 3)
+    soft = [0.0, 0.5 * sp, 0.1 * sp, 0.5 * sp, 0.5 * sp, 0.5 * sp]       # type 1: half a spacing, type 2: a tenth
+    kw = dict(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=soft,
+              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4")
+    idx = np.arange(0, n, 60, dtype=np.int32)
+    out = {}
+    for mode in (pkg.WALK_STRICT, pkg.WALK_GROUP):
+        eng = _engine(pkg, pkg.make_config(walk_mode=mode, **kw), pos, mass, typ)
+        eng.compute_accelerations(pm_step=True)
+        _, old, _ = eng.get_accel()
+        eng.set_opening(0.0, 0.005)
+        eng.set_old_acc(old)
+        eng.compute_accelerations(pm_step=True)
+        acc, _, cost, pm = eng.get_accel(want_pm=True)
+        truth = eng.direct_sum(idx)
+        eng.close()
+        out[mode] = (acc + pm, cost, truth)
+    rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
+    assert rel_err(out[pkg.WALK_STRICT][2], out[pkg.WALK_GROUP][2]).max() < 1e-12      # same direct sum
+    e_s = rel_err(out[pkg.WALK_STRICT][0][idx], out[pkg.WALK_STRICT][2])
+    e_g = rel_err(out[pkg.WALK_GROUP][0][idx], out[pkg.WALK_GROUP][2])
+    d = rel_err(out[pkg.WALK_GROUP][0], out[pkg.WALK_STRICT][0])
+    print("unequal softenings: strict rms %.2e, group rms %.2e vs periodic direct sum; group vs strict median %.1e; ia %.0f / %.0f"
+          % (rms(e_s), rms(e_g), np.median(d), out[pkg.WALK_STRICT][1].mean(), out[pkg.WALK_GROUP][1].mean()))
+    assert rms(e_g) <= 1.05 * rms(e_s) + 1e-3 and np.median(d) < 1e-2
