@@ -643,7 +643,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
   const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *expT = reinterpret_cast<double *>(smem + tab_bytes);
-  unsigned char *wbase = smem + tab_bytes + 32 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
+  unsigned char *wbase = smem + tab_bytes + 40 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
+  double *fsT = expT + 32;   // softening length per particle type (8 entries; index 7 = empty node)
   double4 *lpos = reinterpret_cast<double4 *>(wbase);
   double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE);
   float *lfx = reinterpret_cast<float *>(wbase + (sizeof(double4) + sizeof(double)) * 2 * WAVE);
@@ -652,6 +653,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     {
       if(threadIdx.x < 32)
         expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
+      if(threadIdx.x >= 32 && threadIdx.x < 40)
+        fsT[threadIdx.x - 32] = threadIdx.x - 32 < NGRAVS_NTYPES ? wp.fsoft[threadIdx.x - 32] : 0.0;
       if(PM && TAB_LDS)
         for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
           {
@@ -1087,15 +1090,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   q = *src;
                   hs = wp.fsoft[0];
                 }
-              else if(item >= 0)
-                {
-                  q = s_pm[item];
-                  hs = wp.fsoft[s_type[item]];
-                }
               else
                 {
-                  q = tv.mom[k];
-                  hs = wp.fsoft[(tv.flags[k / NG] >> 2) & 7];
+                  // record and type / flag word are fetched together; the softening length comes from the LDS copy of the
+                  // table (a lookup in the kernel arguments would be a third, dependent, memory round trip)
+                  const bool isp = item >= 0;
+                  const double4 *src = isp ? s_pm + item : tv.mom + k;
+                  q = *src;
+                  int ty;
+                  if(isp)
+                    ty = s_type[item];
+                  else
+                    ty = (tv.flags[k / NG] >> 2) & 7;
+                  hs = fsT[ty];
                 }
             }
         };
@@ -1990,7 +1997,7 @@ static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nul
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 40 * sizeof(double);
   // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
   int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   int per_cu = 1;
@@ -2028,7 +2035,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 32 * sizeof(double);
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 40 * sizeof(double);
   int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   if(waves > GW2_MAXWAVES)
     waves = GW2_MAXWAVES;   // register-limited: 4 waves per SIMD (__launch_bounds__), one workgroup per CU
