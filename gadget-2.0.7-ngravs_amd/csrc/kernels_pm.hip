@@ -195,12 +195,15 @@ __global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned 
   i += first;
   if(s_flag[i] & 2)
     {
-      if(species == 0)
+      if(species <= 0)
         r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
       return;
     }
-  if(t2g_tab[s_type[i]] != species)
+  const int g = t2g_tab[s_type[i]];
+  if(species >= 0 && g != species)
     return;
+  if(species < 0)   // all species' force meshes are resident: [g][N][N][N][3]
+    fm += (size_t)g * 3 * N * N * N;
   const double4 p = s_pm[i];
   double dx, dy, dz;
   int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
@@ -632,8 +635,19 @@ int pm_finish(ngravs_ctx *c)
       // two passes per target species (see k_force_mesh); with many tasks the (replicated) force-mesh pass would cost more
       // than the sharded fused gather below
       const long long NN = (long long)N * N * N;
-      if(c->pm_force.ensure((size_t)(3 * NN)))
+      const bool all_resident = (size_t)3 * NN * ng * sizeof(double) <= ((size_t)16 << 30);   // C4: 6.4 GB; C5 (77 GB): per species
+      if(c->pm_force.ensure((size_t)(3 * NN) * (all_resident ? ng : 1)))
         return NGRAVS_ERR_NOMEM;
+      if(all_resident)
+        {
+          for(int b = 0; b < ng; b++)
+            hipLaunchKernelGGL(k_force_mesh, dim3((unsigned)((NN + bs - 1) / bs)), dim3(bs), 0, c->stream, c->pm_phi.p + real_elems * b, N,
+                               fac, c->pm_force.p + (size_t)3 * NN * b);
+          hipLaunchKernelGGL(k_gather_force, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
+                             (long long)c->shard_first, (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, -1, c->pm_force.p,
+                             c->r_pm.p);
+        }
+      else
       for(int b = 0; b < ng; b++)
         {
           hipLaunchKernelGGL(k_force_mesh, dim3((unsigned)((NN + bs - 1) / bs)), dim3(bs), 0, c->stream, c->pm_phi.p + real_elems * b, N,
