@@ -149,10 +149,10 @@ def main():
     ap.add_argument("--wiring", default="c4")
     ap.add_argument("--walk", default="group", choices=["group", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decomp", default="replicated", choices=["replicated", "domain"],
-                    help="N>1: 'replicated' = every rank holds all particles, the walk is sharded (default, no data-path "
-                         "collective); 'domain' = Peano-Hilbert domain decomposition with migration + halo all-to-all-v and "
-                         "an all-reduced PM mesh (memory-scalable; see DESIGN.md Multi-GPU)")
+    ap.add_argument("--decomp", default=None, choices=["replicated", "domain"],
+                    help="N>1: 'domain' (default) = work-weighted Peano-Hilbert domain decomposition: migration + short-range halo "
+                         "all-to-all-v, x-slab decomposed PM with four plane exchanges (DESIGN.md Multi-GPU); 'replicated' = every "
+                         "rank holds all particles and only the walk is sharded (no data-path collective; tree-only configs)")
     ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 (default, the metric's) | c3: 16M N_GRAVS=1 PMGRID=256 | c2: 4M Plummer tree-only")
     args = ap.parse_args()
@@ -219,6 +219,8 @@ def main():
     d_type = torch.from_numpy(ptype).to(dev)
     d_old = torch.zeros(n, dtype=torch.float64, device=dev)
     del pos, mass, ptype
+    if args.decomp is None:
+        args.decomp = "domain" if world > 1 and not treeonly else "replicated"
     domain = args.decomp == "domain" and world > 1 and not treeonly
     if domain:
         import importlib

@@ -25,7 +25,9 @@ _LIB = None
 # every symbol include/ngravs_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "ngravs_abi_version", "ngravs_build_info", "ngravs_config_default", "ngravs_create", "ngravs_destroy",
-    "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_particles",
+    "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_get_config", "ngravs_set_tuning",
+    "ngravs_memcpy",
+    "ngravs_set_particles",
     "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition",
     "ngravs_force_treebuild", "ngravs_gravity_tree",
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
@@ -33,8 +35,12 @@ EXPORTS = [
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_dd_histogram", "ngravs_dd_pack",
     "ngravs_dd_apply_migration", "ngravs_dd_set_halo", "ngravs_dd_set_ids", "ngravs_dd_get_ids",
-    "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
+    "ngravs_dd_recv_buffer", "ngravs_dd_get_dest", "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
+    "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
+# include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
+HOST_EXPORTS = ["ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
+                "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split"]
 
 
 class NgravsError(RuntimeError):
@@ -72,7 +78,9 @@ def lib():
         L.ngravs_set_particles.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_set_old_acc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.ngravs_get_accel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                       C.c_void_p, C.c_int64, C.c_int]
+                                       C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.ngravs_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.ngravs_memcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.ngravs_get_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_get_domain.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_get_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -83,7 +91,9 @@ def lib():
         L.ngravs_direct_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ngravs_dd_local_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_dd_set_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.ngravs_dd_histogram.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ngravs_dd_histogram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.ngravs_get_config.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_host_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p]
         L.ngravs_dd_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         L.ngravs_dd_apply_migration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -157,8 +167,7 @@ class Engine:
             raise NgravsError("%s failed: status %d (%s)" % (what, rc, msg.decode() if msg else ""))
 
     # -- P[] hand-over ------------------------------------------------------------------------
-    def set_particles(self, pos, mass, ptype, old_acc=None, active=None):
-        """numpy (host) columns; strides are taken from the arrays, so AoS views work."""
+    def _host_columns(self, pos, mass, ptype, old_acc, active, grav_pm, grav_cost=None):
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         mass = np.ascontiguousarray(mass, dtype=np.float64)
         ptype = np.ascontiguousarray(ptype, dtype=np.int32)
@@ -176,39 +185,35 @@ class Engine:
             active = np.ascontiguousarray(active, dtype=np.uint8)
             p.active, p.active_stride = active.ctypes.data, 1
             keep.append(active)
+        if grav_pm is not None:
+            grav_pm = np.ascontiguousarray(grav_pm, dtype=np.float64)
+            p.grav_pm, p.grav_pm_stride = grav_pm.ctypes.data, 24
+            keep.append(grav_pm)
+        if grav_cost is not None:
+            grav_cost = np.ascontiguousarray(grav_cost, dtype=np.float32)
+            p.grav_cost, p.grav_cost_stride = grav_cost.ctypes.data, 4
+            keep.append(grav_cost)
         p.on_device = 0
         self._keep = keep
+        return p
+
+    def set_particles(self, pos, mass, ptype, old_acc=None, active=None, grav_pm=None, grav_cost=None):
+        """numpy (host) columns (the fields of P[] the path reads); grav_pm = P[].GravPM of the last PM step, if any;
+        grav_cost = P[].GravCost (the work weight of the multi-task domain cut)"""
+        p = self._host_columns(pos, mass, ptype, old_acc, active, grav_pm, grav_cost)
         self.n = p.n
         self._check(lib().ngravs_set_particles(self._h, C.byref(p)), "ngravs_set_particles")
 
     def update_particles(self, pos, mass, ptype, old_acc=None, active=None):
         """same particles, new positions / OldAcc / active flags: the decomposition and the tree topology are kept
         (drifted tree, TreeDomainUpdateFrequency > 0); gravity_tree() / pmforce_periodic() refit the nodes first"""
-        pos = np.ascontiguousarray(pos, dtype=np.float64)
-        mass = np.ascontiguousarray(mass, dtype=np.float64)
-        ptype = np.ascontiguousarray(ptype, dtype=np.int32)
-        p = Particles()
-        p.n = len(pos)
-        p.pos, p.pos_stride = pos.ctypes.data, 24
-        p.mass, p.mass_stride = mass.ctypes.data, 8
-        p.type, p.type_stride = ptype.ctypes.data, 4
-        keep = [pos, mass, ptype]
-        if old_acc is not None:
-            old_acc = np.ascontiguousarray(old_acc, dtype=np.float64)
-            p.old_acc, p.old_acc_stride = old_acc.ctypes.data, 8
-            keep.append(old_acc)
-        if active is not None:
-            active = np.ascontiguousarray(active, dtype=np.uint8)
-            p.active, p.active_stride = active.ctypes.data, 1
-            keep.append(active)
-        p.on_device = 0
-        self._keep = keep
+        p = self._host_columns(pos, mass, ptype, old_acc, active, None)
         self._check(lib().ngravs_update_particles(self._h, C.byref(p)), "ngravs_update_particles")
 
     def force_update_tree(self):
         self._check(lib().ngravs_force_update_tree(self._h), "ngravs_force_update_tree")
 
-    def set_particles_device(self, n, pos_ptr, mass_ptr, type_ptr, old_acc_ptr=None, active_ptr=None):
+    def set_particles_device(self, n, pos_ptr, mass_ptr, type_ptr, old_acc_ptr=None, active_ptr=None, grav_pm_ptr=None):
         """HIP device pointers (e.g. torch tensors' data_ptr()): zero-copy hand-over."""
         p = Particles()
         p.n = n
@@ -219,6 +224,8 @@ class Engine:
             p.old_acc, p.old_acc_stride = old_acc_ptr, 8
         if active_ptr:
             p.active, p.active_stride = active_ptr, 1
+        if grav_pm_ptr:
+            p.grav_pm, p.grav_pm_stride = grav_pm_ptr, 24
         p.on_device = 1
         self.n = n
         self._check(lib().ngravs_set_particles(self._h, C.byref(p)), "ngravs_set_particles")
@@ -233,10 +240,10 @@ class Engine:
 
     def get_old_acc_device(self, ptr):
         """write OldAcc (caller order) to a HIP device pointer"""
-        self._check(lib().ngravs_get_accel(self._h, None, 0, None, 0, ptr, 8, None, 0, 1), "ngravs_get_accel")
+        self._check(lib().ngravs_get_accel(self._h, None, 0, None, 0, ptr, 8, None, 0, 1, 0), "ngravs_get_accel")
 
-    def get_accel_device(self, acc_ptr=None, pm_ptr=None, old_ptr=None, cost_ptr=None):
-        self._check(lib().ngravs_get_accel(self._h, acc_ptr, 24, pm_ptr, 24, old_ptr, 8, cost_ptr, 4, 1),
+    def get_accel_device(self, acc_ptr=None, pm_ptr=None, old_ptr=None, cost_ptr=None, only_active=False):
+        self._check(lib().ngravs_get_accel(self._h, acc_ptr, 24, pm_ptr, 24, old_ptr, 8, cost_ptr, 4, 1, int(only_active)),
                     "ngravs_get_accel")
 
     def set_opening(self, theta, err_tol_force_acc):
@@ -246,6 +253,11 @@ class Engine:
 
     def set_walk_mode(self, mode):
         self._check(lib().ngravs_set_walk_mode(self._h, mode), "ngravs_set_walk_mode")
+
+    def set_tuning(self, **kw):
+        """ngravs_set_tuning(): e.g. set_tuning(walk_lcap=1024, walk_compact=0)"""
+        for k, v in kw.items():
+            self._check(lib().ngravs_set_tuning(self._h, k.encode(), float(v)), "ngravs_set_tuning(%s)" % k)
 
     # -- the reference's entry points (proto.h names) ---------------------------------------------
     def domain_Decomposition(self):
@@ -267,20 +279,27 @@ class Engine:
         self._check(lib().ngravs_compute_accelerations(self._h, 1 if pm_step else 0), "compute_accelerations")
 
     # -- results -------------------------------------------------------------------------------------
-    def get_accel(self, want_pm=False):
-        """(GravAccel[N,3], OldAcc[N], GravCost[N]) [+ GravPM[N,3]] in the caller's particle order."""
+    def get_accel(self, want_pm=False, into=None):
+        """(GravAccel[N,3], OldAcc[N], GravCost[N]) [+ GravPM[N,3]] in the caller's particle order.
+        into=(acc, old, cost): write ONLY the rows of active particles into these existing arrays, as the reference
+        does with P[] (gravtree.c:318-341); otherwise fresh arrays, rows that were not walked read 0 / the input OldAcc."""
         n = self.n
-        acc = np.zeros((n, 3))
-        old = np.zeros(n)
-        cost = np.zeros(n, dtype=np.float32)
+        if into is not None:
+            acc, old, cost = into
+            assert acc.dtype == np.float64 and old.dtype == np.float64 and cost.dtype == np.float32
+            assert acc.flags.c_contiguous and old.flags.c_contiguous and cost.flags.c_contiguous
+        else:
+            acc = np.zeros((n, 3))
+            old = np.zeros(n)
+            cost = np.zeros(n, dtype=np.float32)
         pm = np.zeros((n, 3)) if want_pm else None
         self._check(lib().ngravs_get_accel(self._h, acc.ctypes.data, 24, _ptr(pm), 24, old.ctypes.data, 8,
-                                           cost.ctypes.data, 4, 0), "ngravs_get_accel")
+                                           cost.ctypes.data, 4, 0, 1 if into is not None else 0), "ngravs_get_accel")
         return (acc, old, cost, pm) if want_pm else (acc, old, cost)
 
     def get_pm(self):
         pm = np.zeros((self.n, 3))
-        self._check(lib().ngravs_get_accel(self._h, None, 0, pm.ctypes.data, 24, None, 0, None, 0, 0), "ngravs_get_accel")
+        self._check(lib().ngravs_get_accel(self._h, None, 0, pm.ctypes.data, 24, None, 0, None, 0, 0, 0), "ngravs_get_accel")
         return pm
 
     def stats(self):

@@ -5,7 +5,7 @@ compiled library (ngravs_build_info) so that a drift is caught on CPU.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_GRAVS = 3
 NTYPES = 6
 NTAB = 2048
@@ -46,6 +46,8 @@ class Particles(C.Structure):
         ("type", C.c_void_p), ("type_stride", C.c_int64),
         ("old_acc", C.c_void_p), ("old_acc_stride", C.c_int64),
         ("active", C.c_void_p), ("active_stride", C.c_int64),
+        ("grav_pm", C.c_void_p), ("grav_pm_stride", C.c_int64),
+        ("grav_cost", C.c_void_p), ("grav_cost_stride", C.c_int64),
         ("on_device", C.c_int32), ("reserved", C.c_int32),
     ]
 

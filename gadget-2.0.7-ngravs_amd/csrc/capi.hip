@@ -28,17 +28,61 @@ __global__ void k_pack_strided_f64(const unsigned char *src, long long stride, i
   for(int k = 0; k < ncomp; k++)
     dst[i * ncomp + k] = s[k];
 }
-__global__ void k_pack_strided_i32(const unsigned char *src, long long stride, long long n, int *dst)
+// Type column: values outside 0..5 would index fsoft[] / t2g[] out of bounds; they are counted (the host path
+// rejects them before the upload) and clamped
+__global__ void k_pack_type(const unsigned char *src, long long stride, long long n, int *dst, int *nbad)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i < n)
-    dst[i] = *reinterpret_cast<const int *>(src + i * stride);
+  if(i >= n)
+    return;
+  int t = *reinterpret_cast<const int *>(src + i * stride);
+  if(t < 0 || t >= NGRAVS_NTYPES)
+    {
+      atomicAdd(nbad, 1);
+      t = t < 0 ? 0 : NGRAVS_NTYPES - 1;
+    }
+  dst[i] = t;
 }
-__global__ void k_pack_strided_u8(const unsigned char *src, long long stride, long long n, unsigned char *dst)
+// active flag: only bit 0 is the caller's (bit 1 marks halo copies inside the engine)
+__global__ void k_pack_active(const unsigned char *src, long long stride, long long n, unsigned char *dst)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i < n)
-    dst[i] = src[i * stride];
+    dst[i] = src[i * stride] ? 1 : 0;
+}
+// rows of the caller-order result that belong to active particles only (gravtree.c:318-341 touch nothing else)
+__global__ void k_copy_masked_f64(const unsigned char *__restrict__ act, long long n, int ncomp, const double *__restrict__ src,
+                                  double *__restrict__ dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n || !(act[i] & 1))
+    return;
+  for(int k = 0; k < ncomp; k++)
+    dst[i * ncomp + k] = src[i * ncomp + k];
+}
+__global__ void k_copy_masked_f32(const unsigned char *__restrict__ act, long long n, const float *__restrict__ src, float *__restrict__ dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n && (act[i] & 1))
+    dst[i] = src[i];
+}
+__global__ void k_pack_strided_f32_to_f64(const unsigned char *src, long long stride, long long n, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i < n)
+    dst[i] = (double)*reinterpret_cast<const float *>(src + i * stride);
+}
+// GravCost of the walked particles -> the work-weight column (caller order); other rows keep theirs (gravtree.c:387-392 updates
+// P[].GravCost of active particles only)
+__global__ void k_cost_update(const unsigned int *__restrict__ idx, const unsigned char *__restrict__ act, const int *__restrict__ nint,
+                              long long first, long long count, double *__restrict__ cost)
+{
+  long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(k >= count)
+    return;
+  const long long i = first + k;
+  if(act[i] & 1)
+    cost[idx[i]] = (double)nint[i];
 }
 __global__ void k_fill_f64(double *p, long long n, double v)
 {
@@ -257,6 +301,8 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   pm_release(c);
+  pmslab_release(c);
+  c->in_cost.release();
   c->in_pos.release();
   c->in_mass.release();
   c->in_oldacc.release();
@@ -270,6 +316,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->dd_owner_ph.release();
   c->dd_owner_xyz.release();
   c->dd_send.release();
+  c->dd_recv.release();
   c->s_pm.release();
   c->s_type.release();
   c->s_active.release();
@@ -340,6 +387,71 @@ extern "C" int ngravs_set_walk_mode(ngravs_ctx *c, int mode)
   return NGRAVS_OK;
 }
 
+extern "C" int ngravs_get_config(ngravs_ctx *c, ngravs_config_t *out)
+{
+  if(!c || !out)
+    return NGRAVS_ERR_ARG;
+  *out = c->cfg;
+  if(c->cfg.pmgrid)
+    {
+      out->asmth = c->asmth;
+      out->rcut = c->rcut;
+    }
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
+{
+  if(!c || !name)
+    return NGRAVS_ERR_ARG;
+  const std::string k(name);
+  const long long iv = (long long)v;
+  Tuning &t = c->tune;
+  if(k == "walk_fused")
+    t.walk_fused = iv != 0;
+  else if(k == "walk_batch" && iv >= 0)
+    t.walk_batch = iv;
+  else if(k == "walk_waves" && iv >= 0 && iv <= 16)
+    t.walk_waves = (int)iv;
+  else if(k == "walk_lcap" && (iv == 0 || (iv >= 1024 && iv <= 65536)))
+    {
+      t.walk_lcap = (int)iv;
+      c->walk_lcap = 0;   // re-initialised by the next split walk
+    }
+  else if(k == "walk_root")
+    t.walk_root = iv != 0;
+  else if(k == "walk_compact")
+    t.walk_compact = iv != 0;
+  else if(k == "walk_spread" && iv >= 0 && iv <= 64 && (iv & (iv - 1)) == 0)
+    t.walk_spread = (int)iv;
+  else if(k == "walk_exact_reach")
+    t.walk_exact_reach = iv != 0;
+  else if(k == "pm_notile")
+    t.pm_notile = iv != 0;
+  else if(k == "pm_fused_gather")
+    t.pm_fused_gather = iv != 0;
+  else if(k == "pm_tile_gather")
+    t.pm_tile_gather = iv != 0;
+  else
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "ngravs_set_tuning: unknown name or value out of range: " + k);
+      return NGRAVS_ERR_ARG;
+    }
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_memcpy(ngravs_ctx *c, void *dst, const void *src, int64_t bytes, int kind)
+{
+  if(!c || bytes < 0 || kind < 1 || kind > 3 || (bytes > 0 && (!dst || !src)))
+    return NGRAVS_ERR_ARG;
+  if(bytes == 0)
+    return NGRAVS_OK;
+  (void)hipSetDevice(c->cfg.device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(dst, src, (size_t)bytes, kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice)));
+  return NGRAVS_OK;
+}
+
 // ---- data hand-over -----------------------------------------------------------------------------
 static int upload_column_f64(ngravs_ctx *c, const void *src, int64_t stride, int ncomp, int64_t n, int on_device, double *dst)
 {
@@ -385,7 +497,8 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
     }
   (void)hipSetDevice(c->cfg.device);
   const int64_t n = p->n;
-  if(c->in_pos.ensure(3 * n) || c->in_mass.ensure(n) || c->in_oldacc.ensure(n) || c->in_type.ensure(n) || c->in_active.ensure(n))
+  if(c->in_pos.ensure(3 * n) || c->in_mass.ensure(n) || c->in_oldacc.ensure(n) || c->in_type.ensure(n) || c->in_active.ensure(n) ||
+     (!keep_tree && c->in_cost.ensure(n)))
     {
       ngravs_report(c, NGRAVS_ERR_NOMEM, "device allocation failed");
       return NGRAVS_ERR_NOMEM;
@@ -406,10 +519,44 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
     }
   else
     hipLaunchKernelGGL(k_fill_f64, GRID1(n), 0, c->stream, c->in_oldacc.p, (long long)n, 0.0);
+  if(!keep_tree)
+    {
+      if(p->grav_cost && p->on_device)
+        hipLaunchKernelGGL(k_pack_strided_f32_to_f64, GRID1(n), 0, c->stream, (const unsigned char *)p->grav_cost,
+                           (long long)p->grav_cost_stride, (long long)n, c->in_cost.p);
+      else if(p->grav_cost)
+        {
+          c->host_stage.resize(sizeof(double) * (size_t)n);
+          double *h = reinterpret_cast<double *>(c->host_stage.data());
+          for(int64_t i = 0; i < n; i++)
+            {
+              float f;
+              memcpy(&f, (const unsigned char *)p->grav_cost + i * p->grav_cost_stride, sizeof(float));
+              h[i] = f;
+            }
+          HIP_TRY(c, hipMemcpyAsync(c->in_cost.p, h, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+          HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+      else
+        hipLaunchKernelGGL(k_fill_f64, GRID1(n), 0, c->stream, c->in_cost.p, (long long)n, 0.0);
+    }
   // Type (int32)
   if(p->on_device)
-    hipLaunchKernelGGL(k_pack_strided_i32, GRID1(n), 0, c->stream, (const unsigned char *)p->type, (long long)p->type_stride,
-                       (long long)n, c->in_type.p);
+    {
+      if(c->d_counters.ensure(16))
+        return NGRAVS_ERR_NOMEM;
+      int nbad = 0;
+      HIP_TRY(c, hipMemsetAsync(c->d_counters.p + 15, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_pack_type, GRID1(n), 0, c->stream, (const unsigned char *)p->type, (long long)p->type_stride,
+                         (long long)n, c->in_type.p, c->d_counters.p + 15);
+      HIP_TRY(c, hipMemcpyAsync(&nbad, c->d_counters.p + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if(nbad)
+        {
+          ngravs_report(c, NGRAVS_ERR_ARG, "particle Type outside 0..5");
+          return NGRAVS_ERR_ARG;
+        }
+    }
   else
     {
       c->host_stage.resize(sizeof(int) * (size_t)n);
@@ -430,7 +577,7 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   if(p->active)
     {
       if(p->on_device)
-        hipLaunchKernelGGL(k_pack_strided_u8, GRID1(n), 0, c->stream, (const unsigned char *)p->active,
+        hipLaunchKernelGGL(k_pack_active, GRID1(n), 0, c->stream, (const unsigned char *)p->active,
                            (long long)p->active_stride, (long long)n, c->in_active.p);
       else
         {
@@ -448,7 +595,20 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   if(keep_tree)
     c->tree_stale = true;    // same order and topology; columns and moments are refreshed by ngravs_force_update_tree
   else
-    c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over
+    {
+      c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over ...
+      c->pm_parked = false;
+      if(p->grav_pm && c->cfg.pmgrid)
+        {
+          // ... except P[].GravPM, which the host keeps between PM steps: parked in caller order, permuted into the Peano
+          // order by the next ngravs_domain_decomposition (OldAcc on non-PM steps needs it, gravtree.c:318-330)
+          if(c->pm_orig.ensure(3 * n))
+            return NGRAVS_ERR_NOMEM;
+          if((rc = upload_column_f64(c, p->grav_pm, p->grav_pm_stride, 3, n, p->on_device, c->pm_orig.p)))
+            return rc;
+          c->pm_parked = true;
+        }
+    }
   return NGRAVS_OK;
 }
 
@@ -513,8 +673,11 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
         return NGRAVS_ERR_NOMEM;
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->r_pm.p, c->pm_orig.p);
     }
+  else if(c->pm_parked && keep_pm && c->n == c->n_local)
+    c->have_pm = true;   // GravPM handed over with the particles (ngravs_particles_t.grav_pm)
   else
     c->have_pm = false;
+  c->pm_parked = false;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   int rc = dom_find_extent(c);
   if(rc)
@@ -622,6 +785,9 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
   c->stats.interactions = h[0];
   c->stats.n_active = (int64_t)h[1];
   c->have_acc = true;
+  if(c->shard_count > 0)
+    hipLaunchKernelGGL(k_cost_update, GRID1(c->shard_count), 0, c->stream, c->s_idx.p, c->s_active.p, c->r_nint.p,
+                       (long long)c->shard_first, (long long)c->shard_count, c->in_cost.p);
   return NGRAVS_OK;
 }
 
@@ -691,8 +857,41 @@ static int download_strided(ngravs_ctx *c, const void *dsrc, size_t elem, int nc
   return NGRAVS_OK;
 }
 
+// device result column (caller order, contiguous) -> the caller's array; with a mask only the rows of active particles
+static int deliver(ngravs_ctx *c, const void *dsrc, size_t elem, int ncomp, int64_t n, void *dst, int64_t stride, int on_device,
+                   const unsigned char *d_mask)
+{
+  if(!d_mask)
+    return download_strided(c, dsrc, elem, ncomp, n, dst, stride, on_device);
+  const size_t row = elem * ncomp;
+  if(on_device)
+    {
+      if((size_t)stride != row)
+        {
+          ngravs_report(c, NGRAVS_ERR_ARG, "device outputs must be contiguous");
+          return NGRAVS_ERR_ARG;
+        }
+      if(elem == sizeof(double))
+        hipLaunchKernelGGL(k_copy_masked_f64, GRID1(n), 0, c->stream, d_mask, (long long)n, ncomp, (const double *)dsrc, (double *)dst);
+      else
+        hipLaunchKernelGGL(k_copy_masked_f32, GRID1(n), 0, c->stream, d_mask, (long long)n, (const float *)dsrc, (float *)dst);
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      return NGRAVS_OK;
+    }
+  c->host_stage.resize(row * (size_t)n + (size_t)n);
+  unsigned char *hm = c->host_stage.data() + row * (size_t)n;
+  HIP_TRY(c, hipMemcpyAsync(c->host_stage.data(), dsrc, row * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(hm, d_mask, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for(int64_t i = 0; i < n; i++)
+    if(hm[i] & 1)
+      memcpy((unsigned char *)dst + i * stride, c->host_stage.data() + i * row, row);
+  return NGRAVS_OK;
+}
+
 extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel_stride, double *grav_pm, int64_t pm_stride,
-                                double *old_acc, int64_t old_acc_stride, float *grav_cost, int64_t cost_stride, int on_device)
+                                double *old_acc, int64_t old_acc_stride, float *grav_cost, int64_t cost_stride, int on_device,
+                                int only_active)
 {
   if(!c || !c->have_order)
     return NGRAVS_ERR_STATE;
@@ -700,6 +899,8 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
   const int64_t n = c->n;
   if(c->out_tmp.ensure(3 * n) || c->out_tmpf.ensure(n))
     return NGRAVS_ERR_NOMEM;
+  // in_active is the caller-order flag column of the last hand-over (bit 1: halo copies, never written)
+  const unsigned char *mask = (only_active && !(c->all_active && c->n_local == c->n)) ? c->in_active.p : nullptr;
   int rc;
   if(grav_accel)
     {
@@ -707,7 +908,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
         return NGRAVS_ERR_STATE;
       HIP_TRY(c, hipMemsetAsync(c->out_tmp.p, 0, sizeof(double) * 3 * n, c->stream));
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_acc.p, c->out_tmp.p);
-      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 3, n, grav_accel, accel_stride, on_device)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, n, grav_accel, accel_stride, on_device, mask)))
         return rc;
     }
   if(grav_pm)
@@ -715,16 +916,15 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
       if(!c->have_pm)
         return NGRAVS_ERR_STATE;
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_pm.p, c->out_tmp.p);
-      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 3, n, grav_pm, pm_stride, on_device)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, n, grav_pm, pm_stride, on_device, nullptr)))
         return rc;
     }
   if(old_acc)
     {
       if(!c->have_acc)
         return NGRAVS_ERR_STATE;
-      HIP_TRY(c, hipMemsetAsync(c->out_tmp.p, 0, sizeof(double) * n, c->stream));
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 1, c->r_oldacc.p, c->out_tmp.p);
-      if((rc = download_strided(c, c->out_tmp.p, sizeof(double), 1, n, old_acc, old_acc_stride, on_device)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 1, n, old_acc, old_acc_stride, on_device, mask)))
         return rc;
     }
   if(grav_cost)
@@ -732,7 +932,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
       if(!c->have_acc)
         return NGRAVS_ERR_STATE;
       hipLaunchKernelGGL(k_unpermute_i2f, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, c->r_nint.p, c->out_tmpf.p);
-      if((rc = download_strided(c, c->out_tmpf.p, sizeof(float), 1, n, grav_cost, cost_stride, on_device)))
+      if((rc = deliver(c, c->out_tmpf.p, sizeof(float), 1, n, grav_cost, cost_stride, on_device, mask)))
         return rc;
     }
   return NGRAVS_OK;
@@ -878,12 +1078,12 @@ extern "C" int ngravs_dd_set_extent(ngravs_ctx *c, const double lo[3], const dou
   return NGRAVS_OK;
 }
 
-extern "C" int ngravs_dd_histogram(ngravs_ctx *c, int level, int64_t *hist)
+extern "C" int ngravs_dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
 {
   if(!c || !c->have_particles || !c->extent_override || !hist || level < 1 || level > 7)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  return dd_histogram(c, level, hist);
+  return dd_histogram(c, level, hist, work);
 }
 
 extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
@@ -907,6 +1107,25 @@ extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, int level, const int32_t 
         reach += c->dom[6] - c->cfg.box_size;   // the curve's cube is 1.001 x the box: seam slack, conservative
     }
   return dd_pack(c, what, level, owner_ph, owner_xyz, nranks, my_rank, reach, counts, dev_records, nrec);
+}
+
+extern "C" int ngravs_dd_get_dest(ngravs_ctx *c, int level, const int32_t *owner_ph, int32_t *dest)
+{
+  if(!c || !c->have_particles || !c->extent_override || !owner_ph || !dest || level < 1 || level > 7)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_get_dest(c, level, owner_ph, dest);
+}
+
+extern "C" int ngravs_dd_recv_buffer(ngravs_ctx *c, int64_t nrec, void **dev_records)
+{
+  if(!c || nrec < 0 || !dev_records)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  if(c->dd_recv.ensure((size_t)(nrec > 0 ? nrec : 1) * NGRAVS_DD_RECORD_BYTES))
+    return NGRAVS_ERR_NOMEM;
+  *dev_records = c->dd_recv.p;
+  return NGRAVS_OK;
 }
 
 extern "C" int ngravs_dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
@@ -982,5 +1201,59 @@ extern "C" int ngravs_pm_finish(ngravs_ctx *c)
     return rc;
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   c->stats.t_pm = ev_ms(c) * 1e-3;
+  return NGRAVS_OK;
+}
+
+// ---- slab-decomposed pmforce_periodic (kernels_pmslab.hip) ------------------------------------------------------------------
+extern "C" int ngravs_pm_slab_begin(ngravs_ctx *c, int rank, int world, int32_t bbox[6])
+{
+  if(!c || !bbox)
+    return NGRAVS_ERR_ARG;
+  if(!c->have_order)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  if(c->tree_stale)   // drifted particles: the sorted columns are refreshed by the refit
+    {
+      int rc = ngravs_force_update_tree(c);
+      if(rc)
+        return rc;
+    }
+  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  int bb[6];
+  int rc = pmslab_begin(c, rank, world, bb);
+  for(int j = 0; j < 6; j++)
+    bbox[j] = bb[j];
+  return rc;
+}
+
+extern "C" int ngravs_pm_slab_pack(ngravs_ctx *c, int stage, const int32_t *all_bbox, int64_t *send_counts, int64_t *recv_counts,
+                                   void **send, void **recv)
+{
+  if(!c || !send_counts || !recv_counts || !send || !recv)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return pmslab_pack(c, stage, all_bbox, send_counts, recv_counts, send, recv);
+}
+
+extern "C" int ngravs_pm_slab_unpack(ngravs_ctx *c, int stage)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  int rc = pmslab_unpack(c, stage);
+  if(rc == NGRAVS_OK && stage == 3)
+    {
+      HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+      c->stats.t_pm = ev_ms(c) * 1e-3;
+    }
+  return rc;
+}
+
+extern "C" int ngravs_pm_slab_bytes(ngravs_ctx *c, double bytes[4])
+{
+  if(!c || !bytes)
+    return NGRAVS_ERR_ARG;
+  for(int k = 0; k < 4; k++)
+    bytes[k] = c->pms.bytes_sent[k];
   return NGRAVS_OK;
 }

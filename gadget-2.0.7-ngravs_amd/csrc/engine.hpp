@@ -70,7 +70,7 @@ template <typename T> struct DevBuf
 struct WalkParams
 {
   int ng, periodic, pm, use_theta;
-  int dbg;                  // NGRAVS_DEBUG bits: 1 = skip list evaluation (traversal-only timing)
+  int exact_reach;          // group walk: exact fp64 reach test instead of the packed-fp32 pre-test (ngravs_set_tuning)
   double box, boxhalf;
   double theta2;            // ErrTolTheta^2
   double errtol_acc;        // ErrTolForceAcc
@@ -95,9 +95,36 @@ struct TreeView
   double ltab_corner[3], ltab_cl;
 };
 
+// ngravs_set_tuning(): performance / test parameters, set explicitly by the host (no environment variables)
+struct Tuning
+{
+  int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0;
+  long long walk_batch = 0;
+  int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0;
+};
+
+// slab-decomposed particle mesh of the multi-task path (kernels_pmslab.hip)
+struct PmSlab
+{
+  int world = 0, rank = 0, N = 0, stage = -1;
+  int xs = 0, nx = 0, ys = 0, ny = 0;      // own x-slab of the real mesh, own y-slab of the transposed k-space
+  int lo[3] = {0, 0, 0}, ext[3] = {0, 0, 0};   // brick: the mesh cells (lo + i) mod N the own particles' CIC clouds touch
+  int elo[3] = {0, 0, 0}, eext[3] = {0, 0, 0}; // the same +-2 cells (4-point gradient)
+  std::vector<int> bbox;                   // lo[3], ext[3] of every task's brick
+  std::vector<int64_t> scount, rcount;     // doubles per peer of the stage being exchanged
+  long long edesc_off = 0;                 // stage 3: where the extended-brick plane descriptors start in desc
+  DevBuf<double> brick, slab, tbuf, ebrick, send, recv;
+  DevBuf<long long> desc;
+  void *plan2f = nullptr, *plan2i = nullptr, *plan1 = nullptr;
+  int plan_N = 0, plan_nx = 0, plan_ny = 0;
+  double bytes_sent[4] = {0, 0, 0, 0};     // payload of the last step's four exchanges (this task, bytes)
+};
+
 struct ngravs_ctx
 {
   ngravs_config_t cfg;
+  Tuning tune;
+  PmSlab pms;
   ngravs_fatal_fn on_fatal = nullptr;
   hipStream_t stream = nullptr;
   double asmth = 0, rcut = 0;
@@ -107,11 +134,13 @@ struct ngravs_ctx
   double ext_lo[3], ext_hi[3];
   int dd_last_what = -1;
   bool have_particles = false, have_order = false, have_tree = false, have_pm = false, have_acc = false;
+  bool pm_parked = false;     // pm_orig holds the caller's GravPM (handed over with ngravs_set_particles)
   double dom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int64_t shard_first = 0, shard_count = 0;
 
   // inputs (caller order)
   DevBuf<double> in_pos, in_mass, in_oldacc;
+  DevBuf<double> in_cost;      // P[].GravCost (interactions of the particle's last walk): the work weight of the domain cut
   DevBuf<int> in_type;
   DevBuf<unsigned char> in_active;
   DevBuf<double2> in_rec;      // packed 48-byte records of the caller-order columns (dom_keys_and_sort)
@@ -120,7 +149,7 @@ struct ngravs_ctx
   // multi-task decomposition scratch
   DevBuf<unsigned long long> dd_mask, dd_counts;
   DevBuf<int> dd_owner_ph, dd_owner_xyz;
-  DevBuf<unsigned char> dd_send;
+  DevBuf<unsigned char> dd_send, dd_recv;
   // sorted
   DevBuf<double4> s_pm;
   DevBuf<unsigned char> s_type, s_active;
@@ -184,10 +213,11 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
                   long long *d_keys);
 int dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3]);
 void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3]);
-int dd_histogram(ngravs_ctx *c, int level, int64_t *hist);
+int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work);
 int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *owner_xyz, int nranks, int me, double reach,
             int64_t *counts, void **dev_records, int64_t *nrec);
 int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
 // ---- kernels_tree.hip
@@ -204,6 +234,11 @@ int pm_run(ngravs_ctx *c);
 int pm_deposit(ngravs_ctx *c);
 int pm_finish(ngravs_ctx *c);
 void pm_release(ngravs_ctx *c);
+// ---- kernels_pmslab.hip
+int pmslab_begin(ngravs_ctx *c, int rank, int world, int bbox[6]);
+int pmslab_pack(ngravs_ctx *c, int stage, const int *all_bbox, int64_t *send_counts, int64_t *recv_counts, void **send, void **recv);
+int pmslab_unpack(ngravs_ctx *c, int stage);
+void pmslab_release(ngravs_ctx *c);
 // ---- shortrange_table.cpp
 void host_shortrange_table(const ngravs_config_t *cfg, double *force, double *pot);
 double cfg_asmth(const ngravs_config_t *c);

@@ -232,7 +232,7 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
 // =====================================================================================================
 struct DDRecord
 {
-  double x, y, z, m, oldacc;
+  double x, y, z, m, oldacc, cost;
   long long meta;   // type | active << 8 | id << 16
 };
 
@@ -256,8 +256,8 @@ __device__ __forceinline__ void dd_cell(const unsigned short (*step)[8], const d
   *iz = z >> (TREE_BITS - level);
 }
 
-__global__ void k_dd_hist(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
-                          unsigned long long *__restrict__ hist)
+__global__ void k_dd_hist(const double *__restrict__ pos, const double *__restrict__ cost, long long n, double cx, double cy, double cz,
+                          double fac21, int level, unsigned long long *__restrict__ hist, double *__restrict__ work)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
@@ -270,6 +270,7 @@ __global__ void k_dd_hist(const double *__restrict__ pos, long long n, double cx
   long long cell;
   dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
   atomicAdd(&hist[cell], 1ull);
+  atomicAdd(&work[cell], 1.0 + cost[i]);   // domain.c:859-862: work of a cell = sum of (1 + GravCost)
 }
 
 // which other tasks receive particle i?  what = 0: its new owner (migration); what = 1: every task owning a cell within
@@ -332,6 +333,22 @@ __global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx
   mask[i] = m;
 }
 
+__global__ void k_dd_owner(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
+                           const int *__restrict__ owner_ph, int *__restrict__ dest)
+{
+  __shared__ unsigned short step[48][8];
+  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
+    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
+  __syncthreads();
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int ix, iy, iz;
+  long long cell;
+  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+  dest[i] = owner_ph[cell];
+}
+
 __global__ void k_dd_count(const unsigned long long *__restrict__ mask, long long n, int nranks, unsigned long long *__restrict__ counts)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -350,7 +367,7 @@ __global__ void k_dd_count(const unsigned long long *__restrict__ mask, long lon
 
 __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
                           const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
-                          const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                          const unsigned char *__restrict__ active, const long long *__restrict__ id, const double *__restrict__ cost,
                           const unsigned long long *__restrict__ offs, unsigned long long *__restrict__ cursor,
                           DDRecord *__restrict__ out)
 {
@@ -366,6 +383,7 @@ __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long
   rec.z = pos[3 * i + 2];
   rec.m = mass[i];
   rec.oldacc = oldacc[i];
+  rec.cost = cost[i];
   rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
   while(m)
     {
@@ -379,10 +397,10 @@ __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long
 // keep the particles that stay (mask == 0), compacted to the front of fresh columns
 __global__ void k_dd_keep(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
                           const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
-                          const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                          const unsigned char *__restrict__ active, const long long *__restrict__ id, const double *__restrict__ cost,
                           unsigned long long *__restrict__ cursor, double *__restrict__ pos2, double *__restrict__ mass2,
                           int *__restrict__ type2, double *__restrict__ oldacc2, unsigned char *__restrict__ active2,
-                          long long *__restrict__ id2)
+                          long long *__restrict__ id2, double *__restrict__ cost2)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n || mask[i])
@@ -396,11 +414,12 @@ __global__ void k_dd_keep(const unsigned long long *__restrict__ mask, long long
   oldacc2[k] = oldacc[i];
   active2[k] = active[i];
   id2[k] = id[i];
+  cost2[k] = cost[i];
 }
 
 __global__ void k_dd_unpack(const DDRecord *__restrict__ rec, long long nrec, long long at, int halo, double *__restrict__ pos,
                             double *__restrict__ mass, int *__restrict__ type, double *__restrict__ oldacc,
-                            unsigned char *__restrict__ active, long long *__restrict__ id)
+                            unsigned char *__restrict__ active, long long *__restrict__ id, double *__restrict__ cost)
 {
   long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(k >= nrec)
@@ -415,6 +434,7 @@ __global__ void k_dd_unpack(const DDRecord *__restrict__ rec, long long nrec, lo
   type[i] = (int)(r.meta & 255);
   active[i] = halo ? (unsigned char)2 : (unsigned char)((r.meta >> 8) & 1);   // bit 1 = halo copy: source only
   id[i] = r.meta >> 16;
+  cost[i] = r.cost;
 }
 
 template <typename T> static int grow_keep(ngravs_ctx *c, DevBuf<T> &b, size_t keep, size_t want)
@@ -476,22 +496,27 @@ void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
   c->dom[7] = 1.0 / len * (double)(((long long)1) << NGRAVS_BITS_PER_DIMENSION);
 }
 
-int dd_histogram(ngravs_ctx *c, int level, int64_t *hist)
+int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
 {
   const long long ncell = 1ll << (3 * level);
   DevBuf<unsigned long long> d;
-  if(d.ensure(ncell))
+  DevBuf<double> w;
+  if(d.ensure(ncell) || w.ensure(ncell))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * ncell, c->stream));
+  HIP_TRY(c, hipMemsetAsync(w.p, 0, sizeof(double) * ncell, c->stream));
   double fac21;
   dd_fac(c, &fac21);
   const long long n = c->n_local;
   if(n > 0)
-    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1],
-                       c->dom[2], fac21, level, d.p);
+    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_cost.p, n, c->dom[0],
+                       c->dom[1], c->dom[2], fac21, level, d.p, w.p);
   HIP_TRY(c, hipMemcpyAsync(hist, d.p, sizeof(unsigned long long) * ncell, hipMemcpyDeviceToHost, c->stream));
+  if(work)
+    HIP_TRY(c, hipMemcpyAsync(work, w.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   d.release();
+  w.release();
   return NGRAVS_OK;
 }
 
@@ -537,7 +562,7 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
     {
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(k_dd_fill, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
-                         c->in_oldacc.p, c->in_active.p, c->in_id.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
+                         c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
                          (DDRecord *)c->dd_send.p);
     }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -548,30 +573,51 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
   return NGRAVS_OK;
 }
 
+// destination task of every local particle (host array): what the migration pack would do, without packing
+int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest)
+{
+  const long long n = c->n_local, ncell = 1ll << (3 * level);
+  if(n <= 0)
+    return NGRAVS_OK;
+  DevBuf<int> d;
+  if(c->dd_owner_ph.ensure(ncell) || d.ensure(n))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_ph.p, owner_ph, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
+  double fac21;
+  dd_fac(c, &fac21);
+  hipLaunchKernelGGL(k_dd_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2],
+                     fac21, level, c->dd_owner_ph.p, d.p);
+  HIP_TRY(c, hipMemcpyAsync(dest, d.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  d.release();
+  return NGRAVS_OK;
+}
+
 // after the migration all-to-all: drop what was sent (mask != 0 from the last dd_pack(what=0)), append what arrived
 int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
 {
   if(c->dd_last_what != 0)
     return NGRAVS_ERR_STATE;
   const long long n = c->n_local;
-  DevBuf<double> pos2, mass2, old2;
+  DevBuf<double> pos2, mass2, old2, cost2;
   DevBuf<int> type2;
   DevBuf<unsigned char> act2;
   DevBuf<long long> id2;
   const size_t cap = (size_t)(n + nrec + 64);
-  if(pos2.ensure(3 * cap) || mass2.ensure(cap) || old2.ensure(cap) || type2.ensure(cap) || act2.ensure(cap) || id2.ensure(cap))
+  if(pos2.ensure(3 * cap) || mass2.ensure(cap) || old2.ensure(cap) || type2.ensure(cap) || act2.ensure(cap) || id2.ensure(cap) ||
+     cost2.ensure(cap))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p + 195, 0, sizeof(unsigned long long), c->stream));
   if(n > 0)
     hipLaunchKernelGGL(k_dd_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p,
-                       c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->dd_counts.p + 195, pos2.p, mass2.p,
-                       type2.p, old2.p, act2.p, id2.p);
+                       c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 195, pos2.p,
+                       mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p);
   unsigned long long kept = 0;
   HIP_TRY(c, hipMemcpyAsync(&kept, c->dd_counts.p + 195, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if(nrec > 0)
     hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
-                       (long long)nrec, (long long)kept, 0, pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p);
+                       (long long)nrec, (long long)kept, 0, pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   c->in_pos.release();
@@ -580,6 +626,8 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
   c->in_type.release();
   c->in_active.release();
   c->in_id.release();
+  c->in_cost.release();
+  c->in_cost = cost2;
   c->in_pos = pos2;
   c->in_mass = mass2;
   c->in_oldacc = old2;
@@ -596,11 +644,13 @@ int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
 {
   const long long nl = c->n_local, tot = nl + nrec;
   if(grow_keep(c, c->in_pos, 3 * nl, 3 * tot) || grow_keep(c, c->in_mass, nl, tot) || grow_keep(c, c->in_oldacc, nl, tot) ||
-     grow_keep(c, c->in_type, nl, tot) || grow_keep(c, c->in_active, nl, tot) || grow_keep(c, c->in_id, nl, tot))
+     grow_keep(c, c->in_type, nl, tot) || grow_keep(c, c->in_active, nl, tot) || grow_keep(c, c->in_id, nl, tot) ||
+     grow_keep(c, c->in_cost, nl, tot))
     return NGRAVS_ERR_NOMEM;
   if(nrec > 0)
     hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
-                       (long long)nrec, nl, 1, c->in_pos.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p);
+                       (long long)nrec, nl, 1, c->in_pos.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p,
+                       c->in_cost.p);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   c->n = tot;

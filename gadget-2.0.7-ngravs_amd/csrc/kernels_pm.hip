@@ -12,16 +12,8 @@
 // Mesh layout: real [N][N][N+2] fp64 (in-place r2c padding), complex [N][N][N/2+1].  rocFFT is an
 // unnormalised DFT with forward sign -1, like FFTW-2.
 #include "engine.hpp"
+#include "pm_common.hpp"
 #include <hipfft/hipfft.h>
-
-__device__ __forceinline__ int cell_of(double x, double to_slab, int N, double *frac)
-{
-  int s = (int)(to_slab * x);                                         // pm_periodic.c:299-301
-  if(s >= N)
-    s = N - 1;
-  *frac = to_slab * x - s;
-  return s;
-}
 
 __global__ void k_cic_deposit(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
                               const unsigned char *__restrict__ s_flag, long long n,
@@ -49,15 +41,6 @@ __global__ void k_cic_deposit(const double4 *__restrict__ s_pm, const unsigned c
   atomicAdd(&grid[((long long)sxx * N + syy) * NZ + szz], m * (dx)*dy * dz);
 }
 
-struct GreenParams
-{
-  int ng, N;
-  double asmth2;       // (2 pi asmth / L)^2                                     pm_periodic.c:234-235
-  double ym2;          // (YUKAWA_IMASS / 2 pi)^2                                 ngravs.c:871
-  double yfac;         // exp(-ym^2 asmth2)                                       ngravs.c:877
-  double cN[NG_MAX][NG_MAX], cY[NG_MAX][NG_MAX];   // [source][target], as pm_periodic.c:490 indexes GreensFxns
-};
-
 // one thread per complex mode; rho[a] complex in, phi[b] complex out
 template <int NG>
 __global__ void k_green(const double2 *__restrict__ rho, double2 *__restrict__ phi, GreenParams gp)
@@ -70,46 +53,8 @@ __global__ void k_green(const double2 *__restrict__ rho, double2 *__restrict__ p
   int z = (int)(idx % NH);
   int y = (int)((idx / NH) % N);
   int x = (int)(idx / ((long long)NH * N));
-  double kx = x > N / 2 ? x - N : x, ky = y > N / 2 ? y - N : y, kz = z;   // pm_periodic.c:440-451
-  double k2 = kx * kx + ky * ky + kz * kz;
   double2 out[NG];
-#pragma unroll
-  for(int b = 0; b < NG; b++)
-    out[b].x = out[b].y = 0;
-  if(k2 > 0)
-    {
-      double fx = 1, fy = 1, fz = 1;
-      if(kx != 0)
-        {
-          fx = (M_PI * kx) / N;
-          fx = sin(fx) / fx;
-        }
-      if(ky != 0)
-        {
-          fy = (M_PI * ky) / N;
-          fy = sin(fy) / fy;
-        }
-      if(kz != 0)
-        {
-          fz = (M_PI * kz) / N;
-          fz = sin(fz) / fz;
-        }
-      double ff = 1 / (fx * fy * fz);
-      double common = -exp(-k2 * gp.asmth2) * ff * ff * ff * ff;       // pm_periodic.c:491
-      double gN = 1.0 / k2, gY = 1.0 / (k2 + gp.ym2) * gp.yfac;         // pgdelta / pgyukawa
-#pragma unroll
-      for(int a = 0; a < NG; a++)
-        {
-          double2 r = rho[(size_t)a * total + idx];
-#pragma unroll
-          for(int b = 0; b < NG; b++)
-            {
-              double smth = (gp.cN[a][b] * gN + gp.cY[a][b] * gY) * common;
-              out[b].x += r.x * smth;
-              out[b].y += r.y * smth;
-            }
-        }
-    }
+  green_mode<NG>(gp, x, y, z, rho, (size_t)total, (size_t)idx, out);
 #pragma unroll
   for(int b = 0; b < NG; b++)
     phi[(size_t)b * total + idx] = out[b];                             // k = 0 -> 0 (pm_periodic.c:519-520)
@@ -237,7 +182,6 @@ __global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned 
 #define PM_GT (PM_DT + 4)            // gather patch edge: +-2 for the 4-point gradient
 #define PM_TILE_THREADS 1024
 
-__device__ __forceinline__ int wrapN(int a, int N) { return a < 0 ? a + N : (a >= N ? a - N : a); }
 
 template <int NG>
 __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
@@ -461,7 +405,7 @@ __global__ void k_gradient_gather_loose(const double4 *__restrict__ s_pm, const 
 // the level whose cells are at most 16 mesh cells wide (-1: no such level in this tree -> per-particle kernels)
 static int pm_tile_level(const ngravs_ctx *c, double to_slab, double max_cells = 16.0)
 {
-  if(!c->have_tree || getenv("NGRAVS_PM_NOTILE"))
+  if(!c->have_tree || c->tune.pm_notile)
     return -1;
   double len = c->dom[6];
   for(int l = 0; l < c->nlevels && l < TREE_BITS; l++, len *= 0.5)
@@ -486,18 +430,6 @@ void pm_release(ngravs_ctx *c)
     }
   c->pm_plan_n = 0;
 }
-
-#define FFT_TRY(ctx, expr)                                                                  \
-  do                                                                                        \
-    {                                                                                       \
-      hipfftResult r__ = (expr);                                                            \
-      if(r__ != HIPFFT_SUCCESS)                                                             \
-        {                                                                                   \
-          ngravs_report(ctx, NGRAVS_ERR_NO_DEVICE, std::string(#expr) + ": hipfft error " + std::to_string((int)r__)); \
-          return NGRAVS_ERR_NO_DEVICE;                                                      \
-        }                                                                                   \
-    }                                                                                       \
-  while(0)
 
 int pm_deposit(ngravs_ctx *c)
 {
@@ -569,21 +501,7 @@ int pm_finish(ngravs_ctx *c)
     FFT_TRY(c, hipfftExecD2Z(*(hipfftHandle *)c->fft_fwd, c->pm_rho.p + real_elems * a,
                              (hipfftDoubleComplex *)(c->pm_rho.p + real_elems * a)));
   GreenParams gp;
-  memset(&gp, 0, sizeof(gp));
-  gp.ng = ng;
-  gp.N = N;
-  gp.asmth2 = (2 * M_PI) * c->asmth / L;
-  gp.asmth2 *= gp.asmth2;
-  double ym = c->cfg.yukawa_imass / (2 * M_PI);
-  gp.ym2 = ym * ym;
-  gp.yfac = exp(-ym * ym * gp.asmth2);
-  for(int a = 0; a < ng; a++)
-    for(int b = 0; b < ng; b++)
-      {
-        int law = c->cfg.law_greens[a][b];   // [source][target] (pm_periodic.c:490)
-        gp.cN[a][b] = law == NGRAVS_LAW_NEWTON || law == NGRAVS_LAW_COLOYUK ? 1.0 : (law == NGRAVS_LAW_NEG_NEWTON ? -1.0 : 0.0);
-        gp.cY[a][b] = law == NGRAVS_LAW_YUKAWA || law == NGRAVS_LAW_COLOYUK ? 1.0 : 0.0;
-      }
+  make_green_params(c, &gp);
   long long modes = (long long)N * N * (N / 2 + 1);
   unsigned nbm = (unsigned)((modes + bs - 1) / bs);
   switch(ng)
@@ -610,7 +528,7 @@ int pm_finish(ngravs_ctx *c)
   // tiled gather (cells at most 8 mesh cells wide, all species' potential patches in LDS): measured at C4 it LOSES to the
   // per-particle gather (73 ms vs 13.3 ms -- 14 GB of short-row patch loads; the 16-cell one-species variant took 24.6 ms),
   // so it is opt-in for tuning only
-  const int gl = getenv("NGRAVS_PM_TILE_GATHER") ? pm_tile_level(c, to_slab, 8.0) : -1;
+  const int gl = c->tune.pm_tile_gather ? pm_tile_level(c, to_slab, 8.0) : -1;
   if(gl >= 0)
     {
       const long long gl0 = c->level_start[gl], gln = c->level_start[gl + 1] - gl0;
@@ -630,7 +548,7 @@ int pm_finish(ngravs_ctx *c)
                            c->s_type.p, c->s_active.p, c->n_child.p, (int)gl0, (long long)c->shard_first, (long long)c->shard_count,
                            to_slab, N, c->d_counters.p + 8, c->pm_phi.p, fac, c->r_pm.p);
     }
-  else if(nbg > 0 && c->cfg.world_size <= 2 && !(getenv("NGRAVS_PM_FUSED_GATHER") && atoi(getenv("NGRAVS_PM_FUSED_GATHER"))))
+  else if(nbg > 0 && c->cfg.world_size <= 2 && !c->tune.pm_fused_gather)
     {
       // two passes per target species (see k_force_mesh); with many tasks the (replicated) force-mesh pass would cost more
       // than the sharded fused gather below

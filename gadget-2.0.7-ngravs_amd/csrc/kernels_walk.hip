@@ -1160,11 +1160,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- every lane marks the entries within reach of ITS target: two 32-bit words, constant bit per
                 //      unrolled iteration (cndmask + or), LDS reads hoisted by the unroll
                 unsigned int mlo = 0, mhi = 0;
-                const bool direct = !PM && S == 1 && !(wp.dbg & 5);   // tree-only: no masks at all (see the force loop)
+                const bool direct = !PM && S == 1;   // tree-only: no masks at all (see the force loop)
                 if(direct)
                   {
                   }
-                else if(fastmask && !(wp.dbg & (1 | 8)))   // NGRAVS_DEBUG bit 8: use the exact fp64 test below instead (tests)
+                else if(fastmask && !wp.exact_reach)   // tuning "walk_exact_reach": use the exact fp64 test below instead (tests)
                   {
                     // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
                     // (v_alignbit), highest entry first so that entry j ends up in bit j
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     mlo &= (unsigned int)okm;
                     mhi &= (unsigned int)(okm >> 32);
                   }
-                else if(!(wp.dbg & 1))
+                else
                   {
 #pragma unroll
                     for(int w = 0; w < 2; w++)
@@ -1230,8 +1230,6 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- force loop: every lane walks its own bits, ES per trip
                 unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & lane_pat;
                 nint += direct ? (valid ? nc : 0) : __popcll(m);   // evalN takes the (rare) slots beyond the exact cut off again
-                if(wp.dbg & 4)         // debug: masks are built but not evaluated
-                  m = 0;
                 if(direct)
                   {
                     // tree-only: every pool entry interacts with every target -- no masks to decode, all lanes read the
@@ -1778,7 +1776,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
   wp->periodic = cfg.periodic;
   wp->pm = cfg.pmgrid != 0;
   wp->use_theta = cfg.err_tol_theta != 0;
-  wp->dbg = getenv("NGRAVS_DEBUG") ? atoi(getenv("NGRAVS_DEBUG")) : 0;
+  wp->exact_reach = c->tune.walk_exact_reach;
   wp->box = cfg.box_size;
   wp->boxhalf = 0.5 * cfg.box_size;
   wp->theta2 = cfg.err_tol_theta * cfg.err_tol_theta;
@@ -1793,8 +1791,6 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
       if(cfg.walk_mode == NGRAVS_WALK_GROUP)
         {
           double ru = cfg.group_reach > 0 ? cfg.group_reach : NGRAVS_GROUP_REACH;
-          if(getenv("NGRAVS_GROUP_REACH"))
-            ru = atof(getenv("NGRAVS_GROUP_REACH"));
           if(ru < 6.0)
             reach = ru * c->asmth;
         }
@@ -1880,7 +1876,7 @@ static int ensure_level_table(ngravs_ctx *c, double reach)
   c->lvl_table_level = 0;
   // a refit (drifted) tree keeps its cell centres but particles may have left their cells (the sides grow to enclose
   // them): the regular cell grid no longer tells which nodes reach into a region, so such walks start at the root
-  if(!c->cfg.pmgrid || !c->cfg.periodic || c->tree_refit || (getenv("NGRAVS_WALK_ROOT") && atoi(getenv("NGRAVS_WALK_ROOT"))))
+  if(!c->cfg.pmgrid || !c->cfg.periodic || c->tree_refit || c->tune.walk_root)
     return NGRAVS_OK;
   int best = 0;
   for(int l = 2; l <= 6 && l < c->nlevels; l++)
@@ -1961,7 +1957,7 @@ struct ActiveFlag
 static int walk_select_targets(ngravs_ctx *c)
 {
   c->walk_ntargets = -1;
-  if(c->all_active || c->shard_count <= 0 || (getenv("NGRAVS_WALK_COMPACT") && !atoi(getenv("NGRAVS_WALK_COMPACT"))))
+  if(c->all_active || c->shard_count <= 0 || !c->tune.walk_compact)
     return NGRAVS_OK;
   const int n = (int)c->shard_count;
   if(c->walk_tlist.ensure((size_t)n) || c->walk_counters.ensure(32))
@@ -2039,8 +2035,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   if(waves > GW2_MAXWAVES)
     waves = GW2_MAXWAVES;   // register-limited: 4 waves per SIMD (__launch_bounds__), one workgroup per CU
-  if(getenv("NGRAVS_WALK_WAVES") && atoi(getenv("NGRAVS_WALK_WAVES")) > 0 && atoi(getenv("NGRAVS_WALK_WAVES")) < waves)
-    waves = atoi(getenv("NGRAVS_WALK_WAVES"));   // tuning knob: fewer waves per evaluation workgroup
+  if(c->tune.walk_waves > 0 && c->tune.walk_waves < waves)
+    waves = c->tune.walk_waves;   // tuning: fewer waves per evaluation workgroup
   if(waves < 1)
     waves = 1;
   const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
@@ -2051,8 +2047,8 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   if(c->walk_lcap < 1024)
     {
       c->walk_lcap = NG == 1 ? 2 * GW3_LIST_MIN : GW3_LIST_MIN;
-      if(getenv("NGRAVS_WALK_LCAP") && atoi(getenv("NGRAVS_WALK_LCAP")) >= 1024)   // test knob: small lists force the leftover pass
-        c->walk_lcap = atoi(getenv("NGRAVS_WALK_LCAP"));
+      if(c->tune.walk_lcap >= 1024)   // tests: small lists force the leftover pass
+        c->walk_lcap = c->tune.walk_lcap;
     }
   if(c->walk_scap < GW3_STK_MIN)
     c->walk_scap = GW3_STK_MIN;
@@ -2074,9 +2070,9 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
           cap_bytes = (size_t)64 << 30;
       }
   }
-  if(getenv("NGRAVS_WALK_BATCH") && atoll(getenv("NGRAVS_WALK_BATCH")) > 0)
+  if(c->tune.walk_batch > 0)
     {
-      batch = atoll(getenv("NGRAVS_WALK_BATCH"));
+      batch = c->tune.walk_batch;
       cap_bytes = (size_t)64 << 30;
     }
   while(batch > 8192 && (size_t)batch * region_ints * sizeof(int) > cap_bytes)
@@ -2134,7 +2130,7 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
     c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
   constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables beside the pools would leave 9 waves; measured equal to 16 waves reading them through L1/L2
-  const bool v2 = getenv("NGRAVS_WALK_V") && atoi(getenv("NGRAVS_WALK_V")) == 2;   // fused kernel for the whole walk
+  const bool v2 = c->tune.walk_fused != 0;   // fused kernel for the whole walk
   if(allow_split && !v2 && !glist)
     {
       *used_split = true;
@@ -2184,6 +2180,8 @@ int walk_run(ngravs_ctx *c)
     {
       HIP_TRY(c, hipMemsetAsync(c->r_nint.p, 0, sizeof(int) * n, c->stream));
       HIP_TRY(c, hipMemsetAsync(c->r_acc.p, 0, sizeof(double) * 3 * n, c->stream));
+      // ... and keep their OldAcc: k_finish only rewrites the rows of walked particles (gravtree.c:318-331)
+      HIP_TRY(c, hipMemcpyAsync(c->r_oldacc.p, c->s_oldacc.p, sizeof(double) * n, hipMemcpyDeviceToDevice, c->stream));
     }
   const bool pm = c->cfg.pmgrid != 0;
   HIP_TRY(c, hipEventRecord(c->evk0, c->stream));
@@ -2237,12 +2235,8 @@ int walk_run(ngravs_ctx *c)
           // beyond that one target per wave does (intermediate S multiply the traversals without shrinking the lists enough)
           const int sp = cbrt(vol_per_target * 64.0) > 2.5 * sqrt(wp.reach2) ? 64 : 1;
           c->walk_spread = sp;
-          if(getenv("NGRAVS_WALK_SPREAD"))   // test / tuning knob: 1, 2, 4 ... 64 lanes per target
-            {
-              const int e = atoi(getenv("NGRAVS_WALK_SPREAD"));
-              if(e >= 1 && e <= 64 && (e & (e - 1)) == 0)
-                c->walk_spread = e;
-            }
+          if(c->tune.walk_spread >= 1)   // tests / tuning: 1, 2, 4 ... 64 lanes per target
+            c->walk_spread = c->tune.walk_spread;
           if(c->walk_spread <= 1)
             c->walk_spread = 0;
         }

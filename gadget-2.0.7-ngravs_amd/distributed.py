@@ -1,143 +1,159 @@
-"""Multi-task (one process per GPU) host layer: Peano-Hilbert domain decomposition with particle migration and
-a short-range halo, the role of domain_Decomposition() + the export/import loop of gravity_tree() in the
-reference (domain.c:164-330, 554-760; gravtree.c:112-285).
+"""Multi-task (one process per GPU) host layer over torch.distributed.
 
-The C library only packs and unpacks (include/ngravs_hip.h "multi-task domain decomposition"); the
-collectives are done here with torch.distributed -- backend "nccl" (= RCCL over xGMI) on device tensors in
-production, "gloo" on host copies for the CPU-side rehearsal.  Collectives per step:
-  all-reduce(min/max) of the extent [6 doubles]  -- domain.c:906-907
-  all-reduce(sum) of the Peano-cell histogram    -- domain_sumCost, domain.c:869-871
-  all-to-all-v of migrating particles (48 B)     -- domain_exchangeParticles, domain.c:695-747
-  all-to-all-v of halo particles (48 B)          -- replaces gravtree.c:195-257 (targets out, partial forces back)
-  all-reduce(sum) of the density mesh            -- replaces the patch -> slab shipping of pm_periodic.c:333-427
+The choreography itself -- domain_Decomposition() with work-weighted cuts, particle migration and the short-range halo
+(reference domain.c:62-330, 347-544, 695-795; gravtree.c:112-285) and pmforce_periodic() on the x-slab decomposed mesh
+(pm_periodic.c:204-790) -- is plain C inside libngravs_hip.so (host/ngravs_host.c, include/ngravs_host.h), written over a
+three-function communicator vtable.  This module only fills that vtable with torch.distributed collectives: backend
+"nccl" (= RCCL over xGMI) on the library's device buffers in production, "gloo" through host copies for the CPU-side
+rehearsal.  The reference glue fills the same vtable with MPI (host/gadget_glue.c).
+
+Collectives per step (payload per task in DistributedEngine.info / .pm_bytes):
+  all-reduce  extent (2 x 3 f64), per-cell count + work histograms (8^level i64 + f64)
+  all-gather  send-count vectors, PM bricks' bounding boxes (6 i32)
+  all-to-all-v  migrating particles, halo particles (56-byte records), and the four mesh exchanges of the slab PM
 """
 import ctypes as C
 
 import numpy as np
 
-from . import Engine, NgravsError, lib, peano_hilbert_key
+from . import Engine, NgravsError, lib
 
-_REC = 6          # doubles per record
+_I64P = C.POINTER(C.c_int64)
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int)
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, _I64P, _I64P, C.c_void_p, _I64P, _I64P)
+
+
+class Comm(C.Structure):
+    """struct ngravs_comm (include/ngravs_host.h)"""
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("device_buffers", C.c_int32), ("reserved", C.c_int32),
+                ("user", C.c_void_p), ("allreduce", _ALLREDUCE), ("allgather", _ALLGATHER), ("alltoallv", _ALLTOALLV)]
+
+
+class DDInfo(C.Structure):
+    """struct ngravs_dd_info (include/ngravs_host.h)"""
+    _fields_ = [("level", C.c_int32), ("reserved", C.c_int32), ("n_local", C.c_int64), ("n_halo", C.c_int64),
+                ("n_migrated_in", C.c_int64), ("work_balance", C.c_double), ("memory_balance", C.c_double),
+                ("bytes_migration", C.c_double), ("bytes_halo", C.c_double)]
 
 
 class _DevArray:
     """zero-copy view of library device memory for torch (CUDA array interface)"""
 
-    def __init__(self, ptr, shape, typestr="<f8"):
-        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
 
 
-def _ph_of_xyz(level):
-    nc = 1 << level
-    out = np.empty((nc, nc, nc), dtype=np.int64)
-    for x in range(nc):
-        for y in range(nc):
-            for z in range(nc):
-                out[x, y, z] = peano_hilbert_key(x, y, z, level)
-    return out
+def _host_view(ptr, nbytes):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)) if nbytes > 0 else np.zeros(0, np.uint8)
 
 
-def cut_curve(hist, world_size):
-    """owner of every Peano cell: contiguous runs of cells with ~equal particle counts (domain_findSplit by count)"""
-    hist = np.asarray(hist, dtype=np.float64)
-    tot = hist.sum()
-    if tot <= 0:
-        return np.zeros(len(hist), dtype=np.int32)
-    mid = np.cumsum(hist) - 0.5 * hist
-    return np.minimum(world_size - 1, np.floor(mid * world_size / tot)).astype(np.int32)
+class TorchComm:
+    """struct ngravs_comm backed by a torch.distributed process group"""
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group, self.device = torch, dist, group, device
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.error = None
+        self._cb = (_ALLREDUCE(self._allreduce), _ALLGATHER(self._allgather), _ALLTOALLV(self._alltoallv))
+        self.c = Comm(self.rank, self.size, 1, 0, None, *self._cb)
+
+    def _guard(self, fn, *a):
+        try:
+            fn(*a)
+            return 0
+        except Exception as e:          # never let an exception cross the C frame
+            self.error = e
+            return 1
+
+    def _allreduce(self, user, buf, count, dtype, op):
+        def run():
+            torch, dist = self.torch, self.dist
+            h = _host_view(buf, 8 * count).view(np.float64 if dtype == 0 else np.int64)
+            t = torch.from_numpy(h.copy())
+            if self.backend == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[op], group=self.group)
+            h[:] = t.cpu().numpy()
+        return self._guard(run)
+
+    def _allgather(self, user, send, recv, nbytes):
+        def run():
+            torch, dist = self.torch, self.dist
+            t = torch.from_numpy(_host_view(send, nbytes).copy())
+            if self.backend == "nccl":
+                t = t.to(self.device)
+            outs = [torch.empty_like(t) for _ in range(self.size)]
+            dist.all_gather(outs, t, group=self.group)
+            _host_view(recv, self.size * nbytes)[:] = torch.cat(outs).cpu().numpy()
+        return self._guard(run)
+
+    def _alltoallv(self, user, send, sbytes, sdispl, recv, rbytes, rdispl):
+        def run():
+            torch, dist, W = self.torch, self.dist, self.size
+            sb, rb = [int(sbytes[r]) for r in range(W)], [int(rbytes[r]) for r in range(W)]
+            ns, nr = sum(sb), sum(rb)      # blocks are contiguous in task order (displacements are prefix sums)
+            inp = torch.as_tensor(_DevArray(send, ns), device=self.device) if ns else torch.empty(0, dtype=torch.uint8, device=self.device)
+            out = torch.as_tensor(_DevArray(recv, nr), device=self.device) if nr else torch.empty(0, dtype=torch.uint8, device=self.device)
+            if self.backend == "nccl":
+                dist.all_to_all_single(out, inp, rb, sb, group=self.group)
+            else:
+                inp_h, out_h = inp.cpu(), torch.empty(nr, dtype=torch.uint8)
+                try:
+                    dist.all_to_all_single(out_h, inp_h, rb, sb, group=self.group)
+                except RuntimeError:
+                    # gloo builds without alltoall: emulate with all-gathers of the count matrix and the padded send buffers
+                    cnt = torch.tensor(sb, dtype=torch.int64)
+                    mats = [torch.zeros(W, dtype=torch.int64) for _ in range(W)]
+                    dist.all_gather(mats, cnt, group=self.group)
+                    mat = torch.stack(mats)
+                    mx = int(mat.sum(dim=1).max())
+                    pad = torch.zeros(max(mx, 1), dtype=torch.uint8)
+                    pad[:ns] = inp_h
+                    bufs = [torch.zeros(max(mx, 1), dtype=torch.uint8) for _ in range(W)]
+                    dist.all_gather(bufs, pad, group=self.group)
+                    parts = []
+                    for r in range(W):
+                        off = int(mat[r, : self.rank].sum())
+                        parts.append(bufs[r][off: off + int(mat[r, self.rank])])
+                    out_h = torch.cat(parts)
+                if nr:
+                    out.copy_(out_h)
+            torch.cuda.synchronize(self.device)      # the library's unpack kernels run on its own stream
+        return self._guard(run)
 
 
 class DistributedEngine(Engine):
     def __init__(self, cfg, level=None, group=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.group = group
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
-        self.backend = dist.get_backend(group)
-        if self.world > 64:
-            raise NgravsError("at most 64 tasks")
+        import torch
         cfg.rank, cfg.world_size = 0, 1          # the library sees its working set (own + halo) as a single task
         super().__init__(cfg)
+        self.comm = TorchComm(torch.device("cuda", cfg.device), group)
+        self.rank, self.world, self.backend = self.comm.rank, self.comm.size, self.comm.backend
+        if self.world > 64:
+            raise NgravsError("at most 64 tasks")
         self.level = level
-        self._ph = None
-        self._L = lib()
-        self._L.ngravs_dd_num_local.restype = C.c_int64
-        self._L.ngravs_dd_num_local.argtypes = [C.c_void_p]
+        self.info = DDInfo()
         self.timings = {}
+        L = self._L = lib()
+        L.ngravs_dd_num_local.restype = C.c_int64
+        L.ngravs_dd_num_local.argtypes = [C.c_void_p]
+        L.ngravs_host_domain_decomposition.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        L.ngravs_host_pmforce_periodic.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_pm_slab_bytes.argtypes = [C.c_void_p, C.c_void_p]
 
-    # ---- helpers -----------------------------------------------------------------------------------------
-    def _torch(self):
-        import torch
-        return torch
-
-    def _dev(self):
-        torch = self._torch()
-        return torch.device("cuda", self.cfg.device)
-
-    def _allreduce_host(self, arr, op):
-        torch = self._torch()
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        if self.backend == "nccl":
-            t = t.to(self._dev())
-        self.dist.all_reduce(t, op=op, group=self.group)
-        return t.cpu().numpy()
-
-    def _choose_level(self):
-        if self.level is not None:
-            return self.level
-        # the coarsest cells that are still at least as wide as the short-range cut, at most 32^3 of them
-        reach = 6.0 * 1.25 * self.cfg.box_size / self.cfg.pmgrid
-        lvl = 1
-        while lvl < 5 and self.cfg.box_size / (1 << (lvl + 1)) >= 1.05 * reach:
-            lvl += 1
-        return lvl
-
-    def _alltoallv(self, counts, dev_ptr, nrec):
-        torch, dist = self._torch(), self.dist
-        ws = self.world
-        send_counts = torch.tensor(list(counts), dtype=torch.int64)
-        gathered = [torch.zeros(ws, dtype=torch.int64) for _ in range(ws)]
-        if self.backend == "nccl":
-            sc = send_counts.to(self._dev())
-            gl = [g.to(self._dev()) for g in gathered]
-            dist.all_gather(gl, sc, group=self.group)
-            mat = torch.stack([g.cpu() for g in gl])
-        else:
-            dist.all_gather(gathered, send_counts, group=self.group)
-            mat = torch.stack(gathered)
-        recv_counts = [int(mat[r, self.rank]) for r in range(ws)]
-        nrecv = sum(recv_counts)
-        if nrec > 0:
-            inp = torch.as_tensor(_DevArray(dev_ptr, (nrec, _REC)), device=self._dev())
-        else:
-            inp = torch.zeros((0, _REC), dtype=torch.float64, device=self._dev())
-        out = torch.empty((nrecv, _REC), dtype=torch.float64, device=self._dev())
-        in_splits = [int(c) for c in counts]
-        if self.backend == "nccl":
-            dist.all_to_all_single(out, inp, recv_counts, in_splits, group=self.group)
-        else:
-            inp_h, out_h = inp.cpu(), torch.empty((nrecv, _REC), dtype=torch.float64)
-            try:
-                dist.all_to_all_single(out_h, inp_h, recv_counts, in_splits, group=self.group)
-            except RuntimeError:
-                # gloo builds without alltoall: emulate with an all-gather of (padded) send buffers
-                mx = int(mat.sum(dim=1).max())
-                pad = torch.zeros((mx, _REC), dtype=torch.float64)
-                pad[: inp_h.shape[0]] = inp_h
-                bufs = [torch.zeros((mx, _REC), dtype=torch.float64) for _ in range(ws)]
-                dist.all_gather(bufs, pad, group=self.group)
-                parts = []
-                for r in range(ws):
-                    off = int(mat[r, : self.rank].sum())
-                    parts.append(bufs[r][off: off + int(mat[r, self.rank])])
-                out_h = torch.cat(parts) if parts else out_h
-            out.copy_(out_h)
-        return out, nrecv
+    def _host(self, rc, what):
+        if self.comm.error is not None:
+            e, self.comm.error = self.comm.error, None
+            raise e
+        self._check(rc, what)
 
     # ---- particle hand-over ----------------------------------------------------------------------------------
-    def set_particles(self, pos, mass, ptype, old_acc=None, active=None, ids=None):
-        super().set_particles(pos, mass, ptype, old_acc=old_acc, active=active)
+    def set_particles(self, pos, mass, ptype, old_acc=None, active=None, ids=None, grav_pm=None, grav_cost=None):
+        super().set_particles(pos, mass, ptype, old_acc=old_acc, active=active, grav_pm=grav_pm, grav_cost=grav_cost)
         if ids is not None:
             ids = np.ascontiguousarray(ids, dtype=np.int64)
             self._check(self._L.ngravs_dd_set_ids(self._h, ids.ctypes.data, 0), "ngravs_dd_set_ids")
@@ -150,51 +166,22 @@ class DistributedEngine(Engine):
         self._check(self._L.ngravs_dd_get_ids(self._h, out.ctypes.data, 0), "ngravs_dd_get_ids")
         return out
 
-    # ---- the step ------------------------------------------------------------------------------------------------
+    # ---- the step (the reference's names) ----------------------------------------------------------------------------
     def domain_Decomposition(self):
-        dist, L = self.dist, self._L
-        lo, hi = np.zeros(3), np.zeros(3)
-        self._check(L.ngravs_dd_local_extent(self._h, lo.ctypes.data, hi.ctypes.data), "ngravs_dd_local_extent")
-        lo = self._allreduce_host(lo, dist.ReduceOp.MIN)
-        hi = self._allreduce_host(hi, dist.ReduceOp.MAX)
-        self._check(L.ngravs_dd_set_extent(self._h, lo.ctypes.data, hi.ctypes.data), "ngravs_dd_set_extent")
-        level = self._choose_level()
-        ncell = 1 << (3 * level)
-        hist = np.zeros(ncell, dtype=np.int64)
-        self._check(L.ngravs_dd_histogram(self._h, level, hist.ctypes.data), "ngravs_dd_histogram")
-        hist = self._allreduce_host(hist, dist.ReduceOp.SUM)
-        owner_ph = cut_curve(hist, self.world)
-        if self._ph is None or self._ph[0] != level:
-            self._ph = (level, _ph_of_xyz(level))
-        owner_xyz = np.ascontiguousarray(owner_ph[self._ph[1]].reshape(-1), dtype=np.int32)
-        self.owner_ph, self.level_used = owner_ph, level
-        counts = (C.c_int64 * 65)()
-        ptr, nrec = C.c_void_p(), C.c_int64()
-        for what in (0, 1):
-            self._check(L.ngravs_dd_pack(self._h, what, level, owner_ph.ctypes.data, owner_xyz.ctypes.data, self.world, self.rank,
-                                         counts, C.byref(ptr), C.byref(nrec)), "ngravs_dd_pack")
-            recv, nrecv = self._alltoallv([counts[r] for r in range(self.world)], ptr.value, nrec.value)
-            self._torch().cuda.synchronize()
-            fn = L.ngravs_dd_apply_migration if what == 0 else L.ngravs_dd_set_halo
-            self._check(fn(self._h, C.c_void_p(recv.data_ptr()), C.c_int64(nrecv)), "dd unpack")
-            self.timings["migrated" if what == 0 else "halo"] = nrecv
+        rc = self._L.ngravs_host_domain_decomposition(self._h, C.byref(self.comm.c), self.level or 0, 0.0, C.byref(self.info))
+        self._host(rc, "ngravs_host_domain_decomposition")
+        self.level_used = self.info.level
+        self.timings["migrated"], self.timings["halo"] = int(self.info.n_migrated_in), int(self.info.n_halo)
         self.n = self.num_local()
-        super().domain_Decomposition()
 
     def pmforce_periodic(self):
-        torch, dist, L = self._torch(), self.dist, self._L
-        self._check(L.ngravs_pm_deposit(self._h), "ngravs_pm_deposit")
-        ptr, cnt = C.c_void_p(), C.c_int64()
-        self._check(L.ngravs_pm_density(self._h, C.byref(ptr), C.byref(cnt)), "ngravs_pm_density")
-        rho = torch.as_tensor(_DevArray(ptr.value, (cnt.value,)), device=self._dev())
-        if self.backend == "nccl":
-            dist.all_reduce(rho, group=self.group)
-        else:
-            h = rho.cpu()
-            dist.all_reduce(h, group=self.group)
-            rho.copy_(h)
-        torch.cuda.synchronize()
-        self._check(L.ngravs_pm_finish(self._h), "ngravs_pm_finish")
+        self._host(self._L.ngravs_host_pmforce_periodic(self._h, C.byref(self.comm.c)), "ngravs_host_pmforce_periodic")
+
+    def pm_bytes(self):
+        """payload this task sent to other tasks in the four mesh exchanges of the last PM step (bytes)"""
+        b = (C.c_double * 4)()
+        self._check(self._L.ngravs_pm_slab_bytes(self._h, b), "ngravs_pm_slab_bytes")
+        return list(b)
 
     def compute_accelerations(self, pm_step=True):
         self.domain_Decomposition()

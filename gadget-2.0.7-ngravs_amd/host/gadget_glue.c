@@ -1,33 +1,52 @@
-/* gadget_glue.c -- the reference-side binding: what a Gadget-2.0.7-ngravs maintainer adds to the
- * reference tree so that its own entry points run on libngravs_hip.so.
+/* gadget_glue.c -- the reference-side binding: what a Gadget-2.0.7-ngravs maintainer adds to the reference tree so that
+ * its own entry points run on libngravs_hip.so.
  *
- * It is compiled INSIDE the reference tree (it includes the reference's allvars.h / proto.h and
- * therefore sees the real struct particle_data, All, TypeToGrav[], AccelFxns[][] ...), replacing
- * gravtree.o, forcetree.o (walks + build), pm_periodic.o, domain.o's key/sort part and peano.o in
- * Makefile.reference's OBJS.  The reference's signatures are kept exactly (proto.h:36,77,78,86,114,
- * 150,161; ngravs.h:86-87), so accel.c, run.c, init.c, timestep.c are untouched.
+ * It is compiled INSIDE the reference tree (it includes the reference's allvars.h / proto.h and therefore sees the real
+ * struct particle_data, All, TypeToGrav[], AccelFxns[][] ...), replacing gravtree.o, forcetree.o (walks + build),
+ * pm_periodic.o, domain.o, peano.o and gravtree_forcetest.o in Makefile.reference's OBJS.  The
+ * reference's signatures are kept exactly (proto.h:36,77,78,86,113,114,149,150,155,161), so accel.c, run.c, init.c,
+ * timestep.c, predict.c are untouched.
  *
- * This file is NOT built in this repository (the reference headers need GSL and FFTW-2, which the
- * image lacks); gadget-2.0.7-ngravs_amd/host/host_shim_test.c exercises the same call sequence
- * against a stand-alone copy of the fields used here, and tests/test_host_glue.py runs it.
+ * This repository cannot build the reference (its headers need GSL and FFTW-2); tests/test_host_glue.py compiles this file
+ * with -fsyntax-only -Wall -Werror against tests/glue_stub/ (declarations of exactly the globals and prototypes used here,
+ * layouts from SURVEY.md 8(a')), and host/host_shim_test.c drives the same library calls and the same ngravs_host_*
+ * helpers on the GPU, with two tasks.
+ *
+ * One task (NTask == 1): P[] is handed over with byte strides, results come back in P[]'s order.
+ * Several tasks: the cut of the Peano curve (work-weighted, domain.c:347-544) is found by ngravs_host_domain_owners();
+ * P[] itself is migrated HERE with MPI (it carries Vel, ID, timestep data the library never sees -- domain.c:695-795), the
+ * migrated P[] is handed over, and ngravs_host_domain_halo() / ngravs_host_pmforce_periodic() run the device-side exchanges
+ * through the MPI vtable below.  Results of the first NumPart rows are P[]'s.
  *
  * TreeDomainUpdateFrequency: with 0.0 every step re-decomposes and rebuilds.  With a value > 0 the
  * reference keeps decomposition and tree while fewer than TreeDomainUpdateFrequency*TotNumPart forces have been computed
  * (domain.c:76) and drifts/kicks the node moments instead (predict.c:79-91, timestep.c:331-344); here those steps hand the
- * drifted positions over with ngravs_update_particles() and the library refits the nodes (ngravs_force_update_tree),
- * so force_kick_node()/the node drift loop become no-ops (provided below).
+ * drifted positions over with ngravs_update_particles() and the library refits the nodes (ngravs_force_update_tree), so
+ * force_update_len() and the node drift/kick loops become no-ops (single task only; several tasks always re-decompose).
  */
 #ifdef NGRAVS_BUILD_INSIDE_REFERENCE
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
+#include <mpi.h>
 #include "allvars.h"
 #include "proto.h"
 #include "ngravs.h"
 #include "ngravs_hip.h"
+#include "ngravs_host.h"
+
+#ifndef DOUBLEPRECISION
+#error "libngravs_hip reads P[].Pos / Mass / OldAcc as double: build the reference with -DDOUBLEPRECISION (FLOAT = double, allvars.h:93-97)"
+#endif
+#ifndef UNEQUALSOFTENINGS
+#error "libngravs_hip applies per-type softening lengths: build the reference with -DUNEQUALSOFTENINGS"
+#endif
 
 static ngravs_ctx *Ctx = NULL;
+static ngravs_comm Comm;
+static unsigned char *ActiveFlag = NULL;
 
 /* wired function pointer -> law id (the device cannot call through `gravity` pointers) */
 static int law_id(gravity f)
@@ -42,7 +61,7 @@ static int law_id(gravity f)
     return NGRAVS_LAW_YUKAWA;
   if(f == coloyuk || f == pgcoloyuk || f == normed_pgcoloyuk)
     return NGRAVS_LAW_COLOYUK;
-  printf("ngravs-hip: force law %p has no device implementation\n", (void *)f);
+  printf("ngravs-hip: a wired force law has no device implementation\n");
   endrun(1050);
   return -1;
 }
@@ -62,6 +81,66 @@ static void on_fatal(int code, const char *msg)
 {
   printf("ngravs-hip: %s\n", msg);
   endrun(code > 0 ? code : 1052);
+}
+
+static void must(int rc, int code)
+{
+  if(rc != 0)
+    {
+      printf("ngravs-hip: call failed with status %d: %s\n", rc, Ctx ? ngravs_last_error(Ctx) : "");
+      endrun(code);
+    }
+}
+
+/* ---- the communicator vtable over MPI (include/ngravs_host.h) --------------------------------------------------------- */
+static int mpi_allreduce(void *user, void *buf, int64_t count, int dtype, int op)
+{
+  MPI_Op o = op == NGRAVS_OP_SUM ? MPI_SUM : (op == NGRAVS_OP_MIN ? MPI_MIN : MPI_MAX);
+  (void)user;
+  return MPI_Allreduce(MPI_IN_PLACE, buf, (int)count, dtype == NGRAVS_T_F64 ? MPI_DOUBLE : MPI_LONG_LONG, o, MPI_COMM_WORLD) != MPI_SUCCESS;
+}
+static int mpi_allgather(void *user, const void *send, void *recv, int64_t bytes)
+{
+  (void)user;
+  return MPI_Allgather((void *)send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, MPI_COMM_WORLD) != MPI_SUCCESS;
+}
+/* blocks beyond 2 GB per peer are cut into rounds of <= 1 GB (MPI counts are int) */
+static int mpi_alltoallv(void *user, const void *send, const int64_t *sbytes, const int64_t *sdispl, void *recv,
+                         const int64_t *rbytes, const int64_t *rdispl)
+{
+  const int64_t chunk = 1 << 30;
+  int64_t off = 0, more = 1;
+  int *sc = malloc(sizeof(int) * 4 * NTask), *sd = sc + NTask, *rc = sd + NTask, *rd = rc + NTask, r, err = 0;
+  (void)user;
+  /* displacements are prefix sums of the byte counts: exchange round by round with per-peer offsets */
+  while(more && !err)
+    {
+      MPI_Request *req = malloc(sizeof(MPI_Request) * 2 * NTask);
+      int nreq = 0;
+      more = 0;
+      for(r = 0; r < NTask; r++)
+        {
+          int64_t s = sbytes[r] - off, q = rbytes[r] - off;
+          s = s < 0 ? 0 : (s > chunk ? chunk : s);
+          q = q < 0 ? 0 : (q > chunk ? chunk : q);
+          sc[r] = (int)s;
+          rc[r] = (int)q;
+          if(sbytes[r] - off > chunk || rbytes[r] - off > chunk)
+            more = 1;
+          if(q > 0)
+            err |= MPI_Irecv((char *)recv + rdispl[r] + off, rc[r], MPI_BYTE, r, 7711, MPI_COMM_WORLD, &req[nreq++]) != MPI_SUCCESS;
+        }
+      for(r = 0; r < NTask; r++)
+        if(sc[r] > 0)
+          err |= MPI_Isend((char *)send + sdispl[r] + off, sc[r], MPI_BYTE, r, 7711, MPI_COMM_WORLD, &req[nreq++]) != MPI_SUCCESS;
+      err |= MPI_Waitall(nreq, req, MPI_STATUSES_IGNORE) != MPI_SUCCESS;
+      free(req);
+      off += chunk;
+    }
+  (void)sd;
+  (void)rd;
+  free(sc);
+  return err;
 }
 
 static void ensure_ctx(void)
@@ -104,16 +183,35 @@ static void ensure_ctx(void)
   cfg.yukawa_imass = YUKAWA_IMASS;
 #endif
   cfg.walk_mode = NGRAVS_WALK_GROUP;
-  cfg.rank = ThisTask;
-  cfg.world_size = NTask;
+  /* the library always sees its working set (own particles + halo copies) as one task; the tasks are joined by Comm */
+  cfg.rank = 0;
+  cfg.world_size = 1;
   cfg.device = ThisTask;	/* one rank per GPU of the node */
   if(ngravs_create(&cfg, &Ctx) != NGRAVS_OK)
     endrun(1053);
   ngravs_set_fatal_handler(Ctx, on_fatal);
+  memset(&Comm, 0, sizeof(Comm));
+  Comm.rank = ThisTask;
+  Comm.size = NTask;
+  Comm.device_buffers = 0;	/* set to 1 with a GPU-aware MPI: the exchanges then never touch host memory */
+  Comm.allreduce = mpi_allreduce;
+  Comm.allgather = mpi_allgather;
+  Comm.alltoallv = mpi_alltoallv;
+#ifndef PMGRID
+  if(NTask > 1)
+    {
+      printf("ngravs-hip: several tasks need the finite TreePM cut (PMGRID) for the halo decomposition\n");
+      endrun(1054);
+    }
+#endif
+  if(NTask > 1 && All.TotN_gas > 0)
+    {
+      printf("ngravs-hip: gas particles (SphP[]) are not migrated by this glue\n");
+      endrun(1055);
+    }
 }
 
-static unsigned char *ActiveFlag;
-
+/* hand P[0..NumPart) over: the fields of SURVEY.md 8(b), with the byte strides of struct particle_data */
 static void push_particles(int keep_tree)
 {
   ngravs_particles_t p;
@@ -133,30 +231,142 @@ static void push_particles(int keep_tree)
   p.old_acc_stride = sizeof(struct particle_data);
   p.active = ActiveFlag;
   p.active_stride = 1;
-  if(keep_tree)
-    ngravs_update_particles(Ctx, &p);
-  else
-    ngravs_set_particles(Ctx, &p);
+  p.grav_cost = &P[0].GravCost;	/* the work weight of the next domain cut (domain.c:859-862) */
+  p.grav_cost_stride = sizeof(struct particle_data);
+#ifdef PMGRID
+  if(All.PM_Ti_endstep != All.Ti_Current)	/* P[].GravPM of the last PM step enters OldAcc on non-PM steps (gravtree.c:318-330) */
+    {
+      p.grav_pm = &P[0].GravPM[0];
+      p.grav_pm_stride = sizeof(struct particle_data);
+    }
+#endif
+  must(keep_tree ? ngravs_update_particles(Ctx, &p) : ngravs_set_particles(Ctx, &p), 1056);
+}
+
+/* domain_decompose() bookkeeping (domain.c:173-195) */
+static void count_types(void)
+{
+  int i, j, *temp;
+  for(i = 0; i < 6; i++)
+    NtypeLocal[i] = 0;
+  for(i = 0; i < N_GRAVS; i++)
+    NgravLocal[i] = 0;
+  for(i = 0; i < NumPart; i++)
+    {
+      NtypeLocal[P[i].Type]++;
+      NgravLocal[TypeToGrav[P[i].Type]]++;
+    }
+  temp = malloc(NTask * 6 * sizeof(int));
+  MPI_Allgather(NtypeLocal, 6, MPI_INT, temp, 6, MPI_INT, MPI_COMM_WORLD);
+  for(i = 0; i < 6; i++)
+    {
+      Ntype[i] = 0;
+      for(j = 0; j < NTask; j++)
+	Ntype[i] += temp[j * 6 + i];
+    }
+  free(temp);
+}
+
+/* domain_exchangeParticles (domain.c:695-795) for P[]: every particle goes to dest[i]; one all-to-all-v of whole records */
+static void exchange_particles(const int32_t *dest)
+{
+  int *scount = calloc(4 * NTask, sizeof(int)), *sdispl = scount + NTask, *rcount = sdispl + NTask, *rdispl = rcount + NTask;
+  int i, r, nsend = 0, nrecv = 0, nkeep = 0;
+  struct particle_data *sendbuf;
+  int *cursor;
+  for(i = 0; i < NumPart; i++)
+    if(dest[i] != ThisTask)
+      scount[dest[i]]++;
+  MPI_Alltoall(scount, 1, MPI_INT, rcount, 1, MPI_INT, MPI_COMM_WORLD);
+  for(r = 0; r < NTask; r++)
+    {
+      sdispl[r] = nsend;
+      rdispl[r] = nrecv;
+      nsend += scount[r];
+      nrecv += rcount[r];
+    }
+  if(NumPart - nsend + nrecv > All.MaxPart)
+    {
+      printf("task %d: domain decomposition needs %d particles, MaxPart = %d\n", ThisTask, NumPart - nsend + nrecv, All.MaxPart);
+      endrun(1313);		/* the reference's own code for this condition, domain.c */
+    }
+  sendbuf = malloc(sizeof(struct particle_data) * (nsend > 0 ? nsend : 1));
+  cursor = malloc(sizeof(int) * NTask);
+  for(r = 0; r < NTask; r++)
+    cursor[r] = sdispl[r];
+  for(i = 0; i < NumPart; i++)
+    if(dest[i] != ThisTask)
+      sendbuf[cursor[dest[i]]++] = P[i];
+    else
+      P[nkeep++] = P[i];
+  free(cursor);
+  for(r = 0; r < NTask; r++)	/* counts in bytes */
+    {
+      scount[r] *= sizeof(struct particle_data);
+      sdispl[r] *= sizeof(struct particle_data);
+      rcount[r] *= sizeof(struct particle_data);
+      rdispl[r] *= sizeof(struct particle_data);
+    }
+  MPI_Alltoallv(sendbuf, scount, sdispl, MPI_BYTE, &P[nkeep], rcount, rdispl, MPI_BYTE, MPI_COMM_WORLD);
+  NumPart = nkeep + nrecv;
+  free(sendbuf);
+  free(scount);
 }
 
 /* proto.h:36 */
 void domain_Decomposition(void)
 {
+  double d[8], t0, t1;
   ensure_ctx();
 #ifdef PMGRID
   if(All.PM_Ti_endstep == All.Ti_Current)	/* domain.c:66-73: PM steps always re-decompose (particles get wrapped) */
     All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart * All.TreeDomainUpdateFrequency;
 #endif
-  if(All.NumForcesSinceLastDomainDecomp > All.TotNumPart * All.TreeDomainUpdateFrequency)	/* domain.c:76 */
+  if(NTask > 1 || All.NumForcesSinceLastDomainDecomp > All.TotNumPart * All.TreeDomainUpdateFrequency)	/* domain.c:76 */
     {
+      t0 = second();
 #ifdef PERIODIC
       do_box_wrapping();
 #endif
       push_particles(0);
-      ngravs_domain_decomposition(Ctx);
-      ngravs_get_domain(Ctx, &DomainCorner[0]);	/* DomainCorner[3],DomainCenter[3],DomainLen,DomainFac are contiguous in allvars.c */
+      if(NTask == 1)
+	must(ngravs_domain_decomposition(Ctx), 1057);
+      else
+	{
+	  ngravs_dd_plan plan;
+	  ngravs_dd_info info;
+	  int32_t *dest;
+	  must(ngravs_host_domain_owners(Ctx, &Comm, 0, All.PartAllocFactor, &plan, &info), 1058);
+	  dest = malloc(sizeof(int32_t) * (NumPart > 0 ? NumPart : 1));
+	  must(ngravs_dd_get_dest(Ctx, plan.level, plan.owner_ph, dest), 1059);
+	  exchange_particles(dest);
+	  free(dest);
+	  push_particles(0);	/* the migrated P[]: its order is the order of the library's results */
+	  must(ngravs_host_domain_halo(Ctx, &Comm, &plan, &info), 1060);
+	  ngravs_host_plan_free(&plan);
+	  if(ThisTask == 0)
+	    printf("work-load balance=%g   memory-balance=%g\n", info.work_balance, info.memory_balance);	/* domain.c:257-258 */
+	}
+      /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac are four separate globals (allvars.c:44-47) */
+      must(ngravs_get_domain(Ctx, d), 1061);
+      DomainCorner[0] = d[0];
+      DomainCorner[1] = d[1];
+      DomainCorner[2] = d[2];
+      DomainCenter[0] = d[3];
+      DomainCenter[1] = d[4];
+      DomainCenter[2] = d[5];
+      DomainLen = d[6];
+      DomainFac = d[7];
+      count_types();
       All.NumForcesSinceLastDomainDecomp = 0;
       TreeReconstructFlag = 1;
+      t1 = second();
+      {
+	ngravs_stats_t st;
+	ngravs_get_stats(Ctx, &st);
+	All.CPU_Peano += st.t_peano;	/* device time of keys + sort + gather (peano_hilbert_order) */
+	All.CPU_Domain += timediff(t0, t1) - st.t_peano;
+      }
     }
   else
     push_particles(1);		/* drifted tree: gravity_tree() refits it (ngravs_force_update_tree) */
@@ -199,23 +409,33 @@ void force_treefree(void)
 void gravity_tree(void)
 {
   ngravs_stats_t st;
-  double t0 = second();
+  double t0 = second(), nf = 0, ia = 0, tw = 0, sum[3];
   ensure_ctx();
-  ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc);
-  ngravs_gravity_tree(Ctx);
-  ngravs_get_accel(Ctx, &P[0].GravAccel[0], sizeof(struct particle_data), NULL, 0, &P[0].OldAcc,
-		   sizeof(struct particle_data), &P[0].GravCost, sizeof(struct particle_data), 0);
+  must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
+  must(ngravs_gravity_tree(Ctx), 1063);
+  /* only particles with Ti_endstep == Ti_Current are written (gravtree.c:318-341); inactive rows of P[] keep their values */
+  must(ngravs_get_accel(Ctx, &P[0].GravAccel[0], sizeof(struct particle_data), NULL, 0, &P[0].OldAcc,
+			sizeof(struct particle_data), &P[0].GravCost, sizeof(struct particle_data), 0, 1), 1064);
   TreeReconstructFlag = 0;
   if(All.TypeOfOpeningCriterion == 1)
     All.ErrTolTheta = 0;	/* gravtree.c:334-335 */
   ngravs_get_stats(Ctx, &st);
-  All.TotNumOfForces += st.n_active;
+  sum[0] = (double)st.n_active;
+  sum[1] = st.interactions;
+  sum[2] = st.t_treewalk;
+  MPI_Allreduce(MPI_IN_PLACE, sum, 2, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+  MPI_Allreduce(MPI_IN_PLACE, &sum[2], 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
+  nf = sum[0];
+  ia = sum[1];
+  tw = sum[2];
+  All.TotNumOfForces += (long long)nf;
+  All.NumForcesSinceLastDomainDecomp += (long long)nf;	/* gravtree.c:74-78 */
   All.CPU_TreeConstruction += st.t_treebuild;
   All.CPU_TreeWalk += st.t_treewalk;
+  All.CPU_Imbalance += tw - st.t_treewalk;
   if(ThisTask == 0)
     fprintf(FdTimings, "Step= %d  t= %g  Nf= %ld  part/sec=%g  ia/part=%g  (MI355X, %g s)\n", All.NumCurrentTiStep,
-	    All.Time, (long) st.n_active, st.n_active / (st.t_treewalk + 1e-30), st.interactions / (st.n_active + 1e-30),
-	    timediff(t0, second()));
+	    All.Time, (long)nf, nf / (tw * NTask + 1e-30), ia / (nf + 1e-30), timediff(t0, second()));
 }
 
 #ifdef PMGRID
@@ -229,11 +449,68 @@ void pmforce_periodic(void)
 {
   ngravs_stats_t st;
   ensure_ctx();
-  ngravs_pmforce_periodic(Ctx);
-  ngravs_get_accel(Ctx, NULL, 0, &P[0].GravPM[0], sizeof(struct particle_data), NULL, 0, NULL, 0, 0);
+  if(NTask == 1)
+    must(ngravs_pmforce_periodic(Ctx), 1065);
+  else
+    must(ngravs_host_pmforce_periodic(Ctx, &Comm), 1066);	/* x-slab decomposed mesh, four exchanges */
+  must(ngravs_get_accel(Ctx, NULL, 0, &P[0].GravPM[0], sizeof(struct particle_data), NULL, 0, NULL, 0, 0, 0), 1067);
   ngravs_get_stats(Ctx, &st);
   All.CPU_PM += st.t_pm;
   All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart * All.TreeDomainUpdateFrequency;	/* pm_periodic.c:783 */
+}
+#endif
+
+#ifdef FORCETEST
+/* proto.h:113 -- gravtree_forcetest.c:28-356: direct sums for a random FORCETEST fraction of the active particles, one line
+ * per tested particle in forcetest.txt.  Single task (the direct sum runs over the library's working set). */
+void gravity_forcetest(void)
+{
+  int i, k, nt = 0, *idx;
+  double *acc;
+  char buf[200];
+#ifdef PMGRID
+  if(All.PM_Ti_endstep != All.Ti_Current)
+    return;
+#endif
+  if(NTask > 1)
+    return;
+  idx = malloc(sizeof(int) * (NumPart > 0 ? NumPart : 1));
+  for(i = 0; i < NumPart; i++)
+    if(P[i].Ti_endstep == All.Ti_Current && get_random_number(P[i].ID) < FORCETEST)	/* :54-63 */
+      idx[nt++] = i;
+  if(nt > 0)
+    {
+      acc = malloc(sizeof(double) * 3 * nt);
+      must(ngravs_direct_sum(Ctx, idx, nt, acc), 1068);
+      for(k = 0; k < nt; k++)
+	for(i = 0; i < 3; i++)
+	  P[idx[k]].GravAccelDirect[i] = acc[3 * k + i];
+      free(acc);
+      sprintf(buf, "%s%s", All.OutputDir, "forcetest.txt");
+      if(!(FdForceTest = fopen(buf, "a")))
+	{
+	  printf("error in opening file '%s'\n", buf);
+	  endrun(17);
+	}
+      for(k = 0; k < nt; k++)
+	{
+	  i = idx[k];
+#ifndef PMGRID
+	  fprintf(FdForceTest, "%d %g %g %g %g %g %g %g %g %g %g %g %d\n", P[i].Type, All.Time,
+		  All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2], P[i].GravAccelDirect[0],
+		  P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0], P[i].GravAccel[1], P[i].GravAccel[2],
+		  (int)P[i].ID);	/* :297-303 */
+#else
+	  fprintf(FdForceTest, "%d %f %f %f %f %f %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %d\n", P[i].Type,
+		  All.Time, All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2],
+		  P[i].GravAccelDirect[0], P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0],
+		  P[i].GravAccel[1], P[i].GravAccel[2], P[i].GravPM[0] + P[i].GravAccel[0], P[i].GravPM[1] + P[i].GravAccel[1],
+		  P[i].GravPM[2] + P[i].GravAccel[2], (int)P[i].ID);	/* :305-311 */
+#endif
+	}
+      fclose(FdForceTest);
+    }
+  free(idx);
 }
 #endif
 

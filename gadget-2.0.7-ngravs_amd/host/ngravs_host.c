@@ -1,0 +1,422 @@
+/* ngravs_host.c -- multi-task drivers of the gravity path in plain C over a communicator vtable (include/ngravs_host.h).
+ * Linked into libngravs_hip.so; uses nothing but the public C ABI of include/ngravs_hip.h and the caller's callbacks, so the
+ * same code runs under MPI (host/gadget_glue.c), under RCCL through torch.distributed (distributed.py) and under the
+ * shared-memory communicator of host/host_shim_test.c.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ngravs_host.h"
+
+#define CHECK(expr)            \
+  do                           \
+    {                          \
+      int rc__ = (expr);       \
+      if(rc__ != 0)            \
+        return rc__ < 0 ? rc__ : NGRAVS_ERR_STATE; \
+    }                          \
+  while(0)
+
+/* all-to-all-v of library device buffers; counts in bytes.  Without device-capable transport the blocks go through host memory. */
+static int exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const void *dsend, const int64_t *sbytes, void *drecv, const int64_t *rbytes)
+{
+  const int W = cm->size;
+  int64_t *sd = malloc(sizeof(int64_t) * 2 * (size_t)(W + 1)), *rd = sd + W + 1;
+  int r, rc = 0;
+  if(!sd)
+    return NGRAVS_ERR_NOMEM;
+  sd[0] = rd[0] = 0;
+  for(r = 0; r < W; r++)
+    {
+      sd[r + 1] = sd[r] + sbytes[r];
+      rd[r + 1] = rd[r] + rbytes[r];
+    }
+  if(cm->device_buffers)
+    rc = cm->alltoallv(cm->user, dsend, sbytes, sd, drecv, rbytes, rd);
+  else
+    {
+      void *hs = malloc((size_t)(sd[W] > 0 ? sd[W] : 1)), *hr = malloc((size_t)(rd[W] > 0 ? rd[W] : 1));
+      if(!hs || !hr)
+        rc = NGRAVS_ERR_NOMEM;
+      if(!rc)
+        rc = ngravs_memcpy(ctx, hs, dsend, sd[W], 2);
+      if(!rc)
+        rc = cm->alltoallv(cm->user, hs, sbytes, sd, hr, rbytes, rd);
+      if(!rc)
+        rc = ngravs_memcpy(ctx, drecv, hr, rd[W], 1);
+      free(hs);
+      free(hr);
+    }
+  free(sd);
+  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+}
+
+/* ---- the split of the Peano-cell sequence over the tasks --------------------------------------------------------------- */
+typedef struct
+{
+  const int64_t *count;
+  double maxload;
+  int32_t *owner;
+  int *start, *end;      /* first / last cell of every task */
+  double *load;          /* particles of every task          */
+} split_t;
+
+/* domain_findSplit (domain.c:347-456): bisect the cells [first, last] among ncpu tasks so that the larger of the two average
+ * particle loads is minimal, recursively; fails if a side would exceed maxload per task */
+static int find_split(split_t *S, int cpustart, int ncpu, int first, int last)
+{
+  const int nleft = ncpu / 2, nright = ncpu - nleft;
+  double load = 0, left = 0;
+  int i, split = first + nleft;
+  for(i = first; i <= last; i++)
+    load += (double)S->count[i];
+  for(i = first; i < split; i++)
+    left += (double)S->count[i];
+  while(split < last - (nright - 1) && split > 0)   /* every task keeps at least one cell */
+    {
+      const double cur = fmax(left / nleft, (load - left) / nright);
+      const double nxt = fmax((left + (double)S->count[split]) / nleft, (load - left - (double)S->count[split]) / nright);
+      if(nxt > cur)
+        break;
+      left += (double)S->count[split];
+      split++;
+    }
+  if(left > S->maxload * nleft || load - left > S->maxload * nright)
+    return -1;
+  if(nleft >= 2 && find_split(S, cpustart, nleft, first, split - 1))
+    return -1;
+  if(nright >= 2 && find_split(S, cpustart + nleft, nright, split, last))
+    return -1;
+  if(nleft == 1)
+    {
+      for(i = first; i < split; i++)
+        S->owner[i] = cpustart;
+      S->load[cpustart] = left;
+      S->start[cpustart] = first;
+      S->end[cpustart] = split - 1;
+    }
+  if(nright == 1)
+    {
+      for(i = split; i <= last; i++)
+        S->owner[i] = cpustart + nleft;
+      S->load[cpustart + nleft] = load - left;
+      S->start[cpustart + nleft] = split;
+      S->end[cpustart + nleft] = last;
+    }
+  return 0;
+}
+
+int ngravs_host_split(const int64_t *count, const double *work, int64_t ncell, int ntask, double max_load, int32_t *owner)
+{
+  split_t S;
+  double *wk;
+  int t, moved, rc;
+  int64_t iter = 0, i;
+  if(!count || !owner || ntask < 1 || ncell < ntask)
+    return -1;
+  if(ntask == 1)
+    {
+      for(i = 0; i < ncell; i++)
+        owner[i] = 0;
+      return 0;
+    }
+  S.count = count;
+  S.maxload = max_load > 0 ? max_load : 1e300;
+  S.owner = owner;
+  S.start = malloc(sizeof(int) * 2 * (size_t)ntask);
+  S.end = S.start + ntask;
+  S.load = malloc(sizeof(double) * 2 * (size_t)ntask);
+  wk = S.load + ntask;
+  rc = find_split(&S, 0, ntask, 0, (int)ncell - 1);
+  if(rc == 0 && work)
+    {
+      /* domain_shiftSplit (domain.c:468-544): move boundary cells between neighbours while that lowers the larger of the
+       * two work sums and keeps the particle load within bounds */
+      for(t = 0; t < ntask; t++)
+        wk[t] = 0;
+      for(i = 0; i < ncell; i++)
+        wk[owner[i]] += work[i];
+      do
+        {
+          moved = 0;
+          for(t = 0; t < ntask - 1; t++)
+            {
+              const double maxw = fmax(wk[t], wk[t + 1]);
+              if(wk[t] < wk[t + 1])
+                {
+                  const int cell = S.start[t + 1];
+                  if(S.end[t + 1] <= cell)   /* the neighbour keeps at least one cell */
+                    continue;
+                  if(fmax(wk[t] + work[cell], wk[t + 1] - work[cell]) <= maxw && S.load[t] + (double)count[cell] <= S.maxload)
+                    {
+                      wk[t] += work[cell];
+                      wk[t + 1] -= work[cell];
+                      S.load[t] += (double)count[cell];
+                      S.load[t + 1] -= (double)count[cell];
+                      owner[cell] = t;
+                      S.start[t + 1]++;
+                      S.end[t]++;
+                      moved++;
+                    }
+                }
+              else
+                {
+                  const int cell = S.end[t];
+                  if(S.start[t] >= cell)
+                    continue;
+                  if(fmax(wk[t] - work[cell], wk[t + 1] + work[cell]) <= maxw && S.load[t + 1] + (double)count[cell] <= S.maxload)
+                    {
+                      wk[t] -= work[cell];
+                      wk[t + 1] += work[cell];
+                      S.load[t] -= (double)count[cell];
+                      S.load[t + 1] += (double)count[cell];
+                      owner[cell] = t + 1;
+                      S.end[t]--;
+                      S.start[t + 1]--;
+                      moved++;
+                    }
+                }
+            }
+          iter++;
+        }
+      while(moved > 0 && iter < 10 * ncell);
+    }
+  free(S.start);
+  free(S.load);
+  return rc;
+}
+
+/* ---- domain_Decomposition ------------------------------------------------------------------------------------------------ */
+static int choose_level(const ngravs_config_t *cfg)
+{
+  /* the coarsest cells still at least as wide as the short-range cut (the halo looks one cell layer around a task's cells);
+   * the curve's cube is 1.001 x the box */
+  int lvl = 1;
+  if(cfg->pmgrid > 0)
+    {
+      const double reach = 6.0 * NGRAVS_ASMTH * cfg->box_size / cfg->pmgrid;
+      while(lvl < 5 && cfg->box_size / (double)(1 << (lvl + 1)) >= 1.05 * reach)
+        lvl++;
+      return lvl;
+    }
+  return 4;
+}
+
+void ngravs_host_plan_free(ngravs_dd_plan *plan)
+{
+  if(plan)
+    {
+      free(plan->owner_ph);   /* owner_xyz lives in the same block */
+      plan->owner_ph = plan->owner_xyz = NULL;
+      plan->ncell = 0;
+    }
+}
+
+/* domain_findExtent + domain_sumCost + domain_findSplit + domain_shiftSplit (domain.c:882-924, 823-877, 347-544) */
+int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info)
+{
+  ngravs_config_t cfg;
+  double lo[3], hi[3], total = 0, wtot = 0, wmax = 0, cmax = 0, *work = NULL, *twork = NULL;
+  int64_t *hist = NULL, ncell, i;
+  int32_t *owner_ph = NULL, *owner_xyz;
+  int r, x, y, z, nc, rc = 0, W, me;
+  ngravs_dd_info local;
+  if(!ctx || !cm || !plan || cm->size < 1 || cm->size > 64 || cm->rank < 0 || cm->rank >= cm->size)
+    return NGRAVS_ERR_ARG;
+  W = cm->size;
+  me = cm->rank;
+  (void)me;
+  if(!info)
+    info = &local;
+  memset(info, 0, sizeof(*info));
+  memset(plan, 0, sizeof(*plan));
+  CHECK(ngravs_get_config(ctx, &cfg));
+  if(W > 1 && !cfg.pmgrid)
+    return NGRAVS_ERR_ARG;   /* tree-only runs have no finite cut: they need the node import, not a halo */
+  CHECK(ngravs_dd_local_extent(ctx, lo, hi));
+  CHECK(cm->allreduce(cm->user, lo, 3, NGRAVS_T_F64, NGRAVS_OP_MIN));
+  CHECK(cm->allreduce(cm->user, hi, 3, NGRAVS_T_F64, NGRAVS_OP_MAX));
+  CHECK(ngravs_dd_set_extent(ctx, lo, hi));
+  if(level <= 0)
+    level = choose_level(&cfg);
+  while(level < 7 && (1ll << (3 * level)) < 4ll * W)
+    level++;
+  info->level = level;
+  ncell = 1ll << (3 * level);
+  nc = 1 << level;
+  hist = malloc(sizeof(int64_t) * (size_t)ncell);
+  work = malloc(sizeof(double) * (size_t)ncell);
+  owner_ph = malloc(sizeof(int32_t) * 2 * (size_t)ncell);
+  twork = malloc(sizeof(double) * 2 * (size_t)W);
+  if(!hist || !work || !owner_ph || !twork)
+    rc = NGRAVS_ERR_NOMEM;
+  owner_xyz = owner_ph ? owner_ph + ncell : NULL;
+  if(!rc)
+    rc = ngravs_dd_histogram(ctx, level, hist, work);
+  if(!rc)
+    rc = cm->allreduce(cm->user, hist, ncell, NGRAVS_T_I64, NGRAVS_OP_SUM);
+  if(!rc)
+    rc = cm->allreduce(cm->user, work, ncell, NGRAVS_T_F64, NGRAVS_OP_SUM);
+  if(!rc)
+    {
+      for(i = 0; i < ncell; i++)
+        total += (double)hist[i];
+      if(ngravs_host_split(hist, work, ncell, W, (paf > 0 ? paf : 1.5) * total / W, owner_ph) &&
+         ngravs_host_split(hist, work, ncell, W, 0.0, owner_ph))
+        rc = NGRAVS_ERR_ARG;
+    }
+  if(!rc)
+    {
+      for(r = 0; r < 2 * W; r++)
+        twork[r] = 0;
+      for(i = 0; i < ncell; i++)
+        {
+          twork[owner_ph[i]] += work[i];
+          twork[W + owner_ph[i]] += (double)hist[i];
+        }
+      for(r = 0; r < W; r++)
+        {
+          wtot += twork[r];
+          wmax = fmax(wmax, twork[r]);
+          cmax = fmax(cmax, twork[W + r]);
+        }
+      info->work_balance = wtot > 0 ? wmax / (wtot / W) : 1.0;
+      info->memory_balance = total > 0 ? cmax / (total / W) : 1.0;
+      for(x = 0; x < nc; x++)
+        for(y = 0; y < nc; y++)
+          for(z = 0; z < nc; z++)
+            owner_xyz[((size_t)x * nc + y) * nc + z] = owner_ph[ngravs_peano_hilbert_key(x, y, z, level)];
+      plan->level = level;
+      plan->ncell = ncell;
+      plan->owner_ph = owner_ph;
+      plan->owner_xyz = owner_xyz;
+      owner_ph = NULL;
+    }
+  free(hist);
+  free(work);
+  free(owner_ph);
+  free(twork);
+  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+}
+
+/* one packed-record exchange: what = 0 particle migration (domain_exchangeParticles, domain.c:695-795), what = 1 the
+ * short-range halo (replaces the target export / force import of gravtree.c:195-257) */
+static int record_exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, int what, ngravs_dd_info *info)
+{
+  const int W = cm->size, me = cm->rank;
+  int64_t *counts = malloc(sizeof(int64_t) * (size_t)(3 * 65 + W * W)), *mat, *sb, *rb, nrec = 0, nrecv = 0;
+  void *rec = NULL, *recvbuf = NULL;
+  int r, rc;
+  if(!counts)
+    return NGRAVS_ERR_NOMEM;
+  mat = counts + 65;
+  sb = mat + W * W;
+  rb = sb + 65;
+  rc = ngravs_dd_pack(ctx, what, plan->level, plan->owner_ph, plan->owner_xyz, W, me, counts, &rec, &nrec);
+  if(!rc)
+    rc = cm->allgather(cm->user, counts, mat, (int64_t)sizeof(int64_t) * W);
+  if(!rc)
+    {
+      for(r = 0; r < W; r++)
+        {
+          sb[r] = counts[r] * NGRAVS_DD_RECORD_BYTES;
+          rb[r] = mat[(size_t)r * W + me] * NGRAVS_DD_RECORD_BYTES;
+          nrecv += mat[(size_t)r * W + me];
+          if(r != me)
+            *(what == 0 ? &info->bytes_migration : &info->bytes_halo) += (double)sb[r];
+        }
+      rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
+    }
+  if(!rc)
+    rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
+  if(!rc)
+    rc = what == 0 ? ngravs_dd_apply_migration(ctx, recvbuf, nrecv) : ngravs_dd_set_halo(ctx, recvbuf, nrecv);
+  if(what == 0)
+    info->n_migrated_in = nrecv;
+  else
+    info->n_halo = nrecv;
+  free(counts);
+  return rc;
+}
+
+int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, ngravs_dd_info *info)
+{
+  ngravs_dd_info local;
+  if(!ctx || !cm || !plan || !plan->owner_ph)
+    return NGRAVS_ERR_ARG;
+  if(!info)
+    {
+      memset(&local, 0, sizeof(local));
+      info = &local;
+    }
+  CHECK(record_exchange(ctx, cm, plan, 1, info));
+  info->n_local = ngravs_dd_num_local(ctx);
+  return ngravs_domain_decomposition(ctx);
+}
+
+int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int level, double paf, ngravs_dd_info *info)
+{
+  ngravs_dd_plan plan;
+  ngravs_dd_info local;
+  int rc;
+  if(!info)
+    info = &local;
+  CHECK(ngravs_host_domain_owners(ctx, cm, level, paf, &plan, info));
+  rc = record_exchange(ctx, cm, &plan, 0, info);
+  if(!rc)
+    rc = ngravs_host_domain_halo(ctx, cm, &plan, info);
+  ngravs_host_plan_free(&plan);
+  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+}
+
+/* ---- pmforce_periodic on the slab-decomposed mesh -------------------------------------------------------------------------- */
+int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
+{
+  const int W = cm->size;
+  int32_t bb[6], *all;
+  int64_t *sc, *rc_;
+  void *send = NULL, *recv = NULL;
+  int stage, r, rc;
+  if(!ctx || !cm || W < 1)
+    return NGRAVS_ERR_ARG;
+  all = malloc(sizeof(int32_t) * 6 * (size_t)W);
+  sc = malloc(sizeof(int64_t) * 2 * (size_t)W);
+  if(!all || !sc)
+    {
+      free(all);
+      free(sc);
+      return NGRAVS_ERR_NOMEM;
+    }
+  rc_ = sc + W;
+  rc = ngravs_pm_slab_begin(ctx, cm->rank, W, bb);
+  if(!rc)
+    rc = cm->allgather(cm->user, bb, all, (int64_t)sizeof(bb));   /* meshmin/meshmax lists, pm_periodic.c:285-291 */
+  for(stage = 0; stage < 4 && !rc; stage++)
+    {
+      rc = ngravs_pm_slab_pack(ctx, stage, all, sc, rc_, &send, &recv);
+      for(r = 0; r < W; r++)
+        {
+          sc[r] *= (int64_t)sizeof(double);
+          rc_[r] *= (int64_t)sizeof(double);
+        }
+      if(!rc)
+        rc = exchange(ctx, cm, send, sc, recv, rc_);
+      if(!rc)
+        rc = ngravs_pm_slab_unpack(ctx, stage);
+    }
+  free(all);
+  free(sc);
+  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+}
+
+/* compute_accelerations(0), gravity part (accel.c:24-58) */
+int ngravs_host_compute_accelerations(ngravs_ctx *ctx, const ngravs_comm *cm, int pm_step, ngravs_dd_info *info)
+{
+  ngravs_config_t cfg;
+  CHECK(ngravs_get_config(ctx, &cfg));
+  CHECK(ngravs_host_domain_decomposition(ctx, cm, 0, 0.0, info));
+  if(pm_step && cfg.pmgrid)
+    CHECK(ngravs_host_pmforce_periodic(ctx, cm));
+  return ngravs_gravity_tree(ctx);
+}

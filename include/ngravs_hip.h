@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NGRAVS_ABI_VERSION 1
+#define NGRAVS_ABI_VERSION 2
 #define NGRAVS_MAX_GRAVS 3      /* N_GRAVS upper bound compiled in (allvars.h:130-152)            */
 #define NGRAVS_NTYPES 6         /* Gadget particle types                                           */
 #define NGRAVS_NTAB 2048        /* NTAB: short-range table length (Makefile.reference, forcetree.c:33) */
@@ -126,8 +126,15 @@ typedef struct {
   const double *mass;        /* Mass            */  int64_t mass_stride;
   const int32_t *type;       /* Type            */  int64_t type_stride;
   const double *old_acc;     /* OldAcc (may be NULL => 0) */ int64_t old_acc_stride;
-  const uint8_t *active;     /* NULL => all active; else 1 where Ti_endstep==All.Ti_Current (gravtree.c:113) */
+  const uint8_t *active;     /* NULL => all active; else bit 0 set where Ti_endstep==All.Ti_Current (gravtree.c:113) */
   int64_t active_stride;
+  const double *grav_pm;     /* GravPM[3] of the last PM step (may be NULL => none).  P[].GravPM lives in the host's P[] between
+                              * PM steps; on non-PM steps OldAcc = |GravAccel + GravPM/G| needs it (gravtree.c:318-330) */
+  int64_t grav_pm_stride;
+  const float *grav_cost;    /* GravCost of the last walk (may be NULL => 0): the work weight 1 + GravCost of the domain cut
+                              * (domain.c:859-862).  A host with individual timesteps passes (1 + GravCost)/(Ti_endstep -
+                              * Ti_begstep) - 1 to reproduce the reference's weighting by step frequency. */
+  int64_t grav_cost_stride;
   int32_t on_device;
   int32_t reserved;
 } ngravs_particles_t;
@@ -159,6 +166,20 @@ void ngravs_set_fatal_handler(ngravs_ctx *ctx, ngravs_fatal_fn fn);
 /* Change the walk parameters between calls (All.ErrTolTheta latch, gravtree.c:334-335). */
 int ngravs_set_opening(ngravs_ctx *ctx, double err_tol_theta, double err_tol_force_acc);
 int ngravs_set_walk_mode(ngravs_ctx *ctx, int walk_mode);
+/* the configuration the context was created with (opening parameters as last set) */
+int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
+/* Performance / test parameters of the engine, by name (none changes WHAT is computed beyond rounding; there is no
+ * environment variable and no way to make the library skip work):
+ *   "walk_fused" 1: one fused traversal+evaluation kernel instead of the pair     "walk_batch" n: groups per launch pair
+ *   "walk_waves" n: waves per evaluation workgroup (<= 16)                         "walk_lcap" n: initial item-list capacity (>= 1024)
+ *   "walk_root" 1: TreePM group walks start at the root, not at the start table   "walk_compact" 0: do not compact sparse active sets
+ *   "walk_spread" S: lanes per target for compacted active sets (1..64, 0 = auto)  "walk_exact_reach" 1: fp64 reach test, no fp32 pre-test
+ *   "pm_notile" 1: per-particle CIC deposit     "pm_fused_gather" 1: one-pass gradient+gather    "pm_tile_gather" 1: LDS-tiled gather
+ * Returns NGRAVS_ERR_ARG for an unknown name or a value out of range. */
+int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
+/* Plain copies for hosts that do not link HIP themselves (a C/MPI host staging exchange buffers through host memory):
+ * kind 1 = host->device, 2 = device->host, 3 = device->device.  Synchronous. */
+int ngravs_memcpy(ngravs_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
 
 /* ---- data hand-over ---------------------------------------------------------------------- */
 /* Replace the engine's particle set (the role of P[] + NumPart). */
@@ -190,10 +211,14 @@ int ngravs_pmforce_periodic(ngravs_ctx *ctx);
 int ngravs_compute_accelerations(ngravs_ctx *ctx, int pm_step);
 
 /* ---- results, in the caller's ORIGINAL particle order -------------------------------------- */
-/* Any pointer may be NULL.  stride in bytes as above.  grav_cost = ninteractions (gravtree.c) */
+/* Any pointer may be NULL.  stride in bytes as above.  grav_cost = ninteractions (gravtree.c).
+ * only_active != 0: GravAccel / OldAcc / GravCost are written ONLY for the rows the last hand-over marked active, as the
+ * reference does (gravtree.c:318-341 touch only Ti_endstep == Ti_Current) -- inactive rows of the caller's arrays keep
+ * their values.  only_active == 0: every row is written; rows that were not walked read GravAccel = 0, GravCost = 0 and
+ * their input OldAcc.  GravPM is written for all rows either way (pm_periodic.c:716-763 updates every particle). */
 int ngravs_get_accel(ngravs_ctx *ctx, double *grav_accel, int64_t accel_stride,
                      double *grav_pm, int64_t pm_stride, double *old_acc, int64_t old_acc_stride,
-                     float *grav_cost, int64_t cost_stride, int on_device);
+                     float *grav_cost, int64_t cost_stride, int on_device, int only_active);
 int ngravs_get_stats(ngravs_ctx *ctx, ngravs_stats_t *out);
 /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac (domain.c:916-923) -> out[8] */
 int ngravs_get_domain(ngravs_ctx *ctx, double out[8]);
@@ -234,21 +259,51 @@ int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *a
  *   records = ngravs_dd_pack(1, ...)           -> all-to-all-v          -> ngravs_dd_set_halo()
  *   ngravs_domain_decomposition(); ngravs_pm_deposit() -> all-reduce of ngravs_pm_density() -> ngravs_pm_finish();
  *   ngravs_gravity_tree();  results: the first ngravs_dd_num_local() rows of ngravs_get_accel(), ids from ngravs_dd_get_ids().
- * Records are 48 bytes: x,y,z,mass,old_acc (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64. */
+ * Records are 56 bytes (NGRAVS_DD_RECORD_BYTES): x,y,z,mass,old_acc,grav_cost (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64.
+ * ngravs_host.h holds this sequence as plain C over a communicator vtable (MPI in the reference glue, RCCL in bench.py). */
+#define NGRAVS_DD_RECORD_BYTES 56
 int64_t ngravs_dd_num_local(ngravs_ctx *ctx);
 int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);             /* domain.c:894-905 */
 int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */
-int ngravs_dd_histogram(ngravs_ctx *ctx, int level, int64_t *hist);                  /* 8^level counts, Peano-cell order (host) */
+/* 8^level particle counts and work sums sum(1 + GravCost) (domain_sumCost, domain.c:823-877; work may be NULL), Peano-cell order, host arrays */
+int ngravs_dd_histogram(ngravs_ctx *ctx, int level, int64_t *hist, double *work);
 int ngravs_dd_pack(ngravs_ctx *ctx, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
                    int my_rank, int64_t *counts, void **dev_records, int64_t *nrec);
+/* destination task of every local particle under the owner map (its own rank if it stays), host array of ngravs_dd_num_local() ints */
+int ngravs_dd_get_dest(ngravs_ctx *ctx, int level, const int32_t *owner_ph, int32_t *dest);
+/* a library-owned device buffer for nrec incoming records (valid until the next ngravs_dd_recv_buffer call) */
+int ngravs_dd_recv_buffer(ngravs_ctx *ctx, int64_t nrec, void **dev_records);
 int ngravs_dd_apply_migration(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
 int ngravs_dd_set_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
 int ngravs_dd_set_ids(ngravs_ctx *ctx, const int64_t *ids, int on_device);
 int ngravs_dd_get_ids(ngravs_ctx *ctx, int64_t *ids, int on_device);
-/* pmforce_periodic() in two halves around the all-reduce of the density mesh (pm_periodic.c:333-427) */
+/* pmforce_periodic() in two halves around an all-reduce of the whole density mesh: the simple (replicated-mesh) variant */
 int ngravs_pm_deposit(ngravs_ctx *ctx);
 int ngravs_pm_density(ngravs_ctx *ctx, void **dev, int64_t *count);
 int ngravs_pm_finish(ngravs_ctx *ctx);
+
+/* ---- pmforce_periodic() for many tasks: x-slab decomposed mesh -----------------------------------------------------------
+ * The reference's scheme (pm_periodic.c:74-123 slab tables; :336-427 density patches -> slab owners; :433,:525 distributed
+ * FFT in transposed order; :436-520 Green's function on the transposed layout; :529-670 potential bricks with ghost planes
+ * back; :681-763 finite differences + CIC gather on the brick).  A task deposits its own particles (not its halo copies)
+ * into a brick -- the box of mesh cells (lo[j] + i) mod PMGRID, 0 <= i < ext[j], its CIC clouds touch -- and four
+ * all-to-all-v exchanges move planes of that brick / of the slabs:
+ *     ngravs_pm_slab_begin(ctx, rank, world, bbox);              bbox = {lo[3], ext[3]};   host: all-gather -> all_bbox[world][6]
+ *     for stage = 0..3:
+ *         ngravs_pm_slab_pack(ctx, stage, all_bbox, send_counts, recv_counts, &send, &recv);
+ *         host: all-to-all-v of doubles, send_counts[r] to / recv_counts[r] from task r, blocks in task order, device buffers
+ *         ngravs_pm_slab_unpack(ctx, stage);
+ *   stage 0 density planes -> slab owners (+ 2-D r2c FFTs)   1 transpose x<->y (+ 1-D FFTs, Green, inverse 1-D FFTs)
+ *   stage 2 transpose back (+ 2-D c2r FFTs)                  3 potential planes with 2 ghost cells per side -> bricks
+ *                                                               (+ gradient and CIC gather: GravPM of the own particles)
+ * Task r owns the x planes [r*PMGRID/world, (r+1)*PMGRID/world) (integer division), and the same y range of k-space.
+ * Mesh memory per task: NG x (brick + two slabs + exchange buffers).  world <= PMGRID/2. */
+int ngravs_pm_slab_begin(ngravs_ctx *ctx, int rank, int world, int32_t bbox[6]);
+int ngravs_pm_slab_pack(ngravs_ctx *ctx, int stage, const int32_t *all_bbox, int64_t *send_counts, int64_t *recv_counts,
+                        void **send, void **recv);
+int ngravs_pm_slab_unpack(ngravs_ctx *ctx, int stage);
+/* payload this task sent to OTHER tasks in each of the four exchanges of the last step, bytes */
+int ngravs_pm_slab_bytes(ngravs_ctx *ctx, double bytes[4]);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,8 @@ Tolerances (fp64 path, BASELINE.json north_star):
   * group walk: it never uses a node the reference would have opened, so its error against direct
     summation must not exceed the reference tree's own (ErrTolForceAcc 0.005).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -16,8 +18,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-def _engine(pkg, cfg, pos, mass, typ, **kw):
+def _engine(pkg, cfg, pos, mass, typ, tuning=None, **kw):
     eng = pkg.Engine(cfg)
+    if tuning:
+        eng.set_tuning(**tuning)
     eng.set_particles(pos, mass, typ, **kw)
     return eng
 
@@ -159,8 +163,8 @@ def test_group_walk_tree_only_accuracy(pkg, O):
     eng.close()
 
 
-def test_group_walk_leftover_groups(pkg, O, monkeypatch):
-    """split walk with item lists far too short (NGRAVS_WALK_LCAP): most groups are left over by the traversal kernel
+def test_group_walk_leftover_groups(pkg, O):
+    """split walk with item lists far too short (tuning walk_lcap): most groups are left over by the traversal kernel
     and redone in sub-groups (down to one target per wave = the reference's own per-target tests) by the fused kernel.
     Every target must still get a complete force: accuracy against direct summation between the normal group walk's and
     the reference tree's, same interaction-count scale, and the regions grow for the next step."""
@@ -169,8 +173,8 @@ def test_group_walk_leftover_groups(pkg, O, monkeypatch):
     cfg = pkg.make_config(n_gravs=1, G=1.0, theta=0.5, softening=[0.01] * 6, walk_mode=pkg.WALK_GROUP)
     idx = np.arange(0, n, 40, dtype=np.int32)
 
-    def run():
-        eng = _engine(pkg, cfg, pos, mass, typ)
+    def run(tuning=None):
+        eng = _engine(pkg, cfg, pos, mass, typ, tuning=tuning)
         eng.compute_accelerations(pm_step=False)
         _, old, _ = eng.get_accel()
         eng.set_opening(0.0, 0.005)
@@ -184,8 +188,7 @@ def test_group_walk_leftover_groups(pkg, O, monkeypatch):
         return acc, acc_b, cost, direct, old
 
     acc_n, _, cost_n, direct, old = run()
-    monkeypatch.setenv("NGRAVS_WALK_LCAP", "1024")
-    acc_s, acc_s2, cost_s, _, _ = run()
+    acc_s, acc_s2, cost_s, _, _ = run(tuning={"walk_lcap": 1024})
     cfg_s = pkg.make_config(n_gravs=1, G=1.0, theta=0.0, softening=[0.01] * 6)
     a_o, _ = O.Tree(cfg_s, pos, mass, typ).walk(old_acc=old)
     e_ref = rel_err(O.finish(cfg_s, a_o)[0][idx], direct)
@@ -234,7 +237,7 @@ def test_group_walk_sparse_active_set_vs_ewald(pkg, O):
     """individual timesteps: only ~3 % of the particles are active (gravtree.c:113).  The group walk compacts the active
     targets of the Peano order into groups of 64 (boxes ~3x wider than a 64-particle stretch); accuracy against the Ewald
     golden stays in the reference band, inactive particles are not written, Nf is the active count, and the result agrees
-    with the uncompacted walk (NGRAVS_WALK_COMPACT=0) at the level of the walk error."""
+    with the uncompacted walk (tuning walk_compact=0) at the level of the walk error."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
@@ -249,21 +252,23 @@ def test_group_walk_sparse_active_set_vs_ewald(pkg, O):
     rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
     res = {}
     for compact in ("1", "0", "S8", "S64"):      # S8 / S64: compacted, 8 / 64 lanes per target (sub-groups of 8 / 1 targets)
-        os.environ["NGRAVS_WALK_COMPACT"] = "0" if compact == "0" else "1"
+        tuning = {"walk_compact": 0 if compact == "0" else 1}
         if compact.startswith("S"):
-            os.environ["NGRAVS_WALK_SPREAD"] = compact[1:]
-        try:
-            eng = _engine(pkg, cfg, pos, mass, typ, old_acc=gold["old_acc"], active=active)
-            eng.set_opening(0.0, 0.005)
-            eng.compute_accelerations(pm_step=True)
-            acc, _, cost, gpm = eng.get_accel(want_pm=True)
-            st = eng.stats()
-            eng.close()
-        finally:
-            del os.environ["NGRAVS_WALK_COMPACT"]
-            os.environ.pop("NGRAVS_WALK_SPREAD", None)
+            tuning["walk_spread"] = int(compact[1:])
+        eng = _engine(pkg, cfg, pos, mass, typ, tuning=tuning, old_acc=gold["old_acc"], active=active)
+        eng.set_opening(0.0, 0.005)
+        eng.compute_accelerations(pm_step=True)
+        acc, old_out, cost, gpm = eng.get_accel(want_pm=True)
+        # the reference's semantics: only active rows of P[] are touched (gravtree.c:318-341)
+        sent = (np.full((N, 3), 7.0), np.full(N, 8.0), np.full(N, 9.0, dtype=np.float32))
+        eng.get_accel(into=sent)
+        st = eng.stats()
+        eng.close()
         assert st.n_active == int(active.sum())
         assert np.all(acc[active == 0] == 0) and np.all(cost[active == 0] == 0)
+        assert np.array_equal(old_out[active == 0], gold["old_acc"][active == 0])       # not walked: OldAcc is the input's
+        assert np.all(sent[0][active == 0] == 7.0) and np.all(sent[1][active == 0] == 8.0) and np.all(sent[2][active == 0] == 9.0)
+        assert np.array_equal(sent[0][active == 1], acc[active == 1]) and np.array_equal(sent[1][active == 1], old_out[active == 1])
         res[compact] = (acc, cost, rms(rel_err((acc + gpm)[idx], truth)))
     e_ref = rms(rel_err(gold["ref_total"], truth))
     d = rel_err(res["1"][0][active == 1], res["0"][0][active == 1])
@@ -341,15 +346,108 @@ def test_inactive_particles_and_buckets(pkg, O):
     want = O.direct(cfg, pos, mass, typ, idx)
     for mode in (pkg.WALK_STRICT, pkg.WALK_GROUP):
         cfg.walk_mode = mode
-        eng = _engine(pkg, cfg, pos, mass, typ, active=active)
+        eng = _engine(pkg, cfg, pos, mass, typ, active=active, old_acc=np.full(n, 0.25))
         eng.compute_accelerations(pm_step=False)
         acc, old, cost = eng.get_accel()
         assert np.all(acc[active == 0] == 0) and np.all(cost[active == 0] == 0)     # only active particles are written
+        assert np.all(old[active == 0] == 0.25)                                     # ... and inactive ones keep their OldAcc
+        assert np.allclose(old[active == 1], np.linalg.norm(acc[active == 1], axis=1), rtol=1e-12)
         e = rel_err(acc[idx], want)
         assert np.median(e) < 5e-3 and np.quantile(e, 0.99) < 5e-2     # BH theta=0.4 in a uniform cube: a few weak-force outliers
         st = eng.stats()
         assert st.n_active == int(active.sum())
         eng.close()
+
+
+def test_grav_pm_handed_over_with_the_particles(pkg, O):
+    """A PM step followed by a non-PM step that goes through set_particles again (TreeDomainUpdateFrequency = 0: the glue
+    re-decomposes every step).  P[].GravPM lives in the host's P[] between PM steps; handed over with the particles it must
+    enter OldAcc = |GravAccel + GravPM/G| exactly as in the reference (gravtree.c:318-330) -- the oracle's finish()."""
+    n, L, ng = 20000, 1.0, 2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=21)
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=2.5, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=True)
+    acc1, old1, _, pm1 = eng.get_accel(want_pm=True)
+    # next step: the same particles come in again (fresh P[] hand-over), no PM this step
+    eng.set_particles(pos, mass, typ, old_acc=old1, grav_pm=pm1)
+    eng.compute_accelerations(pm_step=False)
+    acc2, old2, _, pm2 = eng.get_accel(want_pm=True)
+    assert np.array_equal(pm2, pm1)                                   # GravPM survives the hand-over unchanged
+    assert np.allclose(old2, np.linalg.norm(acc2 / cfg.G + pm1 / cfg.G, axis=1), rtol=1e-12)
+    # without GravPM the library cannot know it: OldAcc = |GravAccel| only, and asking for GravPM is a state error
+    eng.set_particles(pos, mass, typ, old_acc=old1)
+    eng.compute_accelerations(pm_step=False)
+    acc3, old3, _ = eng.get_accel()
+    assert np.allclose(old3, np.linalg.norm(acc3 / cfg.G, axis=1), rtol=1e-12)
+    with pytest.raises(pkg.NgravsError):
+        eng.get_pm()
+    # oracle: same walk + finish() with the PM force
+    tab, _ = O.shortrange_table(cfg)
+    T = O.Tree(cfg, pos, mass, typ, O.domain_extent(pos))
+    a_o, _ = T.walk(table=tab)
+    a_fin, old_o = O.finish(cfg, a_o, O.pm_periodic(cfg, pos, mass, typ))
+    assert np.abs(acc2 - a_fin).max() / np.abs(a_fin).max() < TOL
+    assert np.abs(old2 - old_o).max() / old_o.max() < TOL
+    eng.close()
+
+
+def test_slab_pm_one_task_equals_the_3d_transform(pkg, O):
+    """pmforce_periodic on the slab-decomposed mesh (brick deposit, plane exchanges, 2-D + 1-D FFTs with the Green's
+    function on the transposed layout, brick gather) with ONE task must equal the single-task path (3-D FFT on the full
+    mesh) to rounding, and the oracle's pmforce_periodic to 1e-10, for 1, 2 and 3 species."""
+    import importlib
+    import torch.distributed as dist
+    dd = importlib.import_module("ngravs_amd.distributed")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1)
+    for ng, wiring, pmgrid in ((1, "newton", 32), (2, "c4", 48), (3, "c4", 40)):
+        n, L = 30000, 2.5
+        pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=40 + ng)
+        pos[: n // 3] = 0.2 * L + 0.3 * (pos[: n // 3] - 0.2 * L)         # a clump: bricks and slabs see uneven load
+        eps = L / (40 * n ** (1 / 3))
+        kw = dict(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.7, theta=0.5, softening=[eps] * 6,
+                  type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=pkg.WALK_GROUP)
+        eng = pkg.Engine(pkg.make_config(**kw))
+        eng.set_particles(pos, mass, typ)
+        eng.domain_Decomposition()
+        eng.pmforce_periodic()
+        pm_ref = eng.get_pm()
+        eng.close()
+        deng = dd.DistributedEngine(pkg.make_config(**kw))
+        deng.set_particles(pos, mass, typ)
+        deng.domain_Decomposition()
+        deng.pmforce_periodic()
+        deng.n = deng.num_local()
+        pm_slab = deng.get_pm()
+        ids = deng.local_ids()
+        deng.close()
+        full = np.zeros_like(pm_ref)
+        full[ids] = pm_slab
+        scale = np.abs(pm_ref).max()
+        pm_o = O.pm_periodic(pkg.make_config(**kw), pos, mass, typ)
+        print("slab PM, N_GRAVS=%d PMGRID=%d: vs 3-D path %.1e, vs oracle %.1e" %
+              (ng, pmgrid, np.abs(full - pm_ref).max() / scale, np.abs(full - pm_o).max() / scale))
+        assert np.abs(full - pm_ref).max() / scale < 1e-12
+        assert np.abs(full - pm_o).max() / scale < TOL
+
+
+def test_bad_type_on_device_is_rejected(pkg):
+    import torch
+    n = 1000
+    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=2)
+    typ = typ.astype(np.int32)
+    typ[17] = 9
+    dev = torch.device("cuda", 0)
+    d_pos, d_mass, d_typ = torch.from_numpy(pos).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(typ).to(dev)
+    eng = pkg.Engine(pkg.make_config(n_gravs=1, softening=[0.01] * 6))
+    with pytest.raises(pkg.NgravsError):
+        eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_typ.data_ptr())
+    with pytest.raises(pkg.NgravsError):
+        eng.set_tuning(no_such_knob=1)
+    eng.close()
 
 
 def test_error_convention(pkg):
@@ -463,20 +561,18 @@ def test_dynamic_tree_update_refit(pkg, O):
         assert rms(e_refit) < 1.3 * rms(e_fresh) + 1e-3
 
 
-def test_reach_pretest_fp32_and_exact_paths_agree(pkg, O, monkeypatch):
+def test_reach_pretest_fp32_and_exact_paths_agree(pkg, O):
     """the evaluation kernel pre-selects pairs within reach in packed fp32 (threshold widened by the rounding bound) and
-    re-tests r2 < reach2 exactly in the force loop; with NGRAVS_DEBUG=8 the selection itself is done in fp64.  Forces and
+    re-tests r2 < reach2 exactly in the force loop; with tuning walk_exact_reach=1 the selection itself is done in fp64.  Forces and
     interaction counts must be bit-identical (a pair the fp32 test lost would show up here)."""
     n, L, ng = 60000, 1.0, 2
     pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=9)
     eps = L / (40 * n ** (1 / 3))
     res = []
-    for dbg in (None, "8"):
-        if dbg:
-            monkeypatch.setenv("NGRAVS_DEBUG", dbg)
+    for exact in (0, 1):
         cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
                               type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_GROUP)
-        eng = _engine(pkg, cfg, pos, mass, typ)
+        eng = _engine(pkg, cfg, pos, mass, typ, tuning={"walk_exact_reach": exact})
         eng.compute_accelerations(pm_step=True)
         acc, old, cost = eng.get_accel()
         eng.set_opening(0.0, 0.005)

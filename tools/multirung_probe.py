@@ -58,7 +58,7 @@ def main():
         act = (rng.uniform(size=n) < frac).astype(np.uint8) if frac < 1.0 else np.ones(n, dtype=np.uint8)
         d_act = torch.from_numpy(act).to(dev)
         for compact in ("1", "0"):
-            os.environ["NGRAVS_WALK_COMPACT"] = compact
+            eng.set_tuning(walk_compact=int(compact))
             eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_type.data_ptr(), old_acc_ptr=d_old.data_ptr(),
                                      active_ptr=d_act.data_ptr())
             eng.domain_Decomposition()
@@ -67,7 +67,7 @@ def main():
             out["walk_ms_active_%g_compact_%s" % (frac, compact)] = ms
             print("active %.3f compact %s: gravity_tree %.2f ms (%.1f ns per active target)" %
                   (frac, compact, ms, ms * 1e6 / max(1, int(act.sum()))), flush=True)
-        del os.environ["NGRAVS_WALK_COMPACT"]
+        eng.set_tuning(walk_compact=1)
 
     def rebuild():
         eng.domain_Decomposition()
