@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--wiring", default="c4")
     ap.add_argument("--walk", default="group", choices=["group", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="ngravs_set_tuning() parameters, e.g. --tune walk_sg=2 (experiments; the default run sets none)")
     ap.add_argument("--decomp", default=None, choices=["replicated", "domain"],
                     help="N>1: 'domain' (default) = work-weighted Peano-Hilbert domain decomposition: migration + short-range halo "
                          "all-to-all-v, x-slab decomposed PM with four plane exchanges (DESIGN.md Multi-GPU); 'replicated' = every "
@@ -234,6 +236,9 @@ def main():
     else:
         eng = pkg.Engine(cfg)
         eng.set_particles_device(n, d_pos.data_ptr(), d_mass.data_ptr(), d_type.data_ptr())
+    for kv in args.tune:
+        k, v = kv.split("=")
+        eng.set_tuning(**{k: float(v)})
     torch.cuda.synchronize()
 
     # pass 1 (untimed): Barnes-Hut theta=0.5 with OldAcc=0, as the reference's first force computation

@@ -424,6 +424,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.walk_compact = iv != 0;
   else if(k == "walk_spread" && iv >= 0 && iv <= 64 && (iv & (iv - 1)) == 0)
     t.walk_spread = (int)iv;
+  else if(k == "walk_sg" && iv >= 0 && iv <= 16)
+    t.walk_sg = (int)iv;
   else if(k == "walk_exact_reach")
     t.walk_exact_reach = iv != 0;
   else if(k == "pm_notile")
@@ -736,8 +738,15 @@ static int ensure_table(ngravs_ctx *c)
   if(!c->cfg.pmgrid || c->table_ready)
     return NGRAVS_OK;
   const int ng = c->cfg.n_gravs;
-  std::vector<double> h((size_t)ng * ng * NTAB);
+  std::vector<double> h((size_t)(ng * ng + 1) * NTAB);
   host_shortrange_table(&c->cfg, h.data(), nullptr);
+  {
+    // bin-wise Yukawa factor E[tab] = exp(-ym tab/asmthfac) behind the tables (kernels_walk.hip, WalkParams::exp_tab)
+    WalkParams wp;
+    make_walk_params(c, &wp);
+    for(int t = 0; t < NTAB; t++)
+      h[(size_t)ng * ng * NTAB + t] = exp(-wp.ym * (double)t * wp.inv_asmthfac);
+  }
   if(c->table.ensure(h.size()))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemcpyAsync(c->table.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));

@@ -82,6 +82,14 @@ struct WalkParams
   unsigned t2g_packed;   // the same map, 2 bits per type (register-resident lookups)
   // law coefficients [target][source]: accel = m*(cN/r2 + cY*exp(-r ym)(ym/r + 1/r2)); spline = cS*plummer
   double cN[NG_MAX][NG_MAX], cY[NG_MAX][NG_MAX], cS[NG_MAX][NG_MAX];
+  // TreePM short-range tables as the evaluation kernel stages them: identical tables of the symmetric wiring are stored once
+  int ntab_lds;                 // distinct tables
+  int tab_slot[NG_MAX * NG_MAX];   // [target * ng + source] -> slot
+  int slot_src[NG_MAX * NG_MAX];   // slot -> a [target * ng + source] index that holds it
+  // Yukawa factor through the table bins: exp(-ym r) = E[tab] * P5(-ym (r - tab/asmthfac)), E[tab] = exp(-ym tab/asmthfac)
+  // appended to the table buffer (valid while ym * bin width is small, else 0 and exp() is evaluated in full)
+  int exp_tab;
+  double inv_asmthfac;
 };
 
 struct TreeView
@@ -98,7 +106,7 @@ struct TreeView
 // ngravs_set_tuning(): performance / test parameters, set explicitly by the host (no environment variables)
 struct Tuning
 {
-  int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0;
+  int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0, walk_sg = 0;
   long long walk_batch = 0;
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0;
 };
@@ -181,6 +189,7 @@ struct ngravs_ctx
   DevBuf<unsigned char> walk_tmp;
   long long walk_ntargets = -1;   // >= 0: the group walk runs over walk_tlist[0..walk_ntargets)
   int walk_spread = 0;        // > 1: every group of 64 targets is walked as `spread` sub-groups by the fused kernel
+  int walk_sg = 1;            // split walk: groups per traversal unit (shared item lists) of the last launch
   bool all_active = true;     // the caller passed no active flags
   DevBuf<int> walk_ovf;       // split walk: groups left to the fused kernel (lists or LIFO outgrew their region)
   DevBuf<int> walk_counters;  // [1] overflow flag, [2] groups in walk_ovf, [3] of them by the LIFO, [8..15] per-XCD group counters, [16..23] 64-bit walk statistics

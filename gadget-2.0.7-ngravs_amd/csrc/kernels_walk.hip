@@ -543,9 +543,9 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 // =============================================================================================
 #define GW_MAXWAVES 12      // fused kernel: waves per persistent workgroup (3 per SIMD at 168 VGPRs)
 #define GW_STACK 8192       // fused kernel: pending-node LIFO per wave (global scratch)
-// one pool per wave (the species are evaluated one after the other): 128 x (double4 pos/mass, double h, 3 floats = position
-// relative to the group's box centre for the packed-fp32 reach pre-test)
-#define GW2_WAVE_LDS ((sizeof(double4) + sizeof(double) + 3 * sizeof(float)) * 128)
+// one pool per wave (the species are evaluated one after the other): 128 x (double4 pos/mass, 4 floats = position relative to
+// the group's box centre and its square for the packed-fp32 reach pre-test, 1 byte = softening type)
+#define GW2_WAVE_LDS ((sizeof(double4) + 4 * sizeof(float) + 1) * 128)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -570,6 +570,8 @@ __device__ __forceinline__ double exp_neg_fast(double x, const double *__restric
   return ldexp(t * pz, -(mi >> 5));
 }
 
+// wave-level "any lane": the condition's lane mask is compared on the scalar unit (no vector select / compare round trip)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ void wave_sync()
 {
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -621,7 +623,7 @@ __device__ __forceinline__ double wave_max(double v)
 #define GW3_STK_MIN 4096      // split walk: pending-node LIFO ints per group (scap; grown likewise)
 #define GW3_STK_MAX 65536
 #ifndef GW2_ES
-#define GW2_ES 2
+#define GW2_ES 1   // measured at C4 (round 2, after the table-bin exp and the expanded-form masks): 1 -> 91.5 ms, 2 -> 96.8 ms
 #endif
 #define GW2_MAXWAVES 16      // evaluation kernel: 4 waves per SIMD (128 VGPRs), 5 KB of LDS each beside the tables
 #define GW3_TBLOCK 256       // traversal kernel: 4 groups per workgroup
@@ -633,22 +635,26 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
     const double *__restrict__ table, WalkParams wp, long long t_first, long long t_count, int *__restrict__ counter,
     int *__restrict__ stack_base, int *__restrict__ err_flag, double *__restrict__ r_acc, int *__restrict__ r_nint,
     int *__restrict__ region_base, int *__restrict__ gcount, long long g_first, long long g_cnt, int lcap, int scap,
-    int *__restrict__ glist, int S, int G0, const int *__restrict__ tlist)
+    int *__restrict__ glist, int S, int G0, const int *__restrict__ tlist, int SG)
 {
+  // SG (split walk): SG consecutive groups of G targets share ONE traversal and one set of item lists -- a traversal unit.
+  // The evaluation kernel culls the unit's lists against the box of its own group, so pool, masks and forces are those of a
+  // per-group list; the lists (HBM traffic of the hand-over) and the traversal's work shrink by ~SG/1.7.  MODE 1 runs over
+  // units (g_first, g_cnt, the group index are unit indices), MODE 2 over groups.
   constexpr int ES = GW2_ES;   // entries per force-loop trip (independent instruction streams)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // LDS: [tables (if TAB_LDS)] [exp table 32] [per wave: chunk pool 64 x (double4 pos/mass, double h, uchar species)]
   double *tab_s = reinterpret_cast<double *>(smem);
-  constexpr int NTABS = NG * (NG + 1) / 2;
-  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * NTABS * NTAB : 0;
+  const int ntabs = wp.ntab_lds + wp.exp_tab;   // distinct short-range tables [+ the exp(-ym r_bin) table]
+  const size_t tab_bytes = (PM && TAB_LDS) ? sizeof(double) * ntabs * NTAB : 0;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *expT = reinterpret_cast<double *>(smem + tab_bytes);
   unsigned char *wbase = smem + tab_bytes + 40 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
   double *fsT = expT + 32;   // softening length per particle type (8 entries; index 7 = empty node)
   double4 *lpos = reinterpret_cast<double4 *>(wbase);
-  double *lh = reinterpret_cast<double *>(wbase + sizeof(double4) * 2 * WAVE);
-  float *lfx = reinterpret_cast<float *>(wbase + (sizeof(double4) + sizeof(double)) * 2 * WAVE);
-  float *lfy = lfx + 2 * WAVE, *lfz = lfx + 4 * WAVE;
+  float *lfx = reinterpret_cast<float *>(wbase + sizeof(double4) * 2 * WAVE);
+  float *lfy = lfx + 2 * WAVE, *lfz = lfx + 4 * WAVE, *le2 = lfx + 6 * WAVE;
+  unsigned char *lty = wbase + (sizeof(double4) + 4 * sizeof(float)) * 2 * WAVE;
   if(MODE != 1)
     {
       if(threadIdx.x < 32)
@@ -656,15 +662,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       if(threadIdx.x >= 32 && threadIdx.x < 40)
         fsT[threadIdx.x - 32] = threadIdx.x - 32 < NGRAVS_NTYPES ? wp.fsoft[threadIdx.x - 32] : 0.0;
       if(PM && TAB_LDS)
-        for(int t = threadIdx.x; t < NTABS * NTAB; t += blockDim.x)
+        for(int t = threadIdx.x; t < ntabs * NTAB; t += blockDim.x)
           {
-            int u = t / NTAB, a = 0;
-            while(u >= NG - a)
-              {
-                u -= NG - a;
-                a++;
-              }
-            tab_s[t] = table[((size_t)a * NG + (a + u)) * NTAB + (t % NTAB)];
+            const int u = t / NTAB;
+            tab_s[t] = table[(size_t)(u < wp.ntab_lds ? wp.slot_src[u] : NG * NG) * NTAB + (t % NTAB)];
           }
       __syncthreads();
     }
@@ -676,8 +677,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       z.x = z.y = z.z = 1e10;
       z.w = 0.0;
       lpos[127] = z;
-      lh[127] = 0.0;
+      lty[127] = 7;   // fsT[7] = 0: unsoftened
       lfx[127] = lfy[127] = lfz[127] = 1e10f;
+      le2[127] = 3e20f;
     }
   // item lists, one per source species: per-wave scratch (fused) or the group's region (split)
   int *stack = nullptr, *lists[NG];
@@ -774,9 +776,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           grp = glist[w / R];
           tk_base = grp * G0 + (w % R) * G;
         }
+      const long long ru = MODE == 2 ? grp / SG : grp;   // the unit's region in this batch
       if(MODE != 0)
         {
-          int *base = region_base + (size_t)grp * ((size_t)NG * lcap + scap);
+          int *base = region_base + (size_t)ru * ((size_t)NG * lcap + scap);
 #pragma unroll
           for(int g = 0; g < NG; g++)
             lists[g] = base + (size_t)g * lcap;
@@ -785,16 +788,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       grp += gbase;
       // targets: the shard's Peano-ordered particles, or (individual timesteps: few active particles) the compacted list of
       // its active ones, so that a wave works for 64 active targets instead of the few a 64-particle stretch contains
-      const long long tk = (tk_base >= 0 ? tk_base : grp * G) + lane / S;
+      const int nsub = MODE == 1 ? SG : 1;
+      const long long tk = (tk_base >= 0 ? tk_base : grp * G * nsub) + lane / S;
       const bool in_range = tk < t_count;
       const long long ti = tlist ? (in_range ? (long long)tlist[tk] : 0ll) : t_first + tk;
       const bool valid = in_range && (tlist != nullptr || (s_active[ti] & 1) != 0);
-      if(!__any(valid ? 1 : 0))
-        {
-          if(MODE == 1 && lane < NG)
-            gcount[(grp - gbase) * NG + lane] = 0;
-          continue;
-        }
       double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
       int tg = 0;
       if(valid)
@@ -808,17 +806,49 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           hT = wp.fsoft[ptype];
           aold = wp.errtol_acc * s_oldacc[ti];
         }
+      // per-lane extremes over the targets this lane stands for (one; the traversal of a unit: one per group of the unit)
+      double mnx = valid ? px : BIG, mxx = valid ? px : -BIG, mny = valid ? py : BIG, mxy = valid ? py : -BIG;
+      double mnz = valid ? pz : BIG, mxz = valid ? pz : -BIG, mna = valid ? aold : BIG, mnh = valid ? hT : BIG;
+      bool anyvalid = valid;
+      if(MODE == 1)
+        for(int j = 1; j < nsub; j++)
+          {
+            const long long tkj = tk + (long long)j * G;
+            const bool inr = tkj < t_count;
+            const long long tij = tlist ? (inr ? (long long)tlist[tkj] : 0ll) : t_first + tkj;
+            if(inr && (tlist != nullptr || (s_active[tij] & 1) != 0))
+              {
+                const double4 p = s_pm[tij];
+                const int ptype = s_type[tij];
+                mnx = fmin(mnx, p.x);
+                mxx = fmax(mxx, p.x);
+                mny = fmin(mny, p.y);
+                mxy = fmax(mxy, p.y);
+                mnz = fmin(mnz, p.z);
+                mxz = fmax(mxz, p.z);
+                mna = fmin(mna, wp.errtol_acc * s_oldacc[tij]);
+                mnh = fmin(mnh, wp.fsoft[ptype]);
+                anyvalid = true;
+              }
+          }
+      if(!__any(anyvalid ? 1 : 0))
+        {
+          if(MODE == 1 && lane < NG)
+            gcount[(grp - gbase) * NG + lane] = 0;
+          continue;
+        }
       // law coefficients and table row of this lane against the source species being evaluated (set by phase2)
       double cNg = 0, cYg = 0, cSg = 0;
       const double *trow = tabp;
+      const double *const etab = (PM && TAB_LDS) ? tab_s + (size_t)wp.ntab_lds * NTAB : table + (size_t)NG * NG * NTAB;
       // group bounding box and the conservative scalars
-      double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
-      double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
-      double loz = wave_min(valid ? pz : BIG), hiz = wave_max(valid ? pz : -BIG);
+      double lox = wave_min(mnx), hix = wave_max(mxx);
+      double loy = wave_min(mny), hiy = wave_max(mxy);
+      double loz = wave_min(mnz), hiz = wave_max(mxz);
       const double bcx = 0.5 * (lox + hix), bcy = 0.5 * (loy + hiy), bcz = 0.5 * (loz + hiz);
       const double bhx = 0.5 * (hix - lox), bhy = 0.5 * (hiy - loy), bhz = 0.5 * (hiz - loz);
-      const double aold_min = wave_min(valid ? aold : BIG);
-      const double hT_min = wave_min(valid ? hT : BIG);
+      const double aold_min = wave_min(mna);
+      const double hT_min = wave_min(mnh);
       // may sources be wrapped once per group (relative to the box centre) instead of per pair?
       const double bhmax = fmax(bhx, fmax(bhy, bhz));
       const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
@@ -828,12 +858,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       // widened by the worst-case rounding so that no true hit is lost; the force loop re-tests in fp64 (in[k])
       typedef float f2v __attribute__((ext_vector_type(2)));
       const bool fastmask = PM && !lanewrap;
+      // r2 - thr = |e|^2 - 2 e.p + |p|^2 - thr with |e|^2 stored per pool entry: three packed FMAs per two entries.
+      // Rounding: e and p are fp32 roundings of coordinates relative to the box centre (each component <= bhmax + reach), so
+      // the true r2 moves by <= 4 rl dl; the evaluation itself makes <= 8 roundings of magnitudes <= M = 3 (2 bhmax + rl)^2.
       const float tfx = (float)(px - bcx), tfy = (float)(py - bcy), tfz = (float)(pz - bcz);
-      float nthr32;
+      const float m2x = -2.0f * tfx, m2y = -2.0f * tfy, m2z = -2.0f * tfz;
+      float cth;
       {
         const double rl = __builtin_sqrt(wp.reach2);
         const double dl = 4.76837158203125e-07 * (bhmax + rl);   // 2^-21 x the largest relative coordinate
-        nthr32 = -(float)((wp.reach2 + 4.0 * rl * dl) * (1.0 + 2e-6));
+        const double M = 3.0 * (2.0 * bhmax + rl) * (2.0 * bhmax + rl);
+        const double thr = (wp.reach2 + 4.0 * rl * dl + 1.0e-6 * M) * (1.0 + 2e-6);
+        cth = (float)((double)tfx * tfx + (double)tfy * tfy + (double)tfz * tfz - thr);
+        cth = cth - 1.2e-7f * __builtin_fabsf(cth);   // the cast may have rounded up: one ulp down
       }
 
       double ax = 0, ay = 0, az = 0;
@@ -867,7 +904,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             if(PM)
               fpos |= act[k] && !(r2[k] < wp.reach2);
           }
-        if(PM && __any(fpos ? 1 : 0))                                     // rare: beyond the exact cut
+        if(PM && wave_any(fpos))                                          // rare: beyond the exact cut
           {
 #pragma unroll
             for(int k = 0; k < ES; k++)
@@ -890,23 +927,42 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             r[k] = rr;
             const double ri2 = ri * ri;
             double f = cNg * ri2;
-            if(YUK)
-              f += cYg * exp_neg_fast(rr * wp.ym, expT) * (wp.ym * ri + ri2);
+            int tab = 0;
             if(PM)
               {
-                int tab = (int)(wp.asmthfac * rr);                        // saturating conversion, then clamped
+                tab = (int)(wp.asmthfac * rr);                            // saturating conversion, then clamped
                 tab = tab < NTAB - 1 ? tab : NTAB - 1;
-                f -= wp.utor2wpi * trow[tab];
               }
+            if(YUK)
+              {
+                double ex;
+                if(PM && wp.exp_tab)
+                  {
+                    // exp(-ym r) = E[tab] exp(-u), u = ym (r - tab/asmthfac) in [0, ym/asmthfac): degree-5 Taylor (u^6/720 < 1e-17)
+                    const double u = wp.ym * __builtin_fma(-(double)tab, wp.inv_asmthfac, rr);
+                    double pz = -1.0 / 120.0;
+                    pz = __builtin_fma(pz, u, 1.0 / 24.0);
+                    pz = __builtin_fma(pz, u, -1.0 / 6.0);
+                    pz = __builtin_fma(pz, u, 0.5);
+                    pz = __builtin_fma(pz, u, -1.0);
+                    pz = __builtin_fma(pz, u, 1.0);
+                    ex = etab[tab] * pz;
+                  }
+                else
+                  ex = exp_neg_fast(rr * wp.ym, expT);
+                f += cYg * ex * (wp.ym * ri + ri2);
+              }
+            if(PM)
+              f -= wp.utor2wpi * trow[tab];
             fac[k] = f * mw[k] * ri;
             anysoft |= r2[k] < h2max;                                     // closer than the largest softening length at all?
           }
-        if(__any(anysoft ? 1 : 0))                                        // rare: possibly inside the softening radius
+        if(wave_any(anysoft))                                             // rare: possibly inside the softening radius
           {
 #pragma unroll
             for(int k = 0; k < ES; k++)
               {
-                const double h = __builtin_fmax(hT, lh[jj[k]]);           // the pair's softening (forcetree.c:1415-1417)
+                const double h = __builtin_fmax(hT, fsT[lty[jj[k]]]);     // the pair's softening (forcetree.c:1415-1417)
                 const bool soft = r[k] < h;
                 double h_inv = 1 / h, u = r[k] * h_inv;
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
@@ -942,7 +998,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
 #pragma unroll
       for(int g = 0; g < NG; g++)
         {
-          n_items[g] = MODE == 2 ? gcount[(grp - gbase) * NG + g] : 0;
+          n_items[g] = MODE == 2 ? gcount[ru * NG + g] : 0;
           bad |= n_items[g] < 0;
         }
       auto STK = [&](int i) -> int & { return stack[i]; };
@@ -1035,10 +1091,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         cYg = wp.cY[tg][g];
         cSg = wp.cS[tg][g];
         if(PM && TAB_LDS)
-          {
-            const int a = tg < g ? tg : g, b = tg < g ? g : tg;
-            trow = tabp + (size_t)(a * NG - a * (a - 1) / 2 + (b - a)) * NTAB;
-          }
+          trow = tabp + (size_t)wp.tab_slot[tg * NG + g] * NTAB;
         else
           trow = tabp + ((size_t)tg * NG + g) * NTAB;
         // golden-ratio stride, coprime with n: item (i * s) mod n is visited i-th
@@ -1076,7 +1129,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           slot = slot >= n ? slot - n : slot;
           return it;
         };
-        auto fetch_rec = [&](int c0, int item, double4 &q, double &hs) {
+        auto fetch_rec = [&](int c0, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
           q.x = q.y = q.z = q.w = 0;
           hs = 0;
           if(c0 + lane < n)
@@ -1088,7 +1141,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   // which would pull another cache line)
                   const double4 *src = item >= 0 ? s_pm + item : tv.mom + k;
                   q = *src;
-                  hs = wp.fsoft[0];
+                  hs = 0;
                 }
               else
                 {
@@ -1102,23 +1155,23 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     ty = s_type[item];
                   else
                     ty = (tv.flags[k / NG] >> 2) & 7;
-                  hs = fsT[ty];
+                  hs = ty;
                 }
             }
         };
         int item1 = fetch_item(0);
         double4 q1;
-        double hs1;
+        int hs1;
         fetch_rec(0, item1, q1, hs1);
         int item2 = fetch_item(WAVE);
         double4 *pp = lpos;
-        double *ph = lh;
+        unsigned char *ph = lty;
         for(int c0 = 0; c0 < n + WAVE; c0 += WAVE)
           {
             const bool last = c0 >= n;
             const bool have = c0 + lane < n;
             double4 q = q1;
-            const double hs = hs1;
+            const int hs = hs1;
             fetch_rec(c0 + WAVE, item2, q1, hs1);   // chunk c+1
             item2 = fetch_item(c0 + 2 * WAVE);       // chunk c+2
             bool live = have && q.w != 0.0;
@@ -1147,10 +1200,12 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               {
                 const int o = npool + lane_prefix(lm);
                 pp[o] = q;
-                ph[o] = hs;
-                lfx[o] = (float)ex;
-                lfy[o] = (float)ey;
-                lfz[o] = (float)ez;
+                ph[o] = (unsigned char)hs;
+                const float fx = (float)ex, fy = (float)ey, fz = (float)ez;
+                lfx[o] = fx;
+                lfy[o] = fy;
+                lfz[o] = fz;
+                le2[o] = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
               }
             npool += __popcll(lm);
             wave_sync();
@@ -1168,7 +1223,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   {
                     // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
                     // (v_alignbit), highest entry first so that entry j ends up in bit j
-                    const f2v p_x = {tfx, tfx}, p_y = {tfy, tfy}, p_z = {tfz, tfz}, n2 = {nthr32, nthr32};
+                    const f2v p_x = {m2x, m2x}, p_y = {m2y, m2y}, p_z = {m2z, m2z}, c2 = {cth, cth};
 #pragma unroll
                     for(int w = 0; w < 2; w++)
                       {
@@ -1179,10 +1234,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                             const f2v e_x = *reinterpret_cast<const f2v *>(lfx + 32 * w + 2 * b);
                             const f2v e_y = *reinterpret_cast<const f2v *>(lfy + 32 * w + 2 * b);
                             const f2v e_z = *reinterpret_cast<const f2v *>(lfz + 32 * w + 2 * b);
-                            const f2v dx = e_x - p_x, dy = e_y - p_y, dz = e_z - p_z;
-                            f2v r = __builtin_elementwise_fma(dx, dx, n2);
-                            r = __builtin_elementwise_fma(dy, dy, r);
-                            r = __builtin_elementwise_fma(dz, dz, r);
+                            f2v r = *reinterpret_cast<const f2v *>(le2 + 32 * w + 2 * b) + c2;
+                            r = __builtin_elementwise_fma(e_x, p_x, r);
+                            r = __builtin_elementwise_fma(e_y, p_y, r);
+                            r = __builtin_elementwise_fma(e_z, p_z, r);
                             word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.y), 31);
                             word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.x), 31);
                           }
@@ -1260,7 +1315,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       }
                     m = 0;
                   }
-                while(__any(m != 0 ? 1 : 0))
+                while(wave_any(m != 0))
                   {
                     st_iters += ES;
                     bool act[ES];
@@ -1285,8 +1340,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // move the remainder to the front
                 const int rem = npool - nc;
                 double4 tq;
-                double th = 0;
-                float t0 = 0, t1 = 0, t2 = 0;
+                unsigned char th = 0;
+                float t0 = 0, t1 = 0, t2 = 0, t3 = 0;
                 tq.x = tq.y = tq.z = tq.w = 0;
                 if(lane < rem)
                   {
@@ -1295,6 +1350,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     t0 = lfx[WAVE + lane];
                     t1 = lfy[WAVE + lane];
                     t2 = lfz[WAVE + lane];
+                    t3 = le2[WAVE + lane];
                   }
                 wave_sync();
                 if(lane < rem)
@@ -1304,6 +1360,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     lfx[lane] = t0;
                     lfy[lane] = t1;
                     lfz[lane] = t2;
+                    le2[lane] = t3;
                   }
                 npool = rem;
                 wave_sync();
@@ -1617,10 +1674,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         }
       else
         {
-          if(MODE == 2)
+          if(MODE == 2 && (grp - gbase) % SG == 0)   // the unit's traversal statistics, once
             {
-              st_nodes = gcount[NG * g_cnt + (grp - gbase)];
-              st_batches = gcount[(NG + 1) * g_cnt + (grp - gbase)];
+              const long long u_cnt = (g_cnt + SG - 1) / SG;
+              st_nodes = gcount[NG * u_cnt + ru];
+              st_batches = gcount[(NG + 1) * u_cnt + ru];
             }
           acc_st[0] += (unsigned long long)st_entries;
           acc_st[1] += (unsigned long long)st_nodes;
@@ -1797,6 +1855,35 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
       wp->reach2 = reach * reach;
     }
   wp->ym = cfg.box_size > 0 ? cfg.yukawa_imass / cfg.box_size : 0.0;
+  // distinct short-range tables of the wiring (same law pair <=> same table), and the bin-wise Yukawa factor
+  {
+    const int ng = cfg.n_gravs;
+    wp->ntab_lds = 0;
+    for(int k = 0; k < ng * ng; k++)
+      {
+        int found = -1;
+        for(int u = 0; u < wp->ntab_lds && found < 0; u++)
+          {
+            const int q = wp->slot_src[u];
+            if(cfg.law_accel[q / ng][q % ng] == cfg.law_accel[k / ng][k % ng] &&
+               cfg.law_normed[q / ng][q % ng] == cfg.law_normed[k / ng][k % ng])
+              found = u;
+          }
+        if(found < 0)
+          {
+            found = wp->ntab_lds++;
+            wp->slot_src[found] = k;
+          }
+        wp->tab_slot[k] = found;
+      }
+    wp->exp_tab = 0;
+    wp->inv_asmthfac = 0;
+    if(cfg.pmgrid && wp->asmthfac > 0)
+      {
+        wp->inv_asmthfac = 1.0 / wp->asmthfac;
+        wp->exp_tab = (wp->ym * wp->inv_asmthfac < 4.0e-3) ? 1 : 0;   // u^6/720 < 6e-18
+      }
+  }
   wp->fac_intp = cfg.box_size > 0 ? 2.0 * LAT_EN / cfg.box_size : 0.0;   // forcetree.c:3737
   for(int t = 0; t < NGRAVS_NTYPES; t++)
     {
@@ -1981,7 +2068,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT>
 static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nullptr, int nlist = 0)
 {
   // lanes per target: the walk's own S, or for the leftover pass (glist) enough to give the few scattered groups many waves
-  const int S0 = c->walk_spread > 1 ? c->walk_spread : 1, G0 = WAVE / S0;
+  const int S0 = c->walk_spread > 1 ? c->walk_spread : 1, G0 = (WAVE / S0) * (glist ? c->walk_sg : 1);
   int S = S0;
   if(glist)
     {
@@ -1993,7 +2080,7 @@ static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nul
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 40 * sizeof(double);
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (wp.ntab_lds + wp.exp_tab) * NTAB : 0) + 40 * sizeof(double);
   // one persistent workgroup per CU with as many waves as fit beside the tables (or several smaller ones)
   int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   int per_cu = 1;
@@ -2019,7 +2106,7 @@ static int launch_group2_t(ngravs_ctx *c, const WalkParams &wp, int *glist = nul
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p,
                      c->s_type.p, c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                      walk_tcount(c), c->walk_counters.p, c->walk_stack.p, c->walk_counters.p + 1, c->r_acc.p,
-                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, glist ? (long long)nlist : 0ll, 0, 0, glist, S, G0, walk_tlist(c));
+                     c->r_nint.p, (int *)nullptr, (int *)nullptr, 0ll, glist ? (long long)nlist : 0ll, 0, 0, glist, S, G0, walk_tlist(c), 1);
   return NGRAVS_OK;
 }
 
@@ -2031,7 +2118,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   hipDeviceProp_t prop;
   if(hipGetDeviceProperties(&prop, c->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
     ncu = prop.multiProcessorCount;
-  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (NG * (NG + 1) / 2) * NTAB : 0) + 40 * sizeof(double);
+  const size_t fixed = ((PM && TAB_LDS) ? sizeof(double) * (wp.ntab_lds + wp.exp_tab) * NTAB : 0) + 40 * sizeof(double);
   int waves = (int)((160 * 1024 - fixed) / GW2_WAVE_LDS);
   if(waves > GW2_MAXWAVES)
     waves = GW2_MAXWAVES;   // register-limited: 4 waves per SIMD (__launch_bounds__), one workgroup per CU
@@ -2042,11 +2129,21 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   const size_t lds = fixed + (size_t)waves * GW2_WAVE_LDS;
   const int S = c->walk_spread > 1 ? c->walk_spread : 1, G = WAVE / S;
   const long long ngroups = (walk_tcount(c) + G - 1) / G;
-  // per-group region: NG item lists of lcap ints + the LIFO.  lcap starts small and is doubled (persistently) by walk_run
+  // groups per traversal unit: 4 for TreePM walks of Peano-contiguous targets (the short-range region of 256 neighbours is
+  // 1.7 x that of 64: lists and traversal work per target fall to ~0.4), 1 for tree-only walks (no cut: a wider box opens more
+  // of the tree for every target) and for scattered (compacted / spread) targets
+  int SG = (PM && c->walk_ntargets < 0) ? 4 : 1;
+  if(c->tune.walk_sg >= 1)
+    SG = c->tune.walk_sg;
+  if(SG != c->walk_sg)
+    c->walk_lcap = 0;   // list capacities are per unit
+  c->walk_sg = SG;
+  const long long nunits = (ngroups + SG - 1) / SG;
+  // per-unit region: NG item lists of lcap ints + the LIFO.  lcap starts small and is doubled (persistently) by walk_run
   // when a list overflows; the batch shrinks so that the scratch stays within ~8 GB
   if(c->walk_lcap < 1024)
     {
-      c->walk_lcap = NG == 1 ? 2 * GW3_LIST_MIN : GW3_LIST_MIN;
+      c->walk_lcap = (NG == 1 ? 2 : 1) * (SG > 1 ? 2 : 1) * GW3_LIST_MIN;
       if(c->tune.walk_lcap >= 1024)   // tests: small lists force the leftover pass
         c->walk_lcap = c->tune.walk_lcap;
     }
@@ -2057,7 +2154,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   // batches as large as memory comfortably allows (every traversal/evaluation launch pair costs ~0.4 ms of ramp and tail:
   // 16 / 8 / 1 launches per step at C4 measured 114 / 107 / 104 ms of evaluation): a quarter of the free device memory, at
   // least 8 GB and at most 64 GB, unless NGRAVS_WALK_BATCH fixes the group count
-  long long batch = 1 << 20;
+  long long batch = 1 << 20;   // units per launch pair
   size_t cap_bytes = (size_t)8 << 30;
   {
     size_t free_b = 0, total_b = 0;
@@ -2077,19 +2174,19 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     }
   while(batch > 8192 && (size_t)batch * region_ints * sizeof(int) > cap_bytes)
     batch /= 2;
-  if(batch > ngroups)
-    batch = ngroups;
+  if(batch > nunits)
+    batch = nunits;
   if(batch < 1)
     batch = 1;
   if(c->walk_stack.ensure((size_t)batch * (region_ints + NG + 2)) || c->walk_counters.ensure(32) ||
-     c->walk_ovf.ensure((size_t)ngroups))
+     c->walk_ovf.ensure((size_t)nunits))
     return NGRAVS_ERR_NOMEM;
   int *region = c->walk_stack.p, *gcount = c->walk_stack.p + (size_t)batch * region_ints;
   HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
   auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
   auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const size_t nbatches = (size_t)((ngroups + batch - 1) / batch);
+  const size_t nbatches = (size_t)((nunits + batch - 1) / batch);
   while(c->ev_batch.size() < 3 * nbatches)
     {
       hipEvent_t e;
@@ -2098,15 +2195,16 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     }
   c->walk_batches = (int)nbatches;
   size_t ib = 0;
-  for(long long g0 = 0; g0 < ngroups; g0 += batch, ib++)
+  for(long long u0 = 0; u0 < nunits; u0 += batch, ib++)
     {
-      const long long nb = ngroups - g0 < batch ? ngroups - g0 : batch;
+      const long long nbu = nunits - u0 < batch ? nunits - u0 : batch;   // units of this batch
+      const long long g0 = u0 * SG, nb = ngroups - g0 < nbu * SG ? ngroups - g0 : nbu * SG;   // its groups
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib], c->stream));
-      const long long tblk = 8 * (((nb + GW3_TBLOCK / 64 - 1) / (GW3_TBLOCK / 64) + 7) / 8);
+      const long long tblk = 8 * (((nbu + GW3_TBLOCK / 64 - 1) / (GW3_TBLOCK / 64) + 7) / 8);
       hipLaunchKernelGGL(kt, dim3((unsigned)tblk), dim3(GW3_TBLOCK), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          walk_tcount(c), c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c));
+                         c->r_nint.p, region, gcount, u0, nbu, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c), SG);
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 1], c->stream));
       if(g0 > 0)
         HIP_TRY(c, hipMemsetAsync(c->walk_counters.p + 8, 0, sizeof(int) * 8, c->stream));
@@ -2116,7 +2214,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
       hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          walk_tcount(c), c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,
-                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c));
+                         c->r_nint.p, region, gcount, g0, nb, lcap, scap, c->walk_ovf.p, S, G, walk_tlist(c), SG);
       HIP_TRY(c, hipEventRecord(c->ev_batch[3 * ib + 2], c->stream));
     }
   return NGRAVS_OK;
@@ -2129,7 +2227,20 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
   if(!glist)
     c->walk_batches = 0;
   const bool pm = c->cfg.pmgrid != 0, yuk = has_yukawa(c);
-  constexpr bool TL = (NG <= 2);   // NG=3: 96 KB of tables beside the pools would leave 9 waves; measured equal to 16 waves reading them through L1/L2
+  // tables in LDS while they leave room for the pools of 16 waves (three 16 KB tables incl. the exp table; the C5 wiring --
+  // Newton on the diagonal, one law off it -- has two distinct ones); otherwise they are read through L1/L2
+  constexpr bool TL = (NG <= 2);
+  if constexpr(NG == 3)
+    if(pm && wp.ntab_lds + wp.exp_tab <= 3)
+      {
+        if(allow_split && !c->tune.walk_fused && !glist)
+          {
+            *used_split = true;
+            return has_yukawa(c) ? launch_group3_t<NG, true, true, true, false>(c, wp) : launch_group3_t<NG, true, false, true, false>(c, wp);
+          }
+        return has_yukawa(c) ? launch_group2_t<NG, true, true, true, false>(c, wp, glist, nlist)
+                             : launch_group2_t<NG, true, false, true, false>(c, wp, glist, nlist);
+      }
   const bool v2 = c->tune.walk_fused != 0;   // fused kernel for the whole walk
   if(allow_split && !v2 && !glist)
     {
@@ -2272,7 +2383,7 @@ int walk_run(ngravs_ctx *c)
               HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
               HIP_TRY(c, hipMemcpyAsync(st64, c->walk_counters.p + 16, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
               HIP_TRY(c, hipStreamSynchronize(c->stream));
-              const int Gs = WAVE / (c->walk_spread > 1 ? c->walk_spread : 1);
+              const int Gs = (WAVE / (c->walk_spread > 1 ? c->walk_spread : 1)) * c->walk_sg;
               const long long ng = (walk_tcount(c) + Gs - 1) / Gs;
               if((long long)ovf[0] * 256 > ng)
                 {

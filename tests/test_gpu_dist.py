@@ -36,11 +36,14 @@ def _worker(rank, world, port, out_dir):
     acc, oa, cost, pm = eng.get_accel(want_pm=True)
     ids = eng.local_ids()
     first_mig, first_halo = eng.timings["migrated"], eng.timings["halo"]
-    eng.compute_accelerations(pm_step=True)               # second step: nothing should migrate any more
+    eng.compute_accelerations(pm_step=True)               # second step: the cut is now weighted by the first step's GravCost
     acc2, _, _, pm2 = eng.get_accel(want_pm=True)
     ids2 = eng.local_ids()
-    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ids=ids, acc=acc, pm=pm, cost=cost, ids2=ids2, acc2=acc2, pm2=pm2,
-             mig=np.array([first_mig, eng.timings["migrated"], first_halo, eng.num_local()]),
+    second_mig = eng.timings["migrated"]
+    eng.compute_accelerations(pm_step=True)               # third step: same particles, same costs -> same cut, nothing moves
+    ids3 = eng.local_ids()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), ids=ids, acc=acc, pm=pm, cost=cost, ids2=ids2, ids3=ids3, acc2=acc2, pm2=pm2,
+             mig=np.array([first_mig, eng.timings["migrated"], first_halo, eng.num_local(), second_mig]),
              pm_bytes=np.array(eng.pm_bytes()), balance=np.array([eng.info.work_balance, eng.info.memory_balance]))
     eng.close()
     dist.destroy_process_group()
@@ -63,8 +66,9 @@ def test_three_rank_domain_decomposition(pkg, tmp_path):
         pm[d["ids"]] = d["pm"]
         seen[d["ids"]] += 1
         mig = d["mig"]
-        assert mig[0] > 0 and mig[1] == 0 and mig[2] > 0          # first step migrates, second does not; halo non-empty
-        assert np.array_equal(np.sort(d["ids"]), np.sort(d["ids2"]))
+        # first step migrates most particles, the second only what the work-weighted cut shifts, the third nothing; halo non-empty
+        assert mig[0] > 0 and mig[4] < mig[0] // 4 and mig[1] == 0 and mig[2] > 0
+        assert np.array_equal(np.sort(d["ids2"]), np.sort(d["ids3"]))
         nloc.append(int(mig[3]))
     assert np.all(seen == 1)                                       # every particle owned exactly once
     assert max(nloc) < 1.5 * N / world                             # the memory bound of the split (PartAllocFactor 1.5)

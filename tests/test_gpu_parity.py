@@ -403,7 +403,7 @@ def test_slab_pm_one_task_equals_the_3d_transform(pkg, O):
     dd = importlib.import_module("ngravs_amd.distributed")
     if not dist.is_initialized():
         dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1)
-    for ng, wiring, pmgrid in ((1, "newton", 32), (2, "c4", 48), (3, "c4", 40)):
+    for ng, wiring, pmgrid in ((1, "newton", 32), (2, "c4", 64), (3, "c4", 32)):
         n, L = 30000, 2.5
         pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=40 + ng)
         pos[: n // 3] = 0.2 * L + 0.3 * (pos[: n // 3] - 0.2 * L)         # a clump: bricks and slabs see uneven load
