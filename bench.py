@@ -44,16 +44,59 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
     return b
 
 
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_walk_traffic.json")
+
+
+def walk_source_hash():
+    """sha256 (first 16 hex digits) of the walk kernels' source: ties a PMC profile to the code it was taken from"""
+    import hashlib
+    with open(os.path.join(ROOT, "gadget-2.0.7-ngravs_amd", "csrc", "kernels_walk.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def walk_traffic(args, n, world, launches):
-    """HBM-side bytes per launch of the walk's evaluation kernel from the committed rocprofv3 --pmc passes (profiles/),
-    only when the run IS that workload (PMC counters cannot be collected inside this process); rescaled if the step is
-    cut into a different number of launches than when it was profiled"""
-    path = os.path.join(ROOT, "profiles", "r01h_walk_traffic.json")
-    if args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and os.path.exists(path):
-        with open(path) as f:
-            d = json.load(f)
-        return d["traffic_bytes_per_launch"] * d.get("launches_per_step", 1) / max(1, launches)
-    return None
+    """HBM-side bytes per launch of the walk's evaluation kernel.  PMC counters cannot be collected inside this process:
+    the figure comes from the committed rocprofv3 --pmc passes of THIS workload (tools/profile_c4.sh), and only while the
+    kernel source is the one that was profiled -- otherwise traffic is null.  Returns (bytes or None, provenance)."""
+    path = os.path.join(ROOT, TRAFFIC_PROFILE)
+    prov = {"source": TRAFFIC_PROFILE, "walk_source_sha16": walk_source_hash()}
+    if not (args.config == "c4" and n == (1 << 26) and world == 1 and args.walk == "group" and not args.tune):
+        prov["status"] = "not the profiled workload"
+        return None, prov
+    if not os.path.exists(path):
+        prov["status"] = "no profile committed"
+        return None, prov
+    with open(path) as f:
+        d = json.load(f)
+    prov["profiled_kernel"] = d.get("kernel")
+    prov["profiled_walk_source_sha16"] = d.get("walk_source_sha16")
+    if d.get("walk_source_sha16") != prov["walk_source_sha16"]:
+        prov["status"] = "stale: kernels_walk.hip changed since the profile was taken"
+        return None, prov
+    prov["status"] = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this workload and this source"
+    return d["traffic_bytes_per_launch"] * d.get("launches_per_step", 1) / max(1, launches), prov
+
+
+def accuracy_block(pkg, eng, n, dev, samples=256):
+    """tree + PM of the timed configuration against the periodic direct sum over ALL sources (nearest image + lattice
+    correction tables: the truth gravity_forcetest() uses, forcetree.c:3428-3548) for `samples` seeded targets, on the GPU"""
+    import torch
+    d_acc = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_pm = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_cost = torch.empty(n, dtype=torch.float32, device=dev)
+    eng.get_accel_device(acc_ptr=d_acc.data_ptr(), pm_ptr=d_pm.data_ptr(), cost_ptr=d_cost.data_ptr())
+    idx = np.sort(np.random.default_rng(7).choice(n, samples, replace=False)).astype(np.int32)
+    sel = torch.from_numpy(idx.astype(np.int64)).to(dev)
+    tot = (d_acc[sel] + d_pm[sel]).cpu().numpy()
+    ia = float(d_cost.double().mean().item())
+    del d_acc, d_pm, d_cost
+    t0 = time.time()
+    truth = eng.direct_sum(idx)
+    e = np.linalg.norm(tot - truth, axis=1) / np.linalg.norm(truth, axis=1)
+    return {"truth": "periodic direct sum over all %d sources on the GPU (ngravs_direct_sum)" % n, "samples": int(samples),
+            "rms": float(np.sqrt(np.mean(e ** 2))), "median": float(np.median(e)), "p99": float(np.percentile(e, 99)),
+            "max": float(e.max()), "ia_per_particle": ia, "seconds": time.time() - t0,
+            "reference_band": "reference TreePM walk at the same ErrTolForceAcc: rms 6.5e-3 ... 9.6e-3 (SURVEY.md 6)"}
 
 
 def make_box(pkg, n, L, n_gravs, seed):
@@ -149,6 +192,7 @@ def main():
     ap.add_argument("--wiring", default="c4")
     ap.add_argument("--walk", default="group", choices=["group", "strict"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the direct-sum accuracy check after the timed region")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
                     help="ngravs_set_tuning() parameters, e.g. --tune walk_sg=2 (experiments; the default run sets none)")
     ap.add_argument("--decomp", default=None, choices=["replicated", "domain"],
@@ -311,7 +355,7 @@ def main():
                                    (args.config.upper(), n, "Plummer sphere" if treeonly else "uniform periodic box", args.ngravs,
                                     args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
-                       "parallelism": ("Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, all-reduced PM mesh" % world)
+                       "parallelism": ("work-weighted Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, x-slab decomposed PM (4 plane exchanges)" % world)
                        if domain else ("walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world),
                        "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
                                      "treewalk": ph[3] * 1e3},
@@ -322,9 +366,14 @@ def main():
                        "step_fraction_of_hbm_roofline": value / world * step_alg_bytes(args.ngravs, cells_per_particle, pm=not treeonly) / HBM_PEAK},
             "roofline": {"bound": "hbm", "kernel": kname, "split_walk": split,
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": walk_traffic(args, n, world, split["launches_per_step"] if split else 1),
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
         }
+        out["roofline"]["traffic"], out["roofline"]["traffic_provenance"] = walk_traffic(args, n, world, split["launches_per_step"] if split else 1)
+        if world == 1 and not treeonly and not args.no_accuracy:
+            out["accuracy"] = accuracy_block(pkg, eng, n, dev)
+        else:
+            out["accuracy"] = None
         if not args.no_cpu_baseline and world == 1 and not treeonly:
             out["cpu_baseline"] = cpu_baseline(pkg, args.ngravs, args.wiring, cells_per_particle)
         else:

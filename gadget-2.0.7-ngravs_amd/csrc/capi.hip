@@ -426,6 +426,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.walk_spread = (int)iv;
   else if(k == "walk_sg" && iv >= 0 && iv <= 16)
     t.walk_sg = (int)iv;
+  else if(k == "walk_nleaf" && iv >= -1 && iv <= 8)
+    t.walk_nleaf = (int)iv;
   else if(k == "walk_exact_reach")
     t.walk_exact_reach = iv != 0;
   else if(k == "pm_notile")

@@ -70,6 +70,7 @@ template <typename T> struct DevBuf
 struct WalkParams
 {
   int ng, periodic, pm, use_theta;
+  int nleaf;                // group walk: an opened node with <= nleaf particles hands over its particles directly (0: only buckets)
   int exact_reach;          // group walk: exact fp64 reach test instead of the packed-fp32 pre-test (ngravs_set_tuning)
   double box, boxhalf;
   double theta2;            // ErrTolTheta^2
@@ -106,7 +107,7 @@ struct TreeView
 // ngravs_set_tuning(): performance / test parameters, set explicitly by the host (no environment variables)
 struct Tuning
 {
-  int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0, walk_sg = 0;
+  int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0, walk_sg = 0, walk_nleaf = -1;
   long long walk_batch = 0;
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0;
 };

@@ -1490,7 +1490,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
                         open = true;
                       if(open)
-                        dec = ((fl & FLAG_BUCKET) || count <= GW_NLEAF) ? 3 : 2;
+                        dec = ((fl & FLAG_BUCKET) || count <= wp.nleaf) ? 3 : 2;
                       else
                         dec = 1;
                     }
@@ -1835,6 +1835,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
   wp->pm = cfg.pmgrid != 0;
   wp->use_theta = cfg.err_tol_theta != 0;
   wp->exact_reach = c->tune.walk_exact_reach;
+  wp->nleaf = c->tune.walk_nleaf < 0 ? GW_NLEAF : c->tune.walk_nleaf;
   wp->box = cfg.box_size;
   wp->boxhalf = 0.5 * cfg.box_size;
   wp->theta2 = cfg.err_tol_theta * cfg.err_tol_theta;

@@ -103,5 +103,5 @@ def test_total_force_against_periodic_direct_sum(pkg, big):
     e = rel_err((acc + pm)[idx], truth)
     print("2^%d particles: rms %.2e median %.2e max %.2e, %.1f interactions/particle" %
           (N_LOG2, np.sqrt(np.mean(e ** 2)), np.median(e), e.max(), cost.mean()))
-    assert np.sqrt(np.mean(e ** 2)) < 1.2e-2 and e.max() < 0.1
+    assert np.sqrt(np.mean(e ** 2)) <= 9.6e-3 and e.max() < 0.1      # the reference's own measured band
     eng.close()

@@ -62,7 +62,10 @@ def main():
             return sum(h) / len(h)
         fb, wb = timed_mean(traffic.get("FETCH_SIZE", [0])), timed_mean(traffic.get("WRITE_SIZE", [0]))
         with open(out_json, "w") as f:
-            json.dump({"kernel": "k_walk_group2<2,true,true,true,false,2> (evaluation)", "workload": "C4 64M",
+            import hashlib
+            src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gadget-2.0.7-ngravs_amd", "csrc", "kernels_walk.hip")
+            sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+            json.dump({"kernel": "k_walk_group2<2,true,true,true,false,2> (evaluation)", "workload": "C4 64M", "walk_source_sha16": sha,
                        "launches_per_step": len(traffic.get("FETCH_SIZE", [0])) - len(traffic.get("FETCH_SIZE", [0])) // 2,
                        "fetch_bytes_reported": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the evaluation-kernel "
