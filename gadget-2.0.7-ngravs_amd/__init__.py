@@ -35,7 +35,8 @@ EXPORTS = [
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_dd_histogram", "ngravs_dd_pack",
     "ngravs_dd_apply_migration", "ngravs_dd_set_halo", "ngravs_dd_set_ids", "ngravs_dd_get_ids",
-    "ngravs_dd_recv_buffer", "ngravs_dd_get_dest", "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
+    "ngravs_dd_recv_buffer", "ngravs_dd_get_dest", "ngravs_dd_cell_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack_cells",
+    "ngravs_dd_set_top", "ngravs_get_domain_extent", "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)

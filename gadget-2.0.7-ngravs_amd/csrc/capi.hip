@@ -317,6 +317,12 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->dd_owner_xyz.release();
   c->dd_send.release();
   c->dd_recv.release();
+  c->top.gcnt.release();
+  c->top.cellxyz.release();
+  c->top.gsum.release();
+  c->top.partial.release();
+  c->top.reqmask.release();
+  c->n_prefix.release();
   c->s_pm.release();
   c->s_type.release();
   c->s_active.release();
@@ -601,6 +607,7 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   else
     {
       c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over ...
+      c->top.level = 0;
       c->pm_parked = false;
       if(p->grav_pm && c->cfg.pmgrid)
         {
@@ -1118,6 +1125,52 @@ extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, int level, const int32_t 
         reach += c->dom[6] - c->cfg.box_size;   // the curve's cube is 1.001 x the box: seam slack, conservative
     }
   return dd_pack(c, what, level, owner_ph, owner_xyz, nranks, my_rank, reach, counts, dev_records, nrec);
+}
+
+extern "C" int ngravs_get_domain_extent(ngravs_ctx *c, double out[8])
+{
+  if(!c || !c->extent_override || !out)
+    return NGRAVS_ERR_STATE;
+  memcpy(out, c->dom, sizeof(double) * 8);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_dd_cell_sums(ngravs_ctx *c, int level, double *cells)
+{
+  if(!c || !c->have_particles || !c->extent_override || !cells || level < 1 || level > 7)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_cell_sums(c, level, cells);
+}
+
+extern "C" int ngravs_dd_target_bounds(ngravs_ctx *c, double out[2])
+{
+  if(!c || !c->have_particles || !out)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_target_bounds(c, out);
+}
+
+extern "C" int ngravs_dd_pack_cells(ngravs_ctx *c, int level, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts,
+                                    void **dev_records, int64_t *nrec)
+{
+  if(!c || !c->have_particles || !c->extent_override || !reqmask || !counts || !dev_records || !nrec)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_pack_cells(c, level, (const unsigned long long *)reqmask, nranks, my_rank, counts, dev_records, nrec);
+}
+
+extern "C" int ngravs_dd_set_top(ngravs_ctx *c, int level, const double *gcells, const uint8_t *present)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  if(level > 0 && c->cfg.periodic && !c->cfg.pmgrid)
+    {
+      ngravs_report(c, NGRAVS_ERR_ARG, "multi-task periodic tree-only runs (lattice correction walk) are not supported");
+      return NGRAVS_ERR_ARG;
+    }
+  (void)hipSetDevice(c->cfg.device);
+  return dd_set_top(c, level, gcells, present);
 }
 
 extern "C" int ngravs_dd_get_dest(ngravs_ctx *c, int level, const int32_t *owner_ph, int32_t *dest)

@@ -21,6 +21,10 @@
 #define NG_MAX NGRAVS_MAX_GRAVS
 #define NTAB NGRAVS_NTAB
 #define TREE_BITS NGRAVS_TREE_BITS
+// n_flags bits beyond the reference's bitflags 2-5 (max-softening type, mixed softening)
+#define FLAG_BUCKET 64     // bit 6: the node holds its particles directly (deepest level)
+#define FLAG_PSEUDO 128    // bit 7: top-level cell whose particles live on another task: global monopoles, no children
+#define FLAG_PARTIAL 256   // bit 8: the cell contains particles that are not on this task (never handed over as a leaf)
 #define MAX_LEVELS (TREE_BITS + 1)
 
 struct ngravs_ctx;
@@ -112,6 +116,25 @@ struct Tuning
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0;
 };
 
+// The global top of the tree for multi-task runs (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996,
+// with the reference's adaptive TopNodes replaced by the complete Peano cells of one level): every task knows, for every
+// cell of levels 0..level, the GLOBAL particle count and per-species mass / first moments.  The tree build forces the
+// topology of those levels from the global counts, so that it is the single-task tree's; a level-`level` cell whose
+// particles are not on this task becomes a pseudo node (global monopoles, no children).
+#define TOP_CW(ng) (7 + 4 * (ng))   // doubles per cell: count, particles per type [6], per species m, m x, m y, m z
+struct TopTree
+{
+  int level = 0;                       // 0: off (single task)
+  int tab_level = 0;                   // level the geometry table (cellxyz) was built for
+  std::vector<long long> off;          // off[d] = index of the first cell of level d in the per-level tables
+  DevBuf<int> gcnt;                    // global count per cell
+  DevBuf<int> cellxyz;                 // ix | iy << 10 | iz << 20 of the cell with that Peano prefix
+  DevBuf<double> gsum;                 // TOP_CW doubles per cell
+  DevBuf<unsigned char> partial;       // cell contains particles that are not on this task
+  DevBuf<unsigned long long> reqmask;  // per level-`level` cell: tasks that asked for its particles
+  std::vector<int> h_cellxyz;
+};
+
 // slab-decomposed particle mesh of the multi-task path (kernels_pmslab.hip)
 struct PmSlab
 {
@@ -134,6 +157,8 @@ struct ngravs_ctx
   ngravs_config_t cfg;
   Tuning tune;
   PmSlab pms;
+  TopTree top;
+  DevBuf<int> n_prefix;       // Peano prefix of a node's cell (top levels of a multi-task tree)
   ngravs_fatal_fn on_fatal = nullptr;
   hipStream_t stream = nullptr;
   double asmth = 0, rcut = 0;
@@ -228,6 +253,11 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
             int64_t *counts, void **dev_records, int64_t *nrec);
 int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest);
+int dd_cell_sums(ngravs_ctx *c, int level, double *cells);
+int dd_target_bounds(ngravs_ctx *c, double out[2]);
+int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records,
+                  int64_t *nrec);
+int dd_set_top(ngravs_ctx *c, int level, const double *gcells, const unsigned char *present);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
 // ---- kernels_tree.hip

@@ -573,6 +573,115 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
   return NGRAVS_OK;
 }
 
+// ---- the global top of the tree (multi-task) ---------------------------------------------------------------------------
+// per-cell sums of the own particles: count, particles per type, per species mass and first moments (the local part of
+// DomainMoment[], forcetree.c:766-850, for every Peano cell of `level`)
+__global__ void k_dd_cellsums(const double *__restrict__ pos, const double *__restrict__ mass, const int *__restrict__ type, long long n,
+                              double cx, double cy, double cz, double fac21, int level, int ng, unsigned t2g_packed,
+                              double *__restrict__ cells)
+{
+  __shared__ unsigned short step[48][8];
+  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
+    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
+  __syncthreads();
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int ix, iy, iz;
+  long long cell;
+  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+  const int ty = type[i], g = (int)((t2g_packed >> (2 * ty)) & 3u);
+  double *c = cells + (size_t)cell * TOP_CW(ng);
+  const double m = mass[i];
+  atomicAdd(&c[0], 1.0);
+  atomicAdd(&c[1 + ty], 1.0);
+  atomicAdd(&c[7 + 4 * g + 0], m);
+  atomicAdd(&c[7 + 4 * g + 1], m * pos[3 * i + 0]);
+  atomicAdd(&c[7 + 4 * g + 2], m * pos[3 * i + 1]);
+  atomicAdd(&c[7 + 4 * g + 3], m * pos[3 * i + 2]);
+}
+
+int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
+{
+  const long long ncell = 1ll << (3 * level), n = c->n_local;
+  const int cw = TOP_CW(c->cfg.n_gravs);
+  DevBuf<double> d;
+  if(d.ensure((size_t)ncell * cw))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(double) * ncell * cw, c->stream));
+  double fac21;
+  dd_fac(c, &fac21);
+  unsigned t2g_packed = 0;
+  for(int t = 0; t < NGRAVS_NTYPES; t++)
+    t2g_packed |= ((unsigned)(c->cfg.type_to_grav[t] & 3)) << (2 * t);
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_cellsums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p, n,
+                       c->dom[0], c->dom[1], c->dom[2], fac21, level, c->cfg.n_gravs, t2g_packed, d.p);
+  HIP_TRY(c, hipMemcpyAsync(cells, d.p, sizeof(double) * ncell * cw, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  d.release();
+  return NGRAVS_OK;
+}
+
+// smallest ErrTolForceAcc * OldAcc and smallest softening length over the own ACTIVE particles: what the conservative
+// opening tests of a whole domain need (the group walk uses the same two minima per group)
+__global__ void k_dd_bounds(const double *__restrict__ oldacc, const int *__restrict__ type, const unsigned char *__restrict__ active,
+                            long long n, WalkParams wp, double *__restrict__ out)
+{
+  double a = 1e300, h = 1e300;
+  for(long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if(active[i] & 1)
+      {
+        a = fmin(a, wp.errtol_acc * oldacc[i]);
+        h = fmin(h, wp.fsoft[type[i]]);
+      }
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      a = fmin(a, __shfl_down(a, off));
+      h = fmin(h, __shfl_down(h, off));
+    }
+  if((threadIdx.x & 63) == 0)
+    {
+      // doubles >= 0 order like their bit patterns
+      atomicMin((unsigned long long *)&out[0], (unsigned long long)__double_as_longlong(a));
+      atomicMin((unsigned long long *)&out[1], (unsigned long long)__double_as_longlong(h));
+    }
+}
+
+int dd_target_bounds(ngravs_ctx *c, double out[2])
+{
+  if(c->red_tmp.ensure(2))
+    return NGRAVS_ERR_NOMEM;
+  double big[2] = {1e300, 1e300};
+  HIP_TRY(c, hipMemcpyAsync(c->red_tmp.p, big, sizeof(big), hipMemcpyHostToDevice, c->stream));
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  if(c->n_local > 0)
+    hipLaunchKernelGGL(k_dd_bounds, dim3(512), dim3(256), 0, c->stream, c->in_oldacc.p, c->in_type.p, c->in_active.p, (long long)c->n_local,
+                       wp, c->red_tmp.p);
+  HIP_TRY(c, hipMemcpyAsync(out, c->red_tmp.p, sizeof(big), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NGRAVS_OK;
+}
+
+// every own particle goes to the tasks that asked for its cell
+__global__ void k_dd_dest_cells(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
+                                const unsigned long long *__restrict__ reqmask, int me, unsigned long long *__restrict__ mask)
+{
+  __shared__ unsigned short step[48][8];
+  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
+    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
+  __syncthreads();
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  int ix, iy, iz;
+  long long cell;
+  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+  mask[i] = reqmask[cell] & ~(1ull << me);
+}
+
 // destination task of every local particle (host array): what the migration pack would do, without packing
 int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest)
 {
@@ -590,6 +699,126 @@ int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest)
   HIP_TRY(c, hipMemcpyAsync(dest, d.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   d.release();
+  return NGRAVS_OK;
+}
+
+// cell import: the records of the own particles of every cell another task asked for (what = 2 of the pack family)
+int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records,
+                  int64_t *nrec)
+{
+  if(nranks > 64 || level < 1 || level > 7)
+    return NGRAVS_ERR_ARG;
+  const long long n = c->n_local, ncell = 1ll << (3 * level);
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->top.reqmask.ensure(ncell) || c->dd_counts.ensure(3 * 65 + 2))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(c->top.reqmask.p, reqmask, sizeof(unsigned long long) * ncell, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
+  double fac21;
+  dd_fac(c, &fac21);
+  unsigned nb = (unsigned)((n + 255) / 256);
+  std::vector<unsigned long long> h(65, 0), offs(65, 0);
+  if(n > 0)
+    {
+      hipLaunchKernelGGL(k_dd_dest_cells, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
+                         c->top.reqmask.p, me, c->dd_mask.p);
+      hipLaunchKernelGGL(k_dd_count, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
+      HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+  long long tot = 0;
+  for(int r = 0; r < nranks; r++)
+    {
+      offs[r] = tot;
+      counts[r] = (int64_t)h[r];
+      tot += h[r];
+    }
+  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(DDRecord)))
+    return NGRAVS_ERR_NOMEM;
+  if(tot > 0)
+    {
+      HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
+      hipLaunchKernelGGL(k_dd_fill, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
+                         c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
+                         (DDRecord *)c->dd_send.p);
+    }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  *dev_records = c->dd_send.p;
+  *nrec = tot;
+  c->dd_last_what = 2;
+  return NGRAVS_OK;
+}
+
+// The global cell table of level `level` (all-reduced dd_cell_sums) and which of those cells are present on this task
+// (own or imported): the tables of all coarser levels are aggregated here and uploaded for the tree build.
+int dd_set_top(ngravs_ctx *c, int level, const double *gcells, const unsigned char *present)
+{
+  TopTree &t = c->top;
+  if(level <= 0)
+    {
+      t.level = 0;
+      return NGRAVS_OK;
+    }
+  if(level > 7 || !gcells || !present)
+    return NGRAVS_ERR_ARG;
+  const int cw = TOP_CW(c->cfg.n_gravs);
+  t.off.assign(level + 2, 0);
+  for(int d = 0; d <= level; d++)
+    t.off[d + 1] = t.off[d] + (1ll << (3 * d));
+  const long long tot = t.off[level + 1];
+  // geometry: the cell (ix, iy, iz) behind every Peano prefix of every level (depends on the level only)
+  if(t.tab_level != level)
+    {
+      t.h_cellxyz.assign((size_t)tot, 0);
+      for(int d = 0; d <= level; d++)
+        {
+          const int nc = 1 << d;
+          for(int x = 0; x < nc; x++)
+            for(int y = 0; y < nc; y++)
+              for(int z = 0; z < nc; z++)
+                t.h_cellxyz[(size_t)(t.off[d] + ngravs_ph_key(x, y, z, d))] = x | (y << 10) | (z << 20);
+        }
+      if(t.cellxyz.ensure((size_t)tot))
+        return NGRAVS_ERR_NOMEM;
+      HIP_TRY(c, hipMemcpyAsync(t.cellxyz.p, t.h_cellxyz.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      t.tab_level = level;
+    }
+  std::vector<double> sum((size_t)tot * cw, 0.0);
+  std::vector<int> cnt((size_t)tot, 0);
+  std::vector<unsigned char> part((size_t)tot, 0);
+  const long long ncell = 1ll << (3 * level);
+  memcpy(&sum[(size_t)t.off[level] * cw], gcells, sizeof(double) * ncell * cw);
+  for(long long i = 0; i < ncell; i++)
+    {
+      cnt[(size_t)(t.off[level] + i)] = (int)(gcells[(size_t)i * cw] + 0.5);
+      part[(size_t)(t.off[level] + i)] = (cnt[(size_t)(t.off[level] + i)] > 0 && !present[i]) ? 1 : 0;
+    }
+  for(int d = level - 1; d >= 0; d--)
+    for(long long p = 0; p < (1ll << (3 * d)); p++)
+      {
+        double *dst = &sum[(size_t)(t.off[d] + p) * cw];
+        int cc = 0;
+        unsigned char pp = 0;
+        for(int k = 0; k < 8; k++)      // fixed order: the same sums on every task
+          {
+            const size_t ch = (size_t)(t.off[d + 1] + p * 8 + k);
+            for(int q = 0; q < cw; q++)
+              dst[q] += sum[ch * cw + q];
+            cc += cnt[ch];
+            pp |= part[ch];
+          }
+        cnt[(size_t)(t.off[d] + p)] = cc;
+        part[(size_t)(t.off[d] + p)] = pp;
+      }
+  if(t.gcnt.ensure((size_t)tot) || t.gsum.ensure((size_t)tot * cw) || t.partial.ensure((size_t)tot))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(t.gcnt.p, cnt.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.gsum.p, sum.data(), sizeof(double) * tot * cw, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.partial.p, part.data(), (size_t)tot, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  t.level = level;
+  c->have_tree = false;
   return NGRAVS_OK;
 }
 

@@ -19,7 +19,6 @@
 #include "engine.hpp"
 #include <hipcub/hipcub.hpp>
 
-#define FLAG_BUCKET 64   // bit 6: node holds its particles directly (deepest level)
 
 __device__ __forceinline__ int key_digit(unsigned long long k, int level)   // digit deciding the child of a level-`level` node
 {
@@ -27,9 +26,14 @@ __device__ __forceinline__ int key_digit(unsigned long long k, int level)   // d
 }
 
 // child[] encoding after this kernel: -1 empty, -2-p particle p, >=0 : start particle of a sub-range (fixed up in k_link)
+// Multi-task trees: for a node of the global top (level < top level) the KIND of every child follows from the GLOBAL particle
+// count of the child cell (gcnt_next[prefix * 8 + k]) -- 0: empty, 1: particle leaf, >= 2: node -- whatever part of it is
+// present on this task; so the topology of the top levels is the single-task tree's (forcetree.c:292-431 builds the same
+// top-level nodes from the global TopNodes on every task).
 __global__ void k_split(const unsigned long long *__restrict__ key, const int *__restrict__ n_first,
                         const int *__restrict__ n_count, int node0, int nnodes_level, int level,
-                        int *__restrict__ n_child, int *__restrict__ n_nchild)
+                        int *__restrict__ n_child, int *__restrict__ n_nchild, const int *__restrict__ gcnt_next = nullptr,
+                        const int *__restrict__ n_prefix = nullptr)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
@@ -71,9 +75,16 @@ __global__ void k_split(const unsigned long long *__restrict__ key, const int *_
   for(int k = 0; k < 8; k++)
     {
       int c = b[k + 1] - b[k], v;
-      if(c == 0)
+      int kind = c;                                          // 0 empty, 1 particle, >= 2 node
+      if(gcnt_next)
+        {
+          kind = gcnt_next[(long long)n_prefix[node] * 8 + k];
+          if(kind == 1 && c != 1)
+            kind = 0;                                        // a single particle that lives elsewhere: its parent is never opened here
+        }
+      if(kind == 0)
         v = -1;
-      else if(c == 1)
+      else if(kind == 1)
         v = -2 - b[k];
       else
         {
@@ -89,7 +100,9 @@ __global__ void k_split(const unsigned long long *__restrict__ key, const int *_
 __global__ void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_first, int *__restrict__ n_count,
                        int *__restrict__ n_child, double4 *__restrict__ n_geo, int *__restrict__ n_flags,
                        const int *__restrict__ scan, int node0, int nnodes_level, int next0, int level,
-                       double cx, double cy, double cz, double fac21)
+                       double cx, double cy, double cz, double fac21, int *__restrict__ n_prefix = nullptr,
+                       const int *__restrict__ xyz_next = nullptr, const unsigned char *__restrict__ partial_next = nullptr,
+                       int top_level = 0)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
@@ -120,21 +133,41 @@ __global__ void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_fir
       n_child[8 * (long long)node + k] = cn;
       n_first[cn] = starts[k];
       n_count[cn] = e - starts[k];
-      // geometric octant of the child from its first particle's cell coordinates; centre recurrence
-      // of forcetree.c:190-206 (centre +- 0.25*len of the parent)
-      double4 p = s_pm[starts[k]];
-      int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
-      int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
-      int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
-      int sh = TREE_BITS - 1 - level;
+      // geometric octant of the child from its first particle's cell coordinates (or, in the global top of a multi-task
+      // tree, where a cell may hold no local particle, from the cell table); centre recurrence of forcetree.c:190-206
+      // (centre +- 0.25*len of the parent)
+      int ox, oy, oz, fl = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
+      if(xyz_next)
+        {
+          const int pc = n_prefix[node] * 8 + k, xyz = xyz_next[pc];
+          ox = xyz & 1;
+          oy = (xyz >> 10) & 1;
+          oz = (xyz >> 20) & 1;
+          n_prefix[cn] = pc;
+          if(partial_next[pc])
+            fl |= FLAG_PARTIAL;
+          if(level + 1 == top_level && e - starts[k] == 0)
+            fl |= FLAG_PSEUDO;          // all of its particles live on other tasks (forcetree.c:345-431 pseudo particle)
+        }
+      else
+        {
+          double4 p = s_pm[starts[k]];
+          int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
+          int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
+          int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
+          int sh = TREE_BITS - 1 - level;
+          ox = (ix >> sh) & 1;
+          oy = (iy >> sh) & 1;
+          oz = (iz >> sh) & 1;
+        }
       double q = 0.25 * g.w;
       double4 cg;
-      cg.x = ((ix >> sh) & 1) ? g.x + q : g.x - q;
-      cg.y = ((iy >> sh) & 1) ? g.y + q : g.y - q;
-      cg.z = ((iz >> sh) & 1) ? g.z + q : g.z - q;
+      cg.x = ox ? g.x + q : g.x - q;
+      cg.y = oy ? g.y + q : g.y - q;
+      cg.z = oz ? g.z + q : g.z - q;
       cg.w = 0.5 * g.w;
       n_geo[cn] = cg;
-      n_flags[cn] = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
+      n_flags[cn] = fl;
     }
 }
 
@@ -261,7 +294,87 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
       o.w = m[g];
       n_mom[(long long)node * NG + g] = o;
     }
-  n_flags[node] = (fl & FLAG_BUCKET) | (4 * sa.maxsofttype + 32 * sa.diff);
+  n_flags[node] = (fl & (FLAG_BUCKET | FLAG_PSEUDO | FLAG_PARTIAL)) | (4 * sa.maxsofttype + 32 * sa.diff);
+}
+
+// Global top of a multi-task tree: monopoles and softening flags of the nodes of one top level from the all-reduced cell sums
+// (force_treeupdate_pseudos, forcetree.c:851-947, adds the remote top-leaf moments up the ancestor chain; here every top node
+// takes the sum over ALL tasks directly).  Level `top_level` itself: only the pseudo nodes (the cells present here keep the
+// bottom-up moments of their own subtree).
+template <int NG>
+__global__ void k_top_moments(const int *__restrict__ n_prefix, const double *__restrict__ gsum_level, const double4 *__restrict__ n_geo,
+                              double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level, int pseudo_only,
+                              WalkParams wp)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  const int node = node0 + t, fl = n_flags[node];
+  if(pseudo_only && !(fl & FLAG_PSEUDO))
+    return;
+  const double *s = gsum_level + (size_t)n_prefix[node] * TOP_CW(NG);
+  const double4 geo = n_geo[node];
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    {
+      double4 o;
+      const double m = s[7 + 4 * g];
+      if(m > 0)
+        {
+          o.x = s[7 + 4 * g + 1] / m;
+          o.y = s[7 + 4 * g + 2] / m;
+          o.z = s[7 + 4 * g + 3] / m;
+        }
+      else
+        {
+          o.x = geo.x;
+          o.y = geo.y;
+          o.z = geo.z;
+        }
+      o.w = m;
+      n_mom[(long long)node * NG + g] = o;
+    }
+  SoftAcc sa;
+  sa.maxsofttype = 7;
+  sa.diff = 0;
+  for(int ty = 0; ty < NGRAVS_NTYPES; ty++)
+    if(s[1 + ty] > 0)
+      soft_merge(sa, ty, 0, wp.fsoft);
+  n_flags[node] = (fl & (FLAG_BUCKET | FLAG_PSEUDO | FLAG_PARTIAL)) | (4 * sa.maxsofttype + 32 * sa.diff);
+}
+
+static int tree_top_moments(ngravs_ctx *c)
+{
+  const TopTree &t = c->top;
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  const int cw = TOP_CW(c->cfg.n_gravs);
+  for(int l = (t.level < c->nlevels - 1 ? t.level : c->nlevels - 1); l >= 0; l--)
+    {
+      const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
+      if(lc <= 0)
+        continue;
+      const unsigned nb = (unsigned)((lc + 127) / 128);
+      const double *gs = t.gsum.p + (size_t)t.off[l] * cw;
+      const int pseudo_only = l == t.level ? 1 : 0;
+      switch(c->cfg.n_gravs)
+        {
+        case 1:
+          hipLaunchKernelGGL(k_top_moments<1>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
+                             (int)lc, pseudo_only, wp);
+          break;
+        case 2:
+          hipLaunchKernelGGL(k_top_moments<2>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
+                             (int)lc, pseudo_only, wp);
+          break;
+        default:
+          hipLaunchKernelGGL(k_top_moments<3>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
+                             (int)lc, pseudo_only, wp);
+          break;
+        }
+    }
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
 }
 
 // multipole moments, softening flags (and, for a refit, grown cell sides) of all nodes, bottom-up, one launch per level
@@ -295,6 +408,8 @@ int tree_moments(ngravs_ctx *c, bool refit)
         }
     }
   HIP_TRY(c, hipGetLastError());
+  if(c->top.level > 0)
+    return tree_top_moments(c);
   return NGRAVS_OK;
 }
 
@@ -303,11 +418,14 @@ int tree_build(ngravs_ctx *c)
   const long long n = c->n;
   double taf = c->cfg.tree_alloc_factor > 0 ? c->cfg.tree_alloc_factor : 0.8;
   long long maxn = (long long)(taf * (double)n) + 1024;
+  const TopTree &top = c->top;
+  if(top.level > 0)
+    maxn += top.off[top.level + 1];   // the global top: every cell of its levels may be a node
   c->max_nodes = maxn;
   const int ng = c->cfg.n_gravs;
   if(c->n_first.ensure(maxn) || c->n_count.ensure(maxn) || c->n_child.ensure(8 * maxn) || c->n_flags.ensure(maxn) ||
      c->n_geo.ensure(maxn) || c->n_mom.ensure(maxn * ng) || c->n_nchild.ensure(maxn) || c->scan_out.ensure(maxn) ||
-     c->d_counters.ensure(16))
+     c->d_counters.ensure(16) || (c->top.level > 0 && c->n_prefix.ensure(maxn)))
     return NGRAVS_ERR_NOMEM;
   // root = the domain cube (forcetree.c:103-110)
   int h_first = 0, h_count = (int)n, h_flags = 0;
@@ -320,6 +438,15 @@ int tree_build(ngravs_ctx *c)
   HIP_TRY(c, hipMemcpyAsync(c->n_count.p, &h_count, sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->n_geo.p, &h_geo, sizeof(double4), hipMemcpyHostToDevice, c->stream));
+  if(top.level > 0)
+    {
+      unsigned char part0 = 0;
+      HIP_TRY(c, hipMemsetAsync(c->n_prefix.p, 0, sizeof(int), c->stream));
+      HIP_TRY(c, hipMemcpyAsync(&part0, top.partial.p, 1, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      h_flags = part0 ? FLAG_PARTIAL : 0;
+      HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    }
   double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
   size_t scan_bytes = 0;
   (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c->n_nchild.p, c->scan_out.p, (int)maxn, c->stream);
@@ -332,8 +459,10 @@ int tree_build(ngravs_ctx *c)
   while(cnt > 0 && level < TREE_BITS)
     {
       unsigned nb = (unsigned)((cnt + bs - 1) / bs);
+      const bool in_top = top.level > 0 && level < top.level;   // children of this level are cells of the global top
       hipLaunchKernelGGL(k_split, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->n_first.p, c->n_count.p, (int)node0,
-                         (int)cnt, level, c->n_child.p, c->n_nchild.p);
+                         (int)cnt, level, c->n_child.p, c->n_nchild.p, in_top ? top.gcnt.p + top.off[level + 1] : (const int *)nullptr,
+                         in_top ? c->n_prefix.p : (const int *)nullptr);
       size_t sb = scan_bytes;
       HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, sb, c->n_nchild.p, c->scan_out.p, (int)cnt, c->stream));
       int last_scan = 0, last_n = 0;
@@ -349,7 +478,9 @@ int tree_build(ngravs_ctx *c)
         }
       hipLaunchKernelGGL(k_link, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->n_first.p, c->n_count.p, c->n_child.p,
                          c->n_geo.p, c->n_flags.p, c->scan_out.p, (int)node0, (int)cnt, (int)next0, level, c->dom[0],
-                         c->dom[1], c->dom[2], fac21);
+                         c->dom[1], c->dom[2], fac21, in_top ? c->n_prefix.p : (int *)nullptr,
+                         in_top ? top.cellxyz.p + top.off[level + 1] : (const int *)nullptr,
+                         in_top ? top.partial.p + top.off[level + 1] : (const unsigned char *)nullptr, top.level);
       level++;
       c->level_start[level] = next0;
       node0 = next0;

@@ -32,7 +32,6 @@
 #include <hipcub/hipcub.hpp>
 #include <type_traits>
 
-#define FLAG_BUCKET 64
 #define WAVE 64
 
 __device__ __forceinline__ double nearest(double x, double box, double boxhalf)
@@ -1490,7 +1489,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
                         open = true;
                       if(open)
-                        dec = ((fl & FLAG_BUCKET) || count <= wp.nleaf) ? 3 : 2;
+                        dec = ((fl & FLAG_BUCKET) || (count <= wp.nleaf && !(fl & FLAG_PARTIAL))) ? 3 : 2;
                       else
                         dec = 1;
                     }

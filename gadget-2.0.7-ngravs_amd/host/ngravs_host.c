@@ -232,8 +232,6 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
   memset(info, 0, sizeof(*info));
   memset(plan, 0, sizeof(*plan));
   CHECK(ngravs_get_config(ctx, &cfg));
-  if(W > 1 && !cfg.pmgrid)
-    return NGRAVS_ERR_ARG;   /* tree-only runs have no finite cut: they need the node import, not a halo */
   CHECK(ngravs_dd_local_extent(ctx, lo, hi));
   CHECK(cm->allreduce(cm->user, lo, 3, NGRAVS_T_F64, NGRAVS_OP_MIN));
   CHECK(cm->allreduce(cm->user, hi, 3, NGRAVS_T_F64, NGRAVS_OP_MAX));
@@ -340,19 +338,322 @@ static int record_exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_
   return rc;
 }
 
+/* ---- which foreign top cells may this task's targets have to open? ----------------------------------------------------------
+ * The walk's own tests (group traversal of kernels_walk.hip = the conservative form of forcetree.c:1364-1518, 1828-1862) against
+ * boxes that enclose the task's domain, applied from the root of the global top tree downwards.  A node no target can open is
+ * used as a monopole at most: nothing below it is needed.  A node that may be opened: its single-particle children, and -- if it
+ * holds <= 8 particles, which the group walk hands over as a leaf -- everything below it, must be on this task. */
+typedef struct
+{
+  int L, ng, periodic, pm, use_theta;
+  double box, theta2, aold_min, h_min, rcut, reach6, fsoft[6], corner[3], len;
+  const double *sums;    /* all levels, TOP_CW doubles per cell */
+  const int64_t *off;    /* first cell of every level */
+  const int32_t *xyz;    /* ix | iy << 10 | iz << 20 per cell */
+  int nbox;
+  double (*bc)[3], (*bh)[3];
+  uint8_t *need;         /* per level-L cell */
+} need_t;
+
+static double near_abs(double x, double box) { return x - box * rint(x / box); }
+
+static int may_open(const need_t *T, int d, int64_t prefix)
+{
+  const int cw = NGRAVS_TOP_CW(T->ng);
+  const double *s = T->sums + (size_t)(T->off[d] + prefix) * cw;
+  const int32_t xyz = T->xyz[T->off[d] + prefix];
+  const double len = T->len / (double)(1 << d), half = 0.5 * len;
+  double c[3], com[NGRAVS_MAX_GRAVS][3], summass = 0, hs_node = 0;
+  int g, j, b, ty, mixed = 0, first = 1;
+  c[0] = T->corner[0] + ((xyz & 1023) + 0.5) * len;
+  c[1] = T->corner[1] + (((xyz >> 10) & 1023) + 0.5) * len;
+  c[2] = T->corner[2] + (((xyz >> 20) & 1023) + 0.5) * len;
+  for(g = 0; g < T->ng; g++)
+    {
+      const double m = s[7 + 4 * g];
+      summass += m;
+      for(j = 0; j < 3; j++)
+        com[g][j] = m > 0 ? s[7 + 4 * g + 1 + j] / m : c[j];
+    }
+  for(ty = 0; ty < 6; ty++)
+    if(s[1 + ty] > 0)
+      {
+        if(!first && T->fsoft[ty] != hs_node)
+          mixed = 1;
+        if(first || T->fsoft[ty] > hs_node)
+          hs_node = T->fsoft[ty];
+        first = 0;
+      }
+  for(b = 0; b < T->nbox; b++)
+    {
+      double w[3], pl[3], r2min = 1e300, q2 = 0;
+      int drop = 0, open, inside = 1;
+      for(j = 0; j < 3; j++)
+        {
+          pl[j] = c[j] - T->bc[b][j];
+          w[j] = T->periodic ? near_abs(pl[j], T->box) : pl[j];
+          {
+            const double q = fmax(0.0, fabs(w[j]) - T->bh[b][j] - half);
+            q2 += q * q;
+          }
+        }
+      if(T->pm && q2 >= T->reach6 * T->reach6)
+        continue;      /* nothing inside the cell is within the short-range table of any target of this box */
+      for(g = 0; g < T->ng; g++)
+        {
+          double r2 = 0;
+          for(j = 0; j < 3; j++)
+            {
+              double dd = com[g][j] - T->bc[b][j];
+              if(T->periodic)
+                dd = near_abs(dd, T->box);
+              dd = fmax(0.0, fabs(dd) - T->bh[b][j]);
+              r2 += dd * dd;
+            }
+          if(r2 < r2min)
+            r2min = r2;
+        }
+      if(T->pm && r2min > T->rcut * T->rcut)
+        for(j = 0; j < 3; j++)
+          if(fabs(w[j]) - T->bh[b][j] > T->rcut + half)
+            drop = 1;
+      if(drop)
+        continue;
+      if(T->use_theta)
+        open = len * len > r2min * T->theta2;
+      else
+        {
+          open = summass * len * len > r2min * r2min * T->aold_min;
+          for(j = 0; j < 3; j++)
+            if(!(fabs(pl[j]) - T->bh[b][j] < 0.60 * len))
+              inside = 0;
+          open = open || inside;
+        }
+      if(!open && T->h_min < hs_node && r2min < hs_node * hs_node && mixed)
+        open = 1;
+      if(open)
+        return 1;
+    }
+  return 0;
+}
+
+static void need_all_below(const need_t *T, int d, int64_t prefix)
+{
+  const int sh = 3 * (T->L - d);
+  int64_t i;
+  for(i = prefix << sh; i < ((prefix + 1) << sh); i++)
+    if(T->sums[(size_t)(T->off[T->L] + i) * NGRAVS_TOP_CW(T->ng)] > 0.5)
+      T->need[i] = 1;
+}
+
+/* called for the children of a node that may be opened */
+static void need_visit(const need_t *T, int d, int64_t prefix)
+{
+  const double cnt = T->sums[(size_t)(T->off[d] + prefix) * NGRAVS_TOP_CW(T->ng)];
+  int k;
+  if(cnt < 0.5)
+    return;
+  if(cnt < 1.5)   /* a single particle: it hangs directly below the opened parent */
+    {
+      need_all_below(T, d, prefix);
+      return;
+    }
+  if(!may_open(T, d, prefix))
+    return;
+  if(d == T->L || cnt < 8.5)   /* a top leaf, or a node the group walk hands over particle by particle (GW_NLEAF) */
+    {
+      need_all_below(T, d, prefix);
+      return;
+    }
+  for(k = 0; k < 8; k++)
+    need_visit(T, d + 1, prefix * 8 + k);
+}
+
+/* Top-leaf moments + tree-node import + local Peano order: the second half of domain_Decomposition() for a task whose own
+ * particles are in place (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996, and what replaces the
+ * export / import loop of gravtree.c:112-285) */
 int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, ngravs_dd_info *info)
 {
   ngravs_dd_info local;
+  ngravs_config_t cfg;
+  need_t T;
+  double *sums = NULL, dom[8], bounds[2], (*bc)[3] = NULL, (*bh)[3] = NULL, blo[64][3], bhi[64][3];
+  int64_t *off = NULL, ncell, tot, i, *counts = NULL, *mat, *sb, *rb, nrec = 0, nrecv = 0;
+  int32_t *xyz = NULL;
+  uint8_t *need = NULL, *allneed = NULL, *present = NULL;
+  uint64_t *reqmask = NULL;
+  void *rec = NULL, *recvbuf = NULL;
+  int L, nc, d, x, y, z, r, j, k, cw, used[64], rc = 0, W, me;
   if(!ctx || !cm || !plan || !plan->owner_ph)
     return NGRAVS_ERR_ARG;
+  W = cm->size;
+  me = cm->rank;
   if(!info)
     {
       memset(&local, 0, sizeof(local));
       info = &local;
     }
-  CHECK(record_exchange(ctx, cm, plan, 1, info));
-  info->n_local = ngravs_dd_num_local(ctx);
-  return ngravs_domain_decomposition(ctx);
+  CHECK(ngravs_get_config(ctx, &cfg));
+  CHECK(ngravs_get_domain_extent(ctx, dom));
+  L = plan->level;
+  ncell = plan->ncell;
+  nc = 1 << L;
+  cw = NGRAVS_TOP_CW(cfg.n_gravs);
+  off = malloc(sizeof(int64_t) * (size_t)(L + 2));
+  off[0] = 0;
+  for(d = 0; d <= L; d++)
+    off[d + 1] = off[d] + (1ll << (3 * d));
+  tot = off[L + 1];
+  sums = calloc((size_t)tot * cw, sizeof(double));
+  xyz = malloc(sizeof(int32_t) * (size_t)tot);
+  need = calloc((size_t)ncell, 1);
+  allneed = malloc((size_t)ncell * (size_t)W);
+  present = malloc((size_t)ncell);
+  reqmask = calloc((size_t)ncell, sizeof(uint64_t));
+  counts = malloc(sizeof(int64_t) * (size_t)(3 * 65 + W * W));
+  if(!sums || !xyz || !need || !allneed || !present || !reqmask || !counts)
+    rc = NGRAVS_ERR_NOMEM;
+  /* top-leaf sums of all tasks (DomainMoment[], forcetree.c:766-850), then every coarser level */
+  if(!rc)
+    rc = ngravs_dd_cell_sums(ctx, L, sums + (size_t)off[L] * cw);
+  if(!rc)
+    rc = cm->allreduce(cm->user, sums + (size_t)off[L] * cw, ncell * cw, NGRAVS_T_F64, NGRAVS_OP_SUM);
+  if(!rc)
+    rc = ngravs_dd_target_bounds(ctx, bounds);
+  if(!rc)
+    {
+      for(d = L - 1; d >= 0; d--)
+        for(i = 0; i < (1ll << (3 * d)); i++)
+          for(k = 0; k < 8; k++)
+            for(j = 0; j < cw; j++)
+              sums[(size_t)(off[d] + i) * cw + j] += sums[(size_t)(off[d + 1] + i * 8 + k) * cw + j];
+      for(d = 0; d <= L; d++)
+        for(x = 0; x < (1 << d); x++)
+          for(y = 0; y < (1 << d); y++)
+            for(z = 0; z < (1 << d); z++)
+              xyz[off[d] + ngravs_peano_hilbert_key(x, y, z, d)] = x | (y << 10) | (z << 20);
+      /* boxes around the own cells that hold particles, one per coarse (<= 4^3) block of the domain grid */
+      {
+        const int csh = L > 2 ? L - 2 : 0;
+        const double cl = dom[6] / nc;
+        for(k = 0; k < 64; k++)
+          used[k] = 0;
+        for(x = 0; x < nc; x++)
+          for(y = 0; y < nc; y++)
+            for(z = 0; z < nc; z++)
+              {
+                const int64_t cell = ngravs_peano_hilbert_key(x, y, z, L);
+                const int cxyz[3] = {x, y, z};
+                if(plan->owner_ph[cell] != me || sums[(size_t)(off[L] + cell) * cw] < 0.5)
+                  continue;
+                k = (((x >> csh) & 3) * 4 + ((y >> csh) & 3)) * 4 + ((z >> csh) & 3);
+                for(j = 0; j < 3; j++)
+                  {
+                    const double lo = dom[j] + cxyz[j] * cl, hi = lo + cl;
+                    if(!used[k] || lo < blo[k][j])
+                      blo[k][j] = lo;
+                    if(!used[k] || hi > bhi[k][j])
+                      bhi[k][j] = hi;
+                  }
+                used[k] = 1;
+              }
+        bc = malloc(sizeof(*bc) * 64);
+        bh = malloc(sizeof(*bh) * 64);
+        T.nbox = 0;
+        for(k = 0; k < 64; k++)
+          if(used[k])
+            {
+              for(j = 0; j < 3; j++)
+                {
+                  bc[T.nbox][j] = 0.5 * (blo[k][j] + bhi[k][j]);
+                  bh[T.nbox][j] = 0.5 * (bhi[k][j] - blo[k][j]) + 1e-9 * dom[6];   /* rounding slack */
+                }
+              T.nbox++;
+            }
+      }
+      T.L = L;
+      T.ng = cfg.n_gravs;
+      T.periodic = cfg.periodic;
+      T.pm = cfg.pmgrid != 0;
+      T.use_theta = cfg.err_tol_theta != 0;
+      T.box = cfg.box_size;
+      T.theta2 = cfg.err_tol_theta * cfg.err_tol_theta;
+      T.aold_min = bounds[0];
+      T.h_min = bounds[1];
+      T.rcut = cfg.rcut;
+      T.reach6 = 6.0 * cfg.asmth;
+      for(j = 0; j < 6; j++)
+        T.fsoft[j] = cfg.force_softening[j];
+      for(j = 0; j < 3; j++)
+        T.corner[j] = dom[j];
+      T.len = dom[6];
+      T.sums = sums;
+      T.off = off;
+      T.xyz = xyz;
+      T.bc = bc;
+      T.bh = bh;
+      T.need = need;
+      if(T.nbox > 0)   /* the root is opened by every target inside it */
+        for(k = 0; k < 8; k++)
+          need_visit(&T, 1, k);
+      for(i = 0; i < ncell; i++)
+        if(plan->owner_ph[i] == me)
+          need[i] = 0;   /* own cells are here already */
+      rc = cm->allgather(cm->user, need, allneed, ncell);
+    }
+  if(!rc)
+    {
+      /* the owners ship every particle of the requested cells (replaces the export of targets, gravtree.c:195-257) */
+      for(r = 0; r < W; r++)
+        for(i = 0; i < ncell; i++)
+          if(allneed[(size_t)r * ncell + i] && plan->owner_ph[i] == me)
+            reqmask[i] |= 1ull << r;
+      mat = counts + 65;
+      sb = mat + W * W;
+      rb = sb + 65;
+      rc = ngravs_dd_pack_cells(ctx, L, reqmask, W, me, counts, &rec, &nrec);
+      if(!rc)
+        rc = cm->allgather(cm->user, counts, mat, (int64_t)sizeof(int64_t) * W);
+      if(!rc)
+        {
+          for(r = 0; r < W; r++)
+            {
+              sb[r] = counts[r] * NGRAVS_DD_RECORD_BYTES;
+              rb[r] = mat[(size_t)r * W + me] * NGRAVS_DD_RECORD_BYTES;
+              nrecv += mat[(size_t)r * W + me];
+              if(r != me)
+                info->bytes_halo += (double)sb[r];
+            }
+          rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
+        }
+      if(!rc)
+        rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
+      if(!rc)
+        rc = ngravs_dd_set_halo(ctx, recvbuf, nrecv);
+      info->n_halo = nrecv;
+    }
+  if(!rc)
+    {
+      for(i = 0; i < ncell; i++)
+        present[i] = (plan->owner_ph[i] == me || need[i]) ? 1 : 0;
+      rc = ngravs_dd_set_top(ctx, L, sums + (size_t)off[L] * cw, present);
+    }
+  if(!rc)
+    {
+      info->n_local = ngravs_dd_num_local(ctx);
+      rc = ngravs_domain_decomposition(ctx);
+    }
+  free(off);
+  free(sums);
+  free(xyz);
+  free(need);
+  free(allneed);
+  free(present);
+  free(reqmask);
+  free(counts);
+  free(bc);
+  free(bh);
+  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
 }
 
 int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int level, double paf, ngravs_dd_info *info)

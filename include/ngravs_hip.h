@@ -269,8 +269,28 @@ int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);        
 int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */
 /* 8^level particle counts and work sums sum(1 + GravCost) (domain_sumCost, domain.c:823-877; work may be NULL), Peano-cell order, host arrays */
 int ngravs_dd_histogram(ngravs_ctx *ctx, int level, int64_t *hist, double *work);
+/* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac as set by ngravs_dd_set_extent (before the local Peano order exists) */
+int ngravs_get_domain_extent(ngravs_ctx *ctx, double out[8]);
 int ngravs_dd_pack(ngravs_ctx *ctx, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
                    int my_rank, int64_t *counts, void **dev_records, int64_t *nrec);
+/* ---- the global top of the tree: top-leaf moments and tree-node import (force_exchange_pseudodata / force_treeupdate_pseudos,
+ * forcetree.c:766-996; replaces the target export / partial-force import of gravtree.c:112-285) ---------------------------------
+ * The Peano cells of one level play the role of the reference's top leaves.  Every task contributes the sums of its own
+ * particles per cell (ngravs_dd_cell_sums: count, particles per type [6], per species mass and mass-weighted position:
+ * NGRAVS_TOP_CW(n_gravs) doubles per cell, Peano-cell order); the host all-reduces the table, decides which foreign cells the
+ * task's targets may have to open (ngravs_host.c: the walk's own opening tests against the task's domain), the owners ship ALL
+ * particles of the requested cells (ngravs_dd_pack_cells: reqmask[cell] bit r = task r asked for it), and
+ * ngravs_dd_set_top() hands the global table over: the next tree build forces the topology of the levels above from the
+ * global counts -- it is the single-task tree's -- gives the top nodes global monopoles, and turns every cell of that level
+ * whose particles are elsewhere into a pseudo node.  Forces are then independent of the number of tasks (domain.c:18-21). */
+#define NGRAVS_TOP_CW(ng) (7 + 4 * (ng))
+int ngravs_dd_cell_sums(ngravs_ctx *ctx, int level, double *cells);
+/* min over the own active particles of ErrTolForceAcc * OldAcc and of the softening length: out[2] */
+int ngravs_dd_target_bounds(ngravs_ctx *ctx, double out[2]);
+int ngravs_dd_pack_cells(ngravs_ctx *ctx, int level, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts,
+                         void **dev_records, int64_t *nrec);
+/* gcells: the all-reduced table; present[cell] != 0: the cell's particles are on this task (own or imported).  level 0: off. */
+int ngravs_dd_set_top(ngravs_ctx *ctx, int level, const double *gcells, const uint8_t *present);
 /* destination task of every local particle under the owner map (its own rank if it stays), host array of ngravs_dd_num_local() ints */
 int ngravs_dd_get_dest(ngravs_ctx *ctx, int level, const int32_t *owner_ph, int32_t *dest);
 /* a library-owned device buffer for nrec incoming records (valid until the next ngravs_dd_recv_buffer call) */

@@ -49,6 +49,81 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _strict_worker(rank, world, port, out_dir, case):
+    """the reference's walk (per-target decisions) on `world` tasks: top-leaf moments + imported top cells"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos, mass, typ, old, cfg = _strict_case(pkg, case)
+    n = len(pos)
+    mine = np.arange(rank, n, world)
+    eng = dd.DistributedEngine(cfg)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], old_acc=old[mine], ids=mine)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    acc, oa, cost = eng.get_accel()[:3]
+    np.savez(os.path.join(out_dir, "s%d.npz" % rank), ids=eng.local_ids(), acc=acc, cost=cost, old=oa,
+             halo=np.array([eng.timings["halo"], eng.num_local()]))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def _strict_case(pkg, case):
+    if case == "plummer":          # tree-only, non-periodic, Barnes-Hut criterion, two species with different softening
+        n = 24000
+        pos, mass, typ = pkg.ic.plummer_sphere(n, seed=31)
+        typ = (1 + (np.arange(n) % 2)).astype(np.int32)
+        cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.02, 0.01, 0.01, 0.01],
+                              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton", walk_mode=pkg.WALK_STRICT)
+        return pos, mass, typ, np.zeros(n), cfg
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_ewald_golden import N, L, SEED, case_config
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ewald_truth_c4.npz"))
+    pos, mass, typ = pkg.ic.uniform_box(N, box=L, n_gravs=2, seed=SEED)
+    cfg, eps = case_config(pkg, "c4", 2, walk_mode=pkg.WALK_STRICT)
+    cfg.err_tol_theta = 0.0        # relative criterion with the golden OldAcc
+    return pos, mass, typ, gold["old_acc"], cfg
+
+
+@pytest.mark.parametrize("case", ["plummer", "c4"])
+def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
+    """The reference's invariant (domain.c:18-21): the tree force does not depend on the number of tasks.  With the global top
+    of the tree (top-leaf moments of all tasks) and the imported top cells every task's tree IS the single-task tree wherever
+    its targets look, so the reference walk (WALK_STRICT) on 3 tasks must give the single-task forces to summation-order
+    noise -- identical interaction counts, max |da|/|a| < 1e-10 -- for a tree-only run (no finite cut: no halo could do it)
+    and for TreePM."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 29700 + (os.getpid() % 2000)
+    mp.spawn(_strict_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    pos, mass, typ, old, cfg = _strict_case(pkg, case)
+    n = len(pos)
+    acc, cost, seen = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.int64)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "s%d.npz" % r))
+        acc[d["ids"]] = d["acc"]
+        cost[d["ids"]] = d["cost"]
+        seen[d["ids"]] += 1
+        print("task %d: %d own + %d imported particles" % (r, d["halo"][1], d["halo"][0]))
+        assert d["halo"][0] < n - d["halo"][1]          # a locally essential set, not everything
+    assert np.all(seen == 1)
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=old)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    a1, _, c1 = eng.get_accel()
+    eng.close()
+    err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1, axis=1)
+    print("%s: 3 tasks vs 1, reference walk: max |da|/|a| = %.2e, interaction counts equal: %s (%.1f per particle)" %
+          (case, err.max(), np.array_equal(cost, c1), c1.mean()))
+    assert np.array_equal(cost, c1)
+    assert err.max() < 1e-10
+
+
 def test_three_rank_domain_decomposition(pkg, tmp_path):
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
