@@ -317,6 +317,9 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->dd_owner_xyz.release();
   c->dd_send.release();
   c->dd_recv.release();
+  c->dd_hist.release();
+  c->dd_work.release();
+  c->dd_cells.release();
   c->top.gcnt.release();
   c->top.cellxyz.release();
   c->top.gsum.release();
@@ -342,6 +345,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->scan_out.release();
   c->scan_tmp.release();
   c->d_counters.release();
+  c->d_levels.release();
   c->table.release();
   c->lat.release();
   c->walk_stack.release();

@@ -167,6 +167,7 @@ struct ngravs_ctx
   bool extent_override = false;
   double ext_lo[3], ext_hi[3];
   int dd_last_what = -1;
+  long long dd_last_sent = 0;
   bool have_particles = false, have_order = false, have_tree = false, have_pm = false, have_acc = false;
   bool pm_parked = false;     // pm_orig holds the caller's GravPM (handed over with ngravs_set_particles)
   double dom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -181,7 +182,8 @@ struct ngravs_ctx
   DevBuf<unsigned long long> in_key;
   DevBuf<long long> in_id;
   // multi-task decomposition scratch
-  DevBuf<unsigned long long> dd_mask, dd_counts;
+  DevBuf<unsigned long long> dd_mask, dd_counts, dd_hist;
+  DevBuf<double> dd_work, dd_cells;
   DevBuf<int> dd_owner_ph, dd_owner_xyz;
   DevBuf<unsigned char> dd_send, dd_recv;
   // sorted
@@ -205,6 +207,8 @@ struct ngravs_ctx
   DevBuf<int> scan_out;
   DevBuf<unsigned char> scan_tmp;
   DevBuf<int> d_counters;
+  DevBuf<int> d_levels;        // tree build: first node / node count of every level (device-resident level table)
+  long long level_hint[MAX_LEVELS + 2] = {0};   // level populations of the previous build (launch sizing only)
   // walk
   DevBuf<double> table;       // [ng][ng][NTAB] shortrange_fourier_force
   bool table_ready = false;

@@ -499,8 +499,8 @@ void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
 int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
 {
   const long long ncell = 1ll << (3 * level);
-  DevBuf<unsigned long long> d;
-  DevBuf<double> w;
+  DevBuf<unsigned long long> &d = c->dd_hist;   // persistent scratch: no hipMalloc / hipFree per step
+  DevBuf<double> &w = c->dd_work;
   if(d.ensure(ncell) || w.ensure(ncell))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * ncell, c->stream));
@@ -515,8 +515,6 @@ int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
   if(work)
     HIP_TRY(c, hipMemcpyAsync(work, w.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  d.release();
-  w.release();
   return NGRAVS_OK;
 }
 
@@ -570,6 +568,7 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
   *dev_records = c->dd_send.p;
   *nrec = tot;
   c->dd_last_what = what;
+  c->dd_last_sent = tot;
   return NGRAVS_OK;
 }
 
@@ -605,7 +604,7 @@ int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
 {
   const long long ncell = 1ll << (3 * level), n = c->n_local;
   const int cw = TOP_CW(c->cfg.n_gravs);
-  DevBuf<double> d;
+  DevBuf<double> &d = c->dd_cells;
   if(d.ensure((size_t)ncell * cw))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(double) * ncell * cw, c->stream));
@@ -620,7 +619,6 @@ int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
   HIP_TRY(c, hipMemcpyAsync(cells, d.p, sizeof(double) * ncell * cw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
-  d.release();
   return NGRAVS_OK;
 }
 
@@ -828,6 +826,12 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
   if(c->dd_last_what != 0)
     return NGRAVS_ERR_STATE;
   const long long n = c->n_local;
+  if(nrec == 0 && c->dd_last_sent == 0)   // steady state: nothing left, nothing arrived -- the columns stay where they are
+    {
+      c->n = c->n_local;
+      c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
+      return NGRAVS_OK;
+    }
   DevBuf<double> pos2, mass2, old2, cost2;
   DevBuf<int> type2;
   DevBuf<unsigned char> act2;

@@ -30,144 +30,224 @@ __device__ __forceinline__ int key_digit(unsigned long long k, int level)   // d
 // count of the child cell (gcnt_next[prefix * 8 + k]) -- 0: empty, 1: particle leaf, >= 2: node -- whatever part of it is
 // present on this task; so the topology of the top levels is the single-task tree's (forcetree.c:292-431 builds the same
 // top-level nodes from the global TopNodes on every task).
-__global__ void k_split(const unsigned long long *__restrict__ key, const int *__restrict__ n_first,
-                        const int *__restrict__ n_count, int node0, int nnodes_level, int level,
-                        int *__restrict__ n_child, int *__restrict__ n_nchild, const int *__restrict__ gcnt_next = nullptr,
-                        const int *__restrict__ n_prefix = nullptr)
+#define TB 128   // nodes per (virtual) block of the build kernels
+
+// The build never returns to the host between levels: lv[2 l], lv[2 l + 1] = first node and node count of level l live on the
+// device (k_scan_blocks writes the next level's), the kernels loop over virtual blocks of TB consecutive nodes with whatever
+// grid they were launched with, and node indices of the next level come from a two-stage scan (per-block sums here, the scan
+// of the block sums in k_scan_blocks, the scan inside a block in k_link) -- deterministic, level-contiguous numbering.
+__global__ __launch_bounds__(TB) void k_split(const unsigned long long *__restrict__ key, const int *__restrict__ n_first,
+                                              const int *__restrict__ n_count, const int *__restrict__ lv, int level,
+                                              int *__restrict__ n_child, int *__restrict__ n_nchild, int *__restrict__ blocksum,
+                                              const int *__restrict__ gcnt_next = nullptr, const int *__restrict__ n_prefix = nullptr)
 {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if(t >= nnodes_level)
-    return;
-  int node = node0 + t;
-  int f = n_first[node], cnt = n_count[node];
-  int b[9];
-  b[0] = f;
-  b[8] = f + cnt;
-  if(cnt <= 24)
+  __shared__ int wsum[TB / 64];
+  const int node0 = lv[2 * level], nnodes_level = lv[2 * level + 1];
+  const int nvb = (nnodes_level + TB - 1) / TB;
+  for(int vb = blockIdx.x; vb < nvb; vb += gridDim.x)
     {
-      int k = 1;
-      for(int i = f; i < f + cnt; i++)
+      const int t = vb * TB + threadIdx.x;
+      int nn = 0;
+      if(t < nnodes_level)
         {
-          int d = key_digit(key[i], level);
-          while(k <= d)
-            b[k++] = i;
-        }
-      while(k < 8)
-        b[k++] = f + cnt;
-    }
-  else
-    {
-      for(int k = 1; k < 8; k++)
-        {
-          int lo = b[k - 1], hi = f + cnt;   // first index with digit >= k
-          while(lo < hi)
+          int node = node0 + t;
+          int f = n_first[node], cnt = n_count[node];
+          int b[9];
+          b[0] = f;
+          b[8] = f + cnt;
+          if(cnt <= 24)
             {
-              int mid = (lo + hi) >> 1;
-              if(key_digit(key[mid], level) < k)
-                lo = mid + 1;
-              else
-                hi = mid;
+              int k = 1;
+              for(int i = f; i < f + cnt; i++)
+                {
+                  int d = key_digit(key[i], level);
+                  while(k <= d)
+                    b[k++] = i;
+                }
+              while(k < 8)
+                b[k++] = f + cnt;
             }
-          b[k] = lo;
+          else
+            {
+              for(int k = 1; k < 8; k++)
+                {
+                  int lo = b[k - 1], hi = f + cnt;   // first index with digit >= k
+                  while(lo < hi)
+                    {
+                      int mid = (lo + hi) >> 1;
+                      if(key_digit(key[mid], level) < k)
+                        lo = mid + 1;
+                      else
+                        hi = mid;
+                    }
+                  b[k] = lo;
+                }
+            }
+          for(int k = 0; k < 8; k++)
+            {
+              int c = b[k + 1] - b[k], v;
+              int kind = c;                                          // 0 empty, 1 particle, >= 2 node
+              if(gcnt_next)
+                {
+                  kind = gcnt_next[(long long)n_prefix[node] * 8 + k];
+                  if(kind == 1 && c != 1)
+                    kind = 0;                                        // a single particle that lives elsewhere: its parent is never opened here
+                }
+              if(kind == 0)
+                v = -1;
+              else if(kind == 1)
+                v = -2 - b[k];
+              else
+                {
+                  v = b[k];
+                  nn++;
+                }
+              n_child[8 * (long long)node + k] = v;
+            }
+          n_nchild[t] = nn;
+        }
+      int s = nn;
+      for(int off = 32; off > 0; off >>= 1)
+        s += __shfl_down(s, off);
+      __syncthreads();
+      if((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = s;
+      __syncthreads();
+      if(threadIdx.x == 0)
+        {
+          int tot = 0;
+          for(int w = 0; w < TB / 64; w++)
+            tot += wsum[w];
+          blocksum[vb] = tot;
         }
     }
-  int nn = 0;
-  for(int k = 0; k < 8; k++)
+}
+
+// exclusive scan of the block sums of one level (one workgroup), and the next level's extent; out of nodes -> lv_err
+__global__ __launch_bounds__(1024) void k_scan_blocks(int *__restrict__ blocksum, int *__restrict__ lv, int level, int maxn)
+{
+  __shared__ int part[1024];
+  const int node0 = lv[2 * level], cnt = lv[2 * level + 1];
+  const int nvb = (cnt + TB - 1) / TB;
+  const int per = (nvb + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < nvb ? lo + per : nvb;
+  int s = 0;
+  for(int i = lo; i < hi; i++)
+    s += blocksum[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for(int off = 1; off < 1024; off <<= 1)   // Hillis-Steele inclusive scan of the 1024 partial sums
     {
-      int c = b[k + 1] - b[k], v;
-      int kind = c;                                          // 0 empty, 1 particle, >= 2 node
-      if(gcnt_next)
-        {
-          kind = gcnt_next[(long long)n_prefix[node] * 8 + k];
-          if(kind == 1 && c != 1)
-            kind = 0;                                        // a single particle that lives elsewhere: its parent is never opened here
-        }
-      if(kind == 0)
-        v = -1;
-      else if(kind == 1)
-        v = -2 - b[k];
-      else
-        {
-          v = b[k];
-          nn++;
-        }
-      n_child[8 * (long long)node + k] = v;
+      int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
     }
-  n_nchild[t] = nn;
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for(int i = lo; i < hi; i++)
+    {
+      const int v = blocksum[i];
+      blocksum[i] = run;
+      run += v;
+    }
+  if(threadIdx.x == 0)
+    {
+      int next_cnt = part[1023];
+      if((long long)node0 + cnt + next_cnt > (long long)maxn)
+        {
+          lv[2 * (MAX_LEVELS + 2)] = 1;   // maximum number of tree nodes reached (forcetree.c:247)
+          next_cnt = 0;
+        }
+      if(level + 1 > TREE_BITS)
+        next_cnt = 0;
+      lv[2 * (level + 1)] = node0 + cnt;
+      lv[2 * (level + 1) + 1] = next_cnt;
+    }
 }
 
 // give the sub-ranges their node indices and initialise the nodes of the next level
-__global__ void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_first, int *__restrict__ n_count,
-                       int *__restrict__ n_child, double4 *__restrict__ n_geo, int *__restrict__ n_flags,
-                       const int *__restrict__ scan, int node0, int nnodes_level, int next0, int level,
-                       double cx, double cy, double cz, double fac21, int *__restrict__ n_prefix = nullptr,
-                       const int *__restrict__ xyz_next = nullptr, const unsigned char *__restrict__ partial_next = nullptr,
-                       int top_level = 0)
+__global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_first, int *__restrict__ n_count,
+                                             int *__restrict__ n_child, double4 *__restrict__ n_geo, int *__restrict__ n_flags,
+                                             const int *__restrict__ n_nchild, const int *__restrict__ blocksum, const int *__restrict__ lv,
+                                             int level, double cx, double cy, double cz, double fac21, int *__restrict__ n_prefix = nullptr,
+                                             const int *__restrict__ xyz_next = nullptr,
+                                             const unsigned char *__restrict__ partial_next = nullptr, int top_level = 0)
 {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if(t >= nnodes_level)
-    return;
-  int node = node0 + t;
-  int end = n_first[node] + n_count[node];
-  double4 g = n_geo[node];
-  int nxt = next0 + scan[t];
-  int starts[8], vals[8];
-  for(int k = 0; k < 8; k++)
+  typedef hipcub::BlockScan<int, TB> BlockScan;
+  __shared__ typename BlockScan::TempStorage tmp;
+  const int node0 = lv[2 * level], nnodes_level = lv[2 * level + 1], next0 = lv[2 * (level + 1)];
+  const int nvb = (nnodes_level + TB - 1) / TB;
+  for(int vb = blockIdx.x; vb < nvb; vb += gridDim.x)
     {
-      int v = n_child[8 * (long long)node + k];
-      vals[k] = v;
-      starts[k] = v >= 0 ? v : (v <= -2 ? -2 - v : -1);
-    }
-  for(int k = 0; k < 8; k++)
-    {
-      if(vals[k] < 0)
+      const int t = vb * TB + threadIdx.x;
+      const int mine = t < nnodes_level ? n_nchild[t] : 0;
+      int excl;
+      BlockScan(tmp).ExclusiveSum(mine, excl);
+      __syncthreads();
+      if(t >= nnodes_level || mine == 0)
         continue;
-      int e = end;
-      for(int kk = k + 1; kk < 8; kk++)
-        if(starts[kk] >= 0)
-          {
-            e = starts[kk];
-            break;
-          }
-      int cn = nxt++;
-      n_child[8 * (long long)node + k] = cn;
-      n_first[cn] = starts[k];
-      n_count[cn] = e - starts[k];
-      // geometric octant of the child from its first particle's cell coordinates (or, in the global top of a multi-task
-      // tree, where a cell may hold no local particle, from the cell table); centre recurrence of forcetree.c:190-206
-      // (centre +- 0.25*len of the parent)
-      int ox, oy, oz, fl = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
-      if(xyz_next)
+      int node = node0 + t;
+      int end = n_first[node] + n_count[node];
+      double4 g = n_geo[node];
+      int nxt = next0 + blocksum[vb] + excl;
+      int starts[8], vals[8];
+      for(int k = 0; k < 8; k++)
         {
-          const int pc = n_prefix[node] * 8 + k, xyz = xyz_next[pc];
-          ox = xyz & 1;
-          oy = (xyz >> 10) & 1;
-          oz = (xyz >> 20) & 1;
-          n_prefix[cn] = pc;
-          if(partial_next[pc])
-            fl |= FLAG_PARTIAL;
-          if(level + 1 == top_level && e - starts[k] == 0)
-            fl |= FLAG_PSEUDO;          // all of its particles live on other tasks (forcetree.c:345-431 pseudo particle)
+          int v = n_child[8 * (long long)node + k];
+          vals[k] = v;
+          starts[k] = v >= 0 ? v : (v <= -2 ? -2 - v : -1);
         }
-      else
+      for(int k = 0; k < 8; k++)
         {
-          double4 p = s_pm[starts[k]];
-          int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
-          int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
-          int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
-          int sh = TREE_BITS - 1 - level;
-          ox = (ix >> sh) & 1;
-          oy = (iy >> sh) & 1;
-          oz = (iz >> sh) & 1;
+          if(vals[k] < 0)
+            continue;
+          int e = end;
+          for(int kk = k + 1; kk < 8; kk++)
+            if(starts[kk] >= 0)
+              {
+                e = starts[kk];
+                break;
+              }
+          int cn = nxt++;
+          n_child[8 * (long long)node + k] = cn;
+          n_first[cn] = starts[k];
+          n_count[cn] = e - starts[k];
+          // geometric octant of the child from its first particle's cell coordinates (or, in the global top of a multi-task
+          // tree, where a cell may hold no local particle, from the cell table); centre recurrence of forcetree.c:190-206
+          // (centre +- 0.25*len of the parent)
+          int ox, oy, oz, fl = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
+          if(xyz_next)
+            {
+              const int pc = n_prefix[node] * 8 + k, xyz = xyz_next[pc];
+              ox = xyz & 1;
+              oy = (xyz >> 10) & 1;
+              oz = (xyz >> 20) & 1;
+              n_prefix[cn] = pc;
+              if(partial_next[pc])
+                fl |= FLAG_PARTIAL;
+              if(level + 1 == top_level && e - starts[k] == 0)
+                fl |= FLAG_PSEUDO;          // all of its particles live on other tasks (forcetree.c:345-431 pseudo particle)
+            }
+          else
+            {
+              double4 p = s_pm[starts[k]];
+              int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
+              int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
+              int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
+              int sh = TREE_BITS - 1 - level;
+              ox = (ix >> sh) & 1;
+              oy = (iy >> sh) & 1;
+              oz = (iz >> sh) & 1;
+            }
+          double q = 0.25 * g.w;
+          double4 cg;
+          cg.x = ox ? g.x + q : g.x - q;
+          cg.y = oy ? g.y + q : g.y - q;
+          cg.z = oz ? g.z + q : g.z - q;
+          cg.w = 0.5 * g.w;
+          n_geo[cn] = cg;
+          n_flags[cn] = fl;
         }
-      double q = 0.25 * g.w;
-      double4 cg;
-      cg.x = ox ? g.x + q : g.x - q;
-      cg.y = oy ? g.y + q : g.y - q;
-      cg.z = oz ? g.z + q : g.z - q;
-      cg.w = 0.5 * g.w;
-      n_geo[cn] = cg;
-      n_flags[cn] = fl;
     }
 }
 
@@ -448,48 +528,53 @@ int tree_build(ngravs_ctx *c)
       HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
   double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
-  size_t scan_bytes = 0;
-  (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, c->n_nchild.p, c->scan_out.p, (int)maxn, c->stream);
-  if(c->scan_tmp.ensure(scan_bytes))
+  // level table on the device: lv[2 l], lv[2 l + 1] = first node, node count of level l; lv[2 (MAX_LEVELS + 2)] = out-of-nodes flag
+  const int LVN = 2 * (MAX_LEVELS + 2) + 2;
+  if(c->d_levels.ensure(LVN) || c->scan_out.ensure((size_t)(maxn / TB + 2)))
     return NGRAVS_ERR_NOMEM;
-  long long node0 = 0, cnt = 1;
-  int level = 0;
-  c->level_start[0] = 0;
-  const int bs = 128;
-  while(cnt > 0 && level < TREE_BITS)
+  int h_lv[2 * (MAX_LEVELS + 2) + 2];
+  memset(h_lv, 0, sizeof(h_lv));
+  h_lv[1] = 1;   // the root
+  HIP_TRY(c, hipMemcpyAsync(c->d_levels.p, h_lv, sizeof(int) * LVN, hipMemcpyHostToDevice, c->stream));
+  // No host round trip between levels: every level's launches are issued blindly, with grids sized from the level populations of
+  // the previous build (any grid is correct: the kernels loop over virtual blocks); levels beyond the deepest find count 0.
+  for(int level = 0; level < TREE_BITS; level++)
     {
-      unsigned nb = (unsigned)((cnt + bs - 1) / bs);
+      long long guess = c->level_hint[level] > 0 ? c->level_hint[level] + c->level_hint[level] / 8 : ((level < 8) ? (1ll << (3 * level)) : (n + 1) / 2);
+      if(guess > (n + 1) / 2 + 1 && level > 0 && top.level == 0)
+        guess = (n + 1) / 2 + 1;
+      unsigned nb = (unsigned)((guess + TB - 1) / TB);
+      nb = nb < 1 ? 1 : (nb > 262144u ? 262144u : nb);
       const bool in_top = top.level > 0 && level < top.level;   // children of this level are cells of the global top
-      hipLaunchKernelGGL(k_split, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->n_first.p, c->n_count.p, (int)node0,
-                         (int)cnt, level, c->n_child.p, c->n_nchild.p, in_top ? top.gcnt.p + top.off[level + 1] : (const int *)nullptr,
+      hipLaunchKernelGGL(k_split, dim3(nb), dim3(TB), 0, c->stream, c->s_key.p, c->n_first.p, c->n_count.p, c->d_levels.p, level, c->n_child.p,
+                         c->n_nchild.p, c->scan_out.p, in_top ? top.gcnt.p + top.off[level + 1] : (const int *)nullptr,
                          in_top ? c->n_prefix.p : (const int *)nullptr);
-      size_t sb = scan_bytes;
-      HIP_TRY(c, hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, sb, c->n_nchild.p, c->scan_out.p, (int)cnt, c->stream));
-      int last_scan = 0, last_n = 0;
-      HIP_TRY(c, hipMemcpyAsync(&last_scan, c->scan_out.p + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(&last_n, c->n_nchild.p + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      long long next_cnt = (long long)last_scan + last_n;
-      long long next0 = node0 + cnt;
-      if(next0 + next_cnt > maxn)
-        {
-          ngravs_report(c, 1, "maximum number of tree-nodes reached (increase tree_alloc_factor)");   // endrun(1), forcetree.c:247
-          return NGRAVS_ERR_TREE;
-        }
-      hipLaunchKernelGGL(k_link, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->n_first.p, c->n_count.p, c->n_child.p,
-                         c->n_geo.p, c->n_flags.p, c->scan_out.p, (int)node0, (int)cnt, (int)next0, level, c->dom[0],
-                         c->dom[1], c->dom[2], fac21, in_top ? c->n_prefix.p : (int *)nullptr,
-                         in_top ? top.cellxyz.p + top.off[level + 1] : (const int *)nullptr,
+      hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, c->scan_out.p, c->d_levels.p, level, (int)maxn);
+      hipLaunchKernelGGL(k_link, dim3(nb), dim3(TB), 0, c->stream, c->s_pm.p, c->n_first.p, c->n_count.p, c->n_child.p, c->n_geo.p,
+                         c->n_flags.p, c->n_nchild.p, c->scan_out.p, c->d_levels.p, level, c->dom[0], c->dom[1], c->dom[2], fac21,
+                         in_top ? c->n_prefix.p : (int *)nullptr, in_top ? top.cellxyz.p + top.off[level + 1] : (const int *)nullptr,
                          in_top ? top.partial.p + top.off[level + 1] : (const unsigned char *)nullptr, top.level);
-      level++;
-      c->level_start[level] = next0;
-      node0 = next0;
-      cnt = next_cnt;
     }
-  // cnt nodes of the last level (level == TREE_BITS, buckets) or 0
-  c->nlevels = level + (cnt > 0 ? 1 : 0);
-  c->nnodes = node0 + cnt;
-  c->level_start[c->nlevels] = c->nnodes;
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(h_lv, c->d_levels.p, sizeof(int) * LVN, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the only one of the build: the host needs the level extents from here on
+  if(h_lv[2 * (MAX_LEVELS + 2)])
+    {
+      ngravs_report(c, 1, "maximum number of tree-nodes reached (increase tree_alloc_factor)");   // endrun(1), forcetree.c:247
+      return NGRAVS_ERR_TREE;
+    }
+  int nl = 0;
+  for(int l = 0; l <= TREE_BITS; l++)
+    {
+      c->level_start[l] = h_lv[2 * l];
+      c->level_hint[l] = h_lv[2 * l + 1];
+      if(h_lv[2 * l + 1] > 0)
+        nl = l + 1;
+    }
+  c->nlevels = nl;
+  c->nnodes = (long long)h_lv[2 * (nl - 1)] + h_lv[2 * (nl - 1) + 1];
+  for(int l = nl; l <= MAX_LEVELS + 1; l++)
+    c->level_start[l] = c->nnodes;
   int rcm = tree_moments(c, false);
   if(rcm)
     return rcm;
