@@ -937,14 +937,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 double ex;
                 if(PM && wp.exp_tab)
                   {
-                    // exp(-ym r) = E[tab] exp(-u), u = ym (r - tab/asmthfac) in [0, ym/asmthfac): degree-5 Taylor (u^6/720 < 1e-17)
+                    // exp(-ym r) = E[tab] exp(-u), u = ym (r - tab/asmthfac) in [0, ym/asmthfac) < 1e-3: degree-4 Taylor
+                    // (u^5/120 < 1e-17), Estrin form: every step has at most one non-inline constant, so no register copies
                     const double u = wp.ym * __builtin_fma(-(double)tab, wp.inv_asmthfac, rr);
-                    double pz = -1.0 / 120.0;
-                    pz = __builtin_fma(pz, u, 1.0 / 24.0);
-                    pz = __builtin_fma(pz, u, -1.0 / 6.0);
-                    pz = __builtin_fma(pz, u, 0.5);
-                    pz = __builtin_fma(pz, u, -1.0);
-                    pz = __builtin_fma(pz, u, 1.0);
+                    const double u2 = u * u;
+                    const double lo = __builtin_fma(u, -1.0, 1.0);                    // 1 - u
+                    const double hi = __builtin_fma(u, -1.0 / 6.0, 0.5);              // 1/2 - u/6
+                    const double pz = __builtin_fma(u2, __builtin_fma(u2, 1.0 / 24.0, hi), lo);
                     ex = etab[tab] * pz;
                   }
                 else
@@ -1081,7 +1080,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         continue;
 
       // ---- phase 2: evaluate the recorded items ------------------------------------------------------------
-      auto phase2 = [&](const int g, const int *__restrict__ items, const int n) {
+      auto phase2 = [&](const int g, const int *__restrict__ items, const int n_) {
+        // the list length is the same in every lane: in an SGPR the stride search below (integer remainders) runs on the scalar unit
+        const int n = __builtin_amdgcn_readfirstlane(n_);
         wave_sync();
         st_entries += n;
         if(n == 0)
@@ -1093,13 +1094,17 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           trow = tabp + (size_t)wp.tab_slot[tg * NG + g] * NTAB;
         else
           trow = tabp + ((size_t)tg * NG + g) * NTAB;
-        // golden-ratio stride, coprime with n: item (i * s) mod n is visited i-th
-        int s_ = (int)(0.6180339887498949 * n) | 1;
-        if(s_ >= n)
+        // The list is visited in QUADS of four consecutive items (one 16-byte load per lane and four chunks: neighbouring
+        // items are neighbours in space, so element b of 64 quads spread over the list is still an even sample of the whole
+        // neighbourhood, and the list is read with a quarter of the cache lines a 4-byte gather per chunk touches), quads in a
+        // golden-ratio stride order: quad (i * s) mod nq is visited i-th, s coprime with nq.
+        const int nq = (n + 3) >> 2;
+        int s_ = (int)(0.6180339887498949 * nq) | 1;
+        if(s_ >= nq)
           s_ = 1;
         for(;;)
           {
-            int a = s_, b = n;
+            int a = s_, b = nq;
             while(b)
               {
                 int t = a % b;
@@ -1109,29 +1114,35 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             if(a == 1)
               break;
             s_ += 2;
-            if(s_ >= n)
+            if(s_ >= nq)
               {
                 s_ = 1;
                 break;
               }
           }
-        const int step64 = (int)((64ll * s_) % n);
-        int slot = (int)(((long long)lane * s_) % n);
+        const int step64 = (int)((64ll * s_) % nq);
+        int slot = (int)(((long long)lane * s_) % nq);
         int npool = 0;
-        // one extra pass (c0 >= n) only drains what is left in the pool, so that the force loop exists once.
-        // Two-deep software pipeline on the memory side: while chunk c is evaluated, the source records of chunk c+1 and
-        // the item indices of chunk c+2 are already in flight.
-        auto fetch_item = [&](int c0) -> int {
-          const bool hv = c0 + lane < n;
-          const int it = hv ? items[slot] : 0;
+        const int nsuper = (nq + WAVE - 1) / WAVE, nchunks = 4 * nsuper;
+        // one extra pass (cc == nchunks) only drains what is left in the pool, so that the force loop exists once.
+        // Software pipeline on the memory side: while chunk c is evaluated, the source records of chunk c+1 are in flight, and
+        // the quad of item indices of the NEXT four chunks was requested four chunks ago.
+        auto fetch_quad = [&](int sc, int4 &v, int &nvalid) {
+          v.x = v.y = v.z = v.w = 0;
+          nvalid = 0;
+          if(sc < nsuper && sc * WAVE + lane < nq)
+            {
+              v = reinterpret_cast<const int4 *>(items)[slot];
+              nvalid = n - 4 * slot;
+              nvalid = nvalid > 4 ? 4 : nvalid;
+            }
           slot += step64;
-          slot = slot >= n ? slot - n : slot;
-          return it;
+          slot = slot >= nq ? slot - nq : slot;
         };
-        auto fetch_rec = [&](int c0, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
+        auto fetch_rec = [&](bool hv, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
           q.x = q.y = q.z = q.w = 0;
           hs = 0;
-          if(c0 + lane < n)
+          if(hv)
             {
               const int k = -1 - item;   // monopole: node * NG + g
               if(usoft)
@@ -1158,21 +1169,35 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 }
             }
         };
-        int item1 = fetch_item(0);
+        int4 qd, qd_next;          // item quads of the current and the next four chunks
+        int nv, nv_next;
+        fetch_quad(0, qd, nv);
+        fetch_quad(1, qd_next, nv_next);
         double4 q1;
         int hs1;
-        fetch_rec(0, item1, q1, hs1);
-        int item2 = fetch_item(WAVE);
+        bool have1 = nv > 0;
+        fetch_rec(have1, qd.x, q1, hs1);
         double4 *pp = lpos;
         unsigned char *ph = lty;
-        for(int c0 = 0; c0 < n + WAVE; c0 += WAVE)
+        for(int cc = 0; cc <= nchunks; cc++)
           {
-            const bool last = c0 >= n;
-            const bool have = c0 + lane < n;
+            const bool last = cc == nchunks;
+            const bool have = have1;
             double4 q = q1;
             const int hs = hs1;
-            fetch_rec(c0 + WAVE, item2, q1, hs1);   // chunk c+1
-            item2 = fetch_item(c0 + 2 * WAVE);       // chunk c+2
+            {
+              // chunk cc+1: element (cc+1) & 3 of its quad
+              const int bn = (cc + 1) & 3;
+              if(bn == 0)
+                {
+                  qd = qd_next;
+                  nv = nv_next;
+                  fetch_quad((cc + 1) / 4 + 1, qd_next, nv_next);   // the quad after that one
+                }
+              const int itn = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
+              have1 = cc + 1 < nchunks && bn < nv;
+              fetch_rec(have1, itn, q1, hs1);
+            }
             bool live = have && q.w != 0.0;
             double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
             if(wp.periodic)
@@ -1881,7 +1906,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
     if(cfg.pmgrid && wp->asmthfac > 0)
       {
         wp->inv_asmthfac = 1.0 / wp->asmthfac;
-        wp->exp_tab = (wp->ym * wp->inv_asmthfac < 4.0e-3) ? 1 : 0;   // u^6/720 < 6e-18
+        wp->exp_tab = (wp->ym * wp->inv_asmthfac < 1.0e-3) ? 1 : 0;   // u^5/120 < 1e-17
       }
   }
   wp->fac_intp = cfg.box_size > 0 ? 2.0 * LAT_EN / cfg.box_size : 0.0;   // forcetree.c:3737
@@ -2149,6 +2174,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
     }
   if(c->walk_scap < GW3_STK_MIN)
     c->walk_scap = GW3_STK_MIN;
+  c->walk_lcap &= ~3;   // the evaluation kernel reads the lists in 16-byte quads
   const int lcap = c->walk_lcap, scap = c->walk_scap;
   const size_t region_ints = (size_t)NG * lcap + scap;
   // batches as large as memory comfortably allows (every traversal/evaluation launch pair costs ~0.4 ms of ramp and tail:

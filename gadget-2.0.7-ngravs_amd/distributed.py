@@ -15,6 +15,7 @@ Collectives per step (payload per task in DistributedEngine.info / .pm_bytes):
 import ctypes as C
 
 import numpy as np
+import torch  # noqa: F401  (before libngravs_hip.so is loaded whenever possible: one HIP runtime per process, torch's own)
 
 from . import Engine, NgravsError, lib
 

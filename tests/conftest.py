@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # torch bundles its own ROCm runtime; libngravs_hip.so links /opt/rocm's.  One process must end up with ONE HIP runtime:
+    # whichever library is loaded first decides which, and torch only initialises with its own -- so torch goes first
+    # (bench.py does the same; C hosts never load torch).
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as ge  # noqa: E402
