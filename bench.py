@@ -199,8 +199,9 @@ def main():
                     help="N>1: 'domain' (default) = work-weighted Peano-Hilbert domain decomposition: migration + short-range halo "
                          "all-to-all-v, x-slab decomposed PM with four plane exchanges (DESIGN.md Multi-GPU); 'replicated' = every "
                          "rank holds all particles and only the walk is sharded (no data-path collective; tree-only configs)")
-    ap.add_argument("--config", default="c4", choices=["c2", "c3", "c4", "c5"],
-                    help="BASELINE.json config: c4 (default, the metric's) | c3: 16M N_GRAVS=1 PMGRID=256 | c2: 4M Plummer tree-only")
+    ap.add_argument("--config", default="c4", choices=["c1", "c2", "c3", "c4", "c5"],
+                    help="BASELINE.json config: c4 (default, the metric's) | c5: 256M N_GRAVS=3 PMGRID=1024 | c3: 16M N_GRAVS=1 PMGRID=256 | "
+                         "c2: 4M Plummer tree-only | c1: the reference's own GalaxyCollision.IC (60k particles, N_GRAVS=2, tree-only)")
     args = ap.parse_args()
     if args.config == "c3":
         args.log2n, args.ngravs, args.wiring, args.pmgrid = (24 if args.log2n == 26 else args.log2n), 1, "newton", args.pmgrid or 256
@@ -247,18 +248,28 @@ def main():
             pmgrid *= 2
     cells_per_particle = pmgrid ** 3 / n
     eps = L / (40 * n ** (1 / 3))
-    treeonly = args.config == "c2"
+    treeonly = args.config in ("c1", "c2")
     if treeonly:
         pmgrid, cells_per_particle, eps = 0, 0.0, 0.01
-    cfg = pkg.make_config(n_gravs=args.ngravs, periodic=0 if treeonly else 1, pmgrid=pmgrid, box_size=0.0 if treeonly else L,
-                          G=1.0, theta=0.5, err_tol_force_acc=0.005, softening=[eps] * 6,
-                          type_to_grav=pkg.ic.default_type_to_grav(args.ngravs), wiring=args.wiring,
-                          walk_mode=pkg.WALK_GROUP if args.walk == "group" else pkg.WALK_STRICT,
-                          device=local_rank, rank=rank, world_size=world)
-    if treeonly:
-        pos, mass, ptype = pkg.ic.plummer_sphere(n, a=1.0, seed=12345)
+    if args.config == "c1":
+        # the reference's shipped IC with the parameters of its Configuration.reference
+        ic = pkg.ic.read_gadget_format1(os.path.join(ROOT, "tests", "golden", "GalaxyCollision.IC"))
+        pos, mass, ptype = ic["pos"], ic["mass"], ic["type"]
+        n, args.ngravs, args.wiring = len(pos), 2, "newton"
+        cfg = pkg.make_config(n_gravs=2, G=43007.1, theta=0.5, err_tol_force_acc=0.005, softening=[0, 1.0, 0.4, 1.0, 1.0, 1.0],
+                              type_to_grav=[0, 0, 1, 0, 0, 0], wiring="newton", tree_alloc_factor=0.8,
+                              walk_mode=pkg.WALK_GROUP if args.walk == "group" else pkg.WALK_STRICT,
+                              device=local_rank, rank=rank, world_size=world)
     else:
-        pos, mass, ptype = make_box(pkg, n, L, args.ngravs, 12345)
+        cfg = pkg.make_config(n_gravs=args.ngravs, periodic=0 if treeonly else 1, pmgrid=pmgrid, box_size=0.0 if treeonly else L,
+                              G=1.0, theta=0.5, err_tol_force_acc=0.005, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(args.ngravs), wiring=args.wiring,
+                              walk_mode=pkg.WALK_GROUP if args.walk == "group" else pkg.WALK_STRICT,
+                              device=local_rank, rank=rank, world_size=world)
+        if treeonly:
+            pos, mass, ptype = pkg.ic.plummer_sphere(n, a=1.0, seed=12345)
+        else:
+            pos, mass, ptype = make_box(pkg, n, L, args.ngravs, 12345)
     dev = torch.device("cuda", local_rank)
     d_pos = torch.from_numpy(pos).to(dev)
     d_mass = torch.from_numpy(mass).to(dev)
@@ -267,7 +278,7 @@ def main():
     del pos, mass, ptype
     if args.decomp is None:
         args.decomp = "domain" if world > 1 and not treeonly else "replicated"
-    domain = args.decomp == "domain" and world > 1 and not treeonly
+    domain = args.decomp == "domain" and world > 1
     if domain:
         import importlib
         dd = importlib.import_module("ngravs_amd.distributed")
@@ -352,7 +363,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d-particle %s, N_GRAVS=%d (%s wiring), %s, relative criterion ErrTolForceAcc=0.005, %s walk" %
-                                   (args.config.upper(), n, "Plummer sphere" if treeonly else "uniform periodic box", args.ngravs,
+                                   (args.config.upper(), n, "GalaxyCollision.IC" if args.config == "c1" else ("Plummer sphere" if treeonly else "uniform periodic box"), args.ngravs,
                                     args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
                        "parallelism": ("work-weighted Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, x-slab decomposed PM (4 plane exchanges)" % world)

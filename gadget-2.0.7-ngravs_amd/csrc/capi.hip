@@ -807,7 +807,7 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
   c->stats.interactions = h[0];
   c->stats.n_active = (int64_t)h[1];
   c->have_acc = true;
-  if(c->shard_count > 0)
+  if(c->shard_count > 0 && c->extent_override)   // the work weights only matter to a multi-task domain cut
     hipLaunchKernelGGL(k_cost_update, GRID1(c->shard_count), 0, c->stream, c->s_idx.p, c->s_active.p, c->r_nint.p,
                        (long long)c->shard_first, (long long)c->shard_count, c->in_cost.p);
   return NGRAVS_OK;

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
 #pragma unroll
       for(int g = 0; g < NG; g++)
         {
-          n_items[g] = MODE == 2 ? gcount[ru * NG + g] : 0;
+          n_items[g] = MODE == 2 ? __builtin_amdgcn_readfirstlane(gcount[ru * NG + g]) : 0;
           bad |= n_items[g] < 0;
         }
       auto STK = [&](int i) -> int & { return stack[i]; };
@@ -1701,8 +1701,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           if(MODE == 2 && (grp - gbase) % SG == 0)   // the unit's traversal statistics, once
             {
               const long long u_cnt = (g_cnt + SG - 1) / SG;
-              st_nodes = gcount[NG * u_cnt + ru];
-              st_batches = gcount[(NG + 1) * u_cnt + ru];
+              st_nodes = __builtin_amdgcn_readfirstlane(gcount[NG * u_cnt + ru]);          // wave-uniform: keep the statistics in SGPRs
+              st_batches = __builtin_amdgcn_readfirstlane(gcount[(NG + 1) * u_cnt + ru]);
             }
           acc_st[0] += (unsigned long long)st_entries;
           acc_st[1] += (unsigned long long)st_nodes;
