@@ -111,6 +111,9 @@ def main():
     while k < len(body) and not re.match(r"^\.LBB\d+_\d+:", body[k]):
         k += 1
     loop_blocks = blocks_of(body[lo:k])
+    with open(os.path.splitext(args.out)[0].replace("_isa_mix", "_force_loop") + ".s", "w") as f:   # the loop itself, for checking
+        f.write("; force loop of %s (gfx950, hipcc -O3): blocks %s .. end of loop\n" % (KERNEL, hdr_label))
+        f.write("\n".join(body[lo:k]) + "\n")
     out = []
     out.append("Evaluation kernel k_walk_group2<2,true,true,true,false,2> (C4: N_GRAVS=2, TreePM, Yukawa pairs, tables in LDS), gfx950, hipcc -O3")
     out.append("registers: %s" % ", ".join("%s=%s" % (k2[1:], v) for k2, v in meta.items()))
