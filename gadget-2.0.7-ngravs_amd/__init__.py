@@ -16,7 +16,7 @@ import numpy as np
 
 from . import abi, ic  # noqa: F401
 from .abi import (Config, Particles, Stats, make_config, WALK_GROUP, WALK_STRICT,  # noqa: F401
-                  LAW_NONE, LAW_NEWTON, LAW_NEG_NEWTON, LAW_YUKAWA, LAW_COLOYUK)
+                  LAW_NONE, LAW_NEWTON, LAW_NEG_NEWTON, LAW_YUKAWA, LAW_COLOYUK, LAW_BAMBAM, LAW_SOURCEBAM, LAW_TARGETBAM)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libngravs_hip.so")

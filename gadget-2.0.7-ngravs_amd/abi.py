@@ -13,8 +13,8 @@ ASMTH = 1.25
 RCUT = 4.5
 BITS_PER_DIMENSION = 18
 
-LAW_NONE, LAW_NEWTON, LAW_NEG_NEWTON, LAW_YUKAWA, LAW_COLOYUK = range(5)
-SPLINE_NONE, SPLINE_PLUMMER, SPLINE_NEG_PLUMMER = range(3)
+LAW_NONE, LAW_NEWTON, LAW_NEG_NEWTON, LAW_YUKAWA, LAW_COLOYUK, LAW_BAMBAM, LAW_SOURCEBAM, LAW_TARGETBAM = range(8)
+SPLINE_NONE, SPLINE_PLUMMER, SPLINE_NEG_PLUMMER, SPLINE_BAMBAM, SPLINE_SOURCEBAM, SPLINE_TARGETBAM = range(6)
 WALK_STRICT, WALK_GROUP = 0, 1
 
 LAW_NAMES = {"none": LAW_NONE, "newtonian": LAW_NEWTON, "neg_newtonian": LAW_NEG_NEWTON,
@@ -34,7 +34,7 @@ class Config(C.Structure):
         ("yukawa_imass", C.c_double), ("asmth", C.c_double), ("rcut", C.c_double),
         ("tree_alloc_factor", C.c_double), ("group_reach", C.c_double),
         ("walk_mode", C.c_int32), ("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("bam_epsilon", C.c_double), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -71,6 +71,8 @@ def make_config(n_gravs=1, periodic=0, pmgrid=0, box_size=0.0, G=1.0, theta=0.5,
             'coloyuk'   all pairs Newton+Yukawa        (NGRAVS_COMBINED_TESTING_UNIFORM, ngravs.c:284-320)
             'yukawa_offdiag' diagonal none, off-diagonal Yukawa (NGRAVS_YUKAWA_FORCETEST, ngravs.c:213-283)
             'c4'        diagonal Newton, off-diagonal Newton+Yukawa (SURVEY.md 8(d) research wiring for C4/C5)
+            'bam'       N_GRAVS=2: species 0 baryons, species 1 BAM (NGRAVS_ACCUMULATOR_TESTING, ngravs.c:163-210): [0][0]
+                        newtonian/plummer, [0][1] sourcebambaryon, [1][0] sourcebaryonbam, [1][1] bambam; tree-only
     """
     cfg = Config()
     cfg.abi_version = ABI_VERSION
@@ -97,12 +99,15 @@ def make_config(n_gravs=1, periodic=0, pmgrid=0, box_size=0.0, G=1.0, theta=0.5,
                 law, spl = (LAW_NONE, SPLINE_NONE) if i == j else (LAW_YUKAWA, SPLINE_PLUMMER)
             elif wiring == "c4":
                 law, spl = (LAW_NEWTON if i == j else LAW_COLOYUK), SPLINE_PLUMMER
+            elif wiring == "bam":
+                law, spl = {(0, 0): (LAW_NEWTON, SPLINE_PLUMMER), (0, 1): (LAW_SOURCEBAM, SPLINE_SOURCEBAM),
+                            (1, 0): (LAW_TARGETBAM, SPLINE_TARGETBAM), (1, 1): (LAW_BAMBAM, SPLINE_BAMBAM)}[(i, j)]
             else:
                 raise ValueError("unknown wiring %r" % wiring)
             cfg.law_accel[i][j] = law
             cfg.law_spline[i][j] = spl
-            cfg.law_greens[i][j] = law
-            cfg.law_normed[i][j] = law
+            cfg.law_greens[i][j] = law if wiring != "bam" else LAW_NONE
+            cfg.law_normed[i][j] = law if wiring != "bam" else LAW_NONE
     cfg.yukawa_imass = float(yukawa_imass)
     cfg.tree_alloc_factor = float(tree_alloc_factor)
     cfg.group_reach = float(group_reach)

@@ -170,7 +170,7 @@ extern "C" const char *ngravs_build_info(void)
   static char buf[512];
   snprintf(buf, sizeof(buf),
            "libngravs_hip abi=%d arch=gfx950 N_GRAVS<=%d NTAB=%d TREE_BITS=%d sizeof(config)=%zu sizeof(particles)=%zu "
-           "sizeof(stats)=%zu walks=strict,group laws=none,newtonian,neg_newtonian,yukawa,coloyuk",
+           "sizeof(stats)=%zu walks=strict,group laws=none,newtonian,neg_newtonian,yukawa,coloyuk,bambam,sourcebambaryon,sourcebaryonbam",
            NGRAVS_ABI_VERSION, NGRAVS_MAX_GRAVS, NGRAVS_NTAB, NGRAVS_TREE_BITS, sizeof(ngravs_config_t),
            sizeof(ngravs_particles_t), sizeof(ngravs_stats_t));
   return buf;
@@ -244,14 +244,22 @@ static int check_config(const ngravs_config_t *cfg, std::string &why)
             why = "force-law table slot not wired (ngravs_core.c:321-360)";
             return NGRAVS_ERR_WIRING;
           }
-        // Newton's third law probe F[i][j](1,1,0.5,3,1) == F[j][i](...) (ngravs_core.c:371-403)
-        if(cfg->law_accel[i][j] != cfg->law_accel[j][i] || cfg->law_spline[i][j] != cfg->law_spline[j][i] ||
+        // Newton's third law probe F[i][j](1,1,0.5,3,1) == F[j][i](...) (ngravs_core.c:371-403): equal ids, or the two views of
+        // the BAM-baryon pair (sourcebambaryon / sourcebaryonbam agree for unit masses and N = 1)
+        auto same = [](int a, int b, int p, int q) { return a == b || (a == p && b == q) || (a == q && b == p); };
+        if(!same(cfg->law_accel[i][j], cfg->law_accel[j][i], NGRAVS_LAW_SOURCEBAM, NGRAVS_LAW_TARGETBAM) ||
+           !same(cfg->law_spline[i][j], cfg->law_spline[j][i], NGRAVS_SPLINE_SOURCEBAM, NGRAVS_SPLINE_TARGETBAM) ||
            cfg->law_normed[i][j] != cfg->law_normed[j][i] || cfg->law_greens[i][j] != cfg->law_greens[j][i])
           {
             why = "force-law table violates Newton's third law (ngravs_core.c:371-403)";
             return NGRAVS_ERR_WIRING;
           }
       }
+  if(cfg_has_bam(*cfg) && (cfg->pmgrid || cfg->periodic))
+    {
+      why = "the BAM laws have no Green's functions: tree-only, non-periodic runs (ngravs.c:189-194)";
+      return NGRAVS_ERR_WIRING;
+    }
   return NGRAVS_OK;
 }
 
@@ -342,6 +350,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->n_nchild.release();
   c->n_geo.release();
   c->n_mom.release();
+  c->n_npart.release();
   c->scan_out.release();
   c->scan_tmp.release();
   c->d_counters.release();

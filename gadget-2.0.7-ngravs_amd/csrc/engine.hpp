@@ -81,6 +81,7 @@ struct WalkParams
   double errtol_acc;        // ErrTolForceAcc
   double rcut, rcut2, asmthfac, utor2wpi, reach2;   // TreePM constants (forcetree.c:1708-1711)
   double ym;                // YUKAWA_IMASS / BoxSize (ngravs.c:859)
+  double bam_eps;           // BAM_EPSILON (ngravs.c:45-47)
   double fac_intp;          // 2*NGRAVS_EN/BoxSize: lattice-table lookup scale (forcetree.c:3737)
   double fsoft[NGRAVS_NTYPES];
   int t2g[NGRAVS_NTYPES];
@@ -100,6 +101,7 @@ struct WalkParams
 struct TreeView
 {
   const int *first, *count, *child, *flags;
+  const int *npart;        // particles per species below a node (NGRAVS_ACCUMULATOR, allvars.h:645-648); null unless a BAM law is wired
   const double4 *geo, *mom;
   int nnodes;
   // start table of the group walk (TreePM only): node index of every cell of one complete tree level, [ix][iy][iz]
@@ -204,6 +206,7 @@ struct ngravs_ctx
   int64_t level_start[MAX_LEVELS + 2];
   DevBuf<int> n_first, n_count, n_child, n_flags, n_nchild;
   DevBuf<double4> n_geo, n_mom;
+  DevBuf<int> n_npart;        // [nodes][NG] particle counts per species (BAM wirings only)
   DevBuf<int> scan_out;
   DevBuf<unsigned char> scan_tmp;
   DevBuf<int> d_counters;
@@ -268,6 +271,14 @@ int dd_fill_ids(ngravs_ctx *c);
 int tree_build(ngravs_ctx *c);
 int tree_moments(ngravs_ctx *c, bool refit);
 int dom_regather(ngravs_ctx *c);
+static inline bool cfg_has_bam(const ngravs_config_t &cfg)
+{
+  for(int i = 0; i < cfg.n_gravs; i++)
+    for(int j = 0; j < cfg.n_gravs; j++)
+      if(cfg.law_accel[i][j] >= NGRAVS_LAW_BAMBAM || cfg.law_spline[i][j] >= NGRAVS_SPLINE_BAMBAM)
+        return true;
+  return false;
+}
 // ---- kernels_walk.hip
 void make_walk_params(const ngravs_ctx *c, WalkParams *wp);
 int walk_run(ngravs_ctx *c);

@@ -278,16 +278,20 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
                           const int *__restrict__ n_first, const int *__restrict__ n_count,
                           const int *__restrict__ n_child, const double4 *__restrict__ n_geo,
                           double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level,
-                          WalkParams wp, double4 *__restrict__ geo_rw = nullptr)
+                          WalkParams wp, double4 *__restrict__ geo_rw = nullptr, int *__restrict__ n_npart = nullptr)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
     return;
   int node = node0 + t;
   double m[NG], sx[NG], sy[NG], sz[NG];
+  int np[NG];   // Nparticles[] of NGRAVS_ACCUMULATOR (forcetree.c:471-626)
 #pragma unroll
   for(int g = 0; g < NG; g++)
-    m[g] = sx[g] = sy[g] = sz[g] = 0;
+    {
+      m[g] = sx[g] = sy[g] = sz[g] = 0;
+      np[g] = 0;
+    }
   SoftAcc sa;
   sa.maxsofttype = 7;
   sa.diff = 0;
@@ -306,6 +310,7 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
     for(int g = 0; g < NG; g++)
       if(g == gg)
         {
+          np[g]++;
           m[g] += v.w;
           sx[g] += v.w * v.x;
           sy[g] += v.w * v.y;
@@ -334,6 +339,8 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
               for(int g = 0; g < NG; g++)
                 {
                   double4 cm = n_mom[(long long)c * NG + g];
+                  if(n_npart)
+                    np[g] += n_npart[(long long)c * NG + g];
                   m[g] += cm.w;
                   sx[g] += cm.w * cm.x;
                   sy[g] += cm.w * cm.y;
@@ -373,6 +380,8 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
         }
       o.w = m[g];
       n_mom[(long long)node * NG + g] = o;
+      if(n_npart)
+        n_npart[(long long)node * NG + g] = np[g];
     }
   n_flags[node] = (fl & (FLAG_BUCKET | FLAG_PSEUDO | FLAG_PARTIAL)) | (4 * sa.maxsofttype + 32 * sa.diff);
 }
@@ -463,6 +472,13 @@ int tree_moments(ngravs_ctx *c, bool refit)
   const int ng = c->cfg.n_gravs;
   const int bs = 128;
   double4 *grw = refit ? c->n_geo.p : nullptr;
+  int *npp = nullptr;
+  if(cfg_has_bam(c->cfg))
+    {
+      if(c->n_npart.ensure((size_t)c->max_nodes * ng))
+        return NGRAVS_ERR_NOMEM;
+      npp = c->n_npart.p;
+    }
   WalkParams wp;
   make_walk_params(c, &wp);
   for(int l = c->nlevels - 1; l >= 0; l--)
@@ -475,15 +491,15 @@ int tree_moments(ngravs_ctx *c, bool refit)
         {
         case 1:
           hipLaunchKernelGGL(k_moments<1>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
           break;
         case 2:
           hipLaunchKernelGGL(k_moments<2>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
           break;
         default:
           hipLaunchKernelGGL(k_moments<3>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
           break;
         }
     }

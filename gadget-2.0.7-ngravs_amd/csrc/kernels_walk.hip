@@ -48,10 +48,41 @@ __device__ __forceinline__ double nearest_abs(double x, double box, double invbo
 // ---------------------------------------------------------------------------------------------
 // force laws, reference formulation (strict walk, direct sum)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double law_accel_ref(int law, double m, double r2, double r, double ym)
+// the BAM family (ngravs.c:495-668): laws of the TARGET mass and of the particle number N behind the source
+__device__ __forceinline__ double bam_eta(int law, double target, double m, double N, double eps)
+{
+  if(law == NGRAVS_LAW_BAMBAM)
+    return 4.0 * M_PI * eps / (target + m / N);                        // ngravs.c:506, :542
+  if(law == NGRAVS_LAW_SOURCEBAM)
+    return 4.0 * M_PI * eps * N / m;                                   // ngravs.c:569, :597
+  return 4.0 * M_PI * eps / target;                                    // ngravs.c:624, :654
+}
+__device__ __forceinline__ double bam_accel(int law, double target, double m, double r, double N, double eps)
+{
+  double eta = bam_eta(law, target, m, N, eps), rho = 2 * target * m / M_PI;
+  double reta = r * eta, reta2 = reta * reta, eta3 = eta * eta * eta;
+  if(reta < 0.1)
+    return rho * eta3 * (2.0 * r / 3.0 - 4.0 * reta2 * r / 5.0 + 6.0 * reta2 * reta2 * r / 7.0);
+  return rho * eta3 * (atan(reta) / (reta2 * eta) - 1.0 / (reta * eta * (1 + reta2)));
+}
+__device__ __forceinline__ double bam_spline(int law, double target, double m, double r, double N, double eps)
+{
+  double eta = bam_eta(law, target, m, N, eps), rho = 2 * target * m / M_PI;
+  double reta = r * eta, reta2 = reta * reta, eta3 = eta * eta * eta;
+  if(reta < 0.1)
+    return rho * eta3 * (2.0 / 3.0 - 4.0 * reta2 / 5.0 + 6.0 * reta2 * reta2 / 7.0);
+  return rho * eta3 * (atan(reta) / (reta2 * reta) - 1.0 / (reta2 * (1 + reta2)));
+}
+
+__device__ __forceinline__ double law_accel_ref(int law, double m, double r2, double r, double ym, double target = 1.0, double N = 1.0,
+                                                double eps = 0.0)
 {
   switch(law)
     {
+    case NGRAVS_LAW_BAMBAM:
+    case NGRAVS_LAW_SOURCEBAM:
+    case NGRAVS_LAW_TARGETBAM:
+      return bam_accel(law, target, m, r, N, eps);
     case NGRAVS_LAW_NEWTON:
       return m / r2;                                                   // ngravs.c:351
     case NGRAVS_LAW_NEG_NEWTON:
@@ -64,10 +95,13 @@ __device__ __forceinline__ double law_accel_ref(int law, double m, double r2, do
       return 0.0;
     }
 }
-__device__ __forceinline__ double law_spline_ref(int id, double m, double h, double r)
+__device__ __forceinline__ double law_spline_ref(int id, double m, double h, double r, double target = 1.0, double N = 1.0, double eps = 0.0)
 {
   if(id == NGRAVS_SPLINE_NONE)
     return 0.0;
+  if(id >= NGRAVS_SPLINE_BAMBAM)
+    return bam_spline(id == NGRAVS_SPLINE_BAMBAM ? NGRAVS_LAW_BAMBAM : (id == NGRAVS_SPLINE_SOURCEBAM ? NGRAVS_LAW_SOURCEBAM : NGRAVS_LAW_TARGETBAM),
+                      target, m, r, N, eps);
   double h_inv = 1 / h, v;                                             // ngravs.c:420-434, literal constants
   r *= h_inv;
   if(r < 0.5)
@@ -225,7 +259,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
   const bool valid = (grp * WAVE + lane) < t_count && (s_active[ti < t_first + t_count ? ti : t_first] & 1) != 0;
   if(grp * WAVE >= t_count)
     return;
-  double px = 0, py = 0, pz = 0, aold = 0, hT = 0;
+  double px = 0, py = 0, pz = 0, aold = 0, hT = 0, pmass = 1.0;
   int ptype = 0, tg = 0;
   if(valid)
     {
@@ -233,6 +267,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
       px = p.x;
       py = p.y;
       pz = p.z;
+      pmass = p.w;
       ptype = s_type[ti];
       tg = wp.t2g[ptype];
       hT = wp.fsoft[ptype];
@@ -245,7 +280,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
   int sp = -1;
 
   // one source (particle or one species of a node): forcetree.c:1534-1583 / :1953-2032
-  auto interact = [&](int g, double dx, double dy, double dz, double r2, double m, double h) -> bool {
+  auto interact = [&](int g, double dx, double dy, double dz, double r2, double m, double h, double N = 1.0) -> bool {
     double r = sqrt(r2), fac;
     if(PM)
       {
@@ -264,9 +299,9 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
     else
       {
         if(r >= h)
-          fac = law_accel_ref(li.accel[tg][g], m, r2, r, wp.ym) / r;
+          fac = law_accel_ref(li.accel[tg][g], m, r2, r, wp.ym, pmass, N, wp.bam_eps) / r;
         else
-          fac = law_spline_ref(li.spline[tg][g], m, h, r);
+          fac = law_spline_ref(li.spline[tg][g], m, h, r, pmass, N, wp.bam_eps);
       }
     ax += dx * fac;
     ay += dy * fac;
@@ -380,7 +415,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #pragma unroll
                     for(int g = 0; g < NG; g++)
                       if(mom[g].w != 0.0)
-                        added |= interact(g, dx[g], dy[g], dz[g], r2[g], mom[g].w, h);
+                        added |= interact(g, dx[g], dy[g], dz[g], r2[g], mom[g].w, h, tv.npart ? (double)tv.npart[(long long)c * NG + g] : 1.0);
                     if(added || !PM)
                       nint++;
                   }
@@ -1809,9 +1844,9 @@ __global__ __launch_bounds__(256) void k_direct(const double4 *__restrict__ s_pm
         }
       double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2), u = r * (1 / h), fac;
       if(u >= 1)
-        fac = law_accel_ref(li.accel[tg][sg], q.w, r2, r, wp.ym) / r;
+        fac = law_accel_ref(li.accel[tg][sg], q.w, r2, r, wp.ym, p.w, 1.0, wp.bam_eps) / r;
       else
-        fac = law_spline_ref(li.spline[tg][sg], q.w, h, r);
+        fac = law_spline_ref(li.spline[tg][sg], q.w, h, r, p.w, 1.0, wp.bam_eps);
       ax += dx * fac;
       ay += dy * fac;
       az += dz * fac;
@@ -1880,6 +1915,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
       wp->reach2 = reach * reach;
     }
   wp->ym = cfg.box_size > 0 ? cfg.yukawa_imass / cfg.box_size : 0.0;
+  wp->bam_eps = cfg.bam_epsilon > 0 ? cfg.bam_epsilon : 1.31e-6;
   // distinct short-range tables of the wiring (same law pair <=> same table), and the bin-wise Yukawa factor
   {
     const int ng = cfg.n_gravs;
@@ -1956,6 +1992,7 @@ static TreeView tree_view(ngravs_ctx *c)
   tv.flags = c->n_flags.p;
   tv.geo = c->n_geo.p;
   tv.mom = c->n_mom.p;
+  tv.npart = cfg_has_bam(c->cfg) ? c->n_npart.p : nullptr;
   tv.nnodes = (int)c->nnodes;
   tv.ltab = c->lvl_table.p;
   tv.ltab_level = c->lvl_table_level;
@@ -2304,7 +2341,8 @@ int walk_run(ngravs_ctx *c)
   LawIds li;
   make_law_ids(c, &li);
   c->walk_ntargets = -1;
-  if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
+  const bool strict = c->cfg.walk_mode == NGRAVS_WALK_STRICT || cfg_has_bam(c->cfg);
+  if(!strict)
     {
       int rct = ensure_level_table(c, sqrt(wp.reach2));
       if(rct)
@@ -2357,7 +2395,8 @@ int walk_run(ngravs_ctx *c)
         break;
       }
   };
-  if(c->cfg.walk_mode == NGRAVS_WALK_STRICT)
+  // the BAM laws depend on the target's mass and on per-node particle counts: only the reference walk evaluates them
+  if(c->cfg.walk_mode == NGRAVS_WALK_STRICT || cfg_has_bam(c->cfg))
     strict_launch();
   else
     {
@@ -2383,7 +2422,7 @@ int walk_run(ngravs_ctx *c)
     return rc;
   HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
   HIP_TRY(c, hipGetLastError());
-  if(c->cfg.walk_mode != NGRAVS_WALK_STRICT)
+  if(!strict)
     {
       int flag = 0;
       unsigned long long st64[4] = {0, 0, 0, 0};

@@ -61,6 +61,12 @@ static int law_id(gravity f)
     return NGRAVS_LAW_YUKAWA;
   if(f == coloyuk || f == pgcoloyuk || f == normed_pgcoloyuk)
     return NGRAVS_LAW_COLOYUK;
+  if(f == bambam)
+    return NGRAVS_LAW_BAMBAM;
+  if(f == sourcebambaryon)
+    return NGRAVS_LAW_SOURCEBAM;
+  if(f == sourcebaryonbam)
+    return NGRAVS_LAW_TARGETBAM;
   printf("ngravs-hip: a wired force law has no device implementation\n");
   endrun(1050);
   return -1;
@@ -73,6 +79,12 @@ static int spline_id(gravity f)
     return NGRAVS_SPLINE_PLUMMER;
   if(f == neg_plummer)
     return NGRAVS_SPLINE_NEG_PLUMMER;
+  if(f == bambam_spline)
+    return NGRAVS_SPLINE_BAMBAM;
+  if(f == sourcebambaryon_spline)
+    return NGRAVS_SPLINE_SOURCEBAM;
+  if(f == sourcebaryonbam_spline)
+    return NGRAVS_SPLINE_TARGETBAM;
   endrun(1051);
   return -1;
 }
@@ -181,6 +193,9 @@ static void ensure_ctx(void)
       }
 #ifdef YUKAWA_IMASS
   cfg.yukawa_imass = YUKAWA_IMASS;
+#endif
+#ifdef BAM_EPSILON
+  cfg.bam_epsilon = BAM_EPSILON;
 #endif
   cfg.walk_mode = NGRAVS_WALK_GROUP;
   /* the library always sees its working set (own particles + halo copies) as one task; the tasks are joined by Comm */

@@ -56,6 +56,12 @@ typedef enum {
   NGRAVS_LAW_NEG_NEWTON = 2,  /* neg_newtonian :357, neg_pgdelta :406                 */
   NGRAVS_LAW_YUKAWA = 3,      /* yukawa :856, pgyukawa :869, normed_pgyukawa :880     */
   NGRAVS_LAW_COLOYUK = 4,     /* coloyuk :826, pgcoloyuk :830, normed_pgcoloyuk :834  */
+  /* The BAM family (ngravs.c:495-668, NGRAVS_ACCUMULATOR_TESTING wiring :163-210): laws that depend on the TARGET mass and
+   * on the number N of particles of the source species a node holds (allvars.h:645-648).  Tree-only (their Green's functions
+   * are `none`); evaluated by the reference walk (NGRAVS_WALK_STRICT) and the direct sum. */
+  NGRAVS_LAW_BAMBAM = 5,      /* bambam :495             BAM target, BAM source              */
+  NGRAVS_LAW_SOURCEBAM = 6,   /* sourcebambaryon :590    baryon target, BAM source            */
+  NGRAVS_LAW_TARGETBAM = 7,   /* sourcebaryonbam :646    BAM target, baryon source            */
   NGRAVS_LAW_COUNT
 } ngravs_law;
 
@@ -63,6 +69,9 @@ typedef enum {
   NGRAVS_SPLINE_NONE = 0,        /* none                 */
   NGRAVS_SPLINE_PLUMMER = 1,     /* plummer      ngravs.c:420-434 */
   NGRAVS_SPLINE_NEG_PLUMMER = 2, /* neg_plummer  ngravs.c:438-455 */
+  NGRAVS_SPLINE_BAMBAM = 3,      /* bambam_spline :531 */
+  NGRAVS_SPLINE_SOURCEBAM = 4,   /* sourcebambaryon_spline :562 */
+  NGRAVS_SPLINE_TARGETBAM = 5,   /* sourcebaryonbam_spline :616 */
   NGRAVS_SPLINE_COUNT
 } ngravs_spline;
 
@@ -113,7 +122,8 @@ typedef struct {
   int32_t walk_mode;          /* ngravs_walk_mode                                                */
   int32_t device;             /* HIP device ordinal                                              */
   int32_t rank, world_size;   /* ThisTask, NTask: target shard = Peano segment `rank` of `world_size` */
-  int32_t reserved[8];
+  double bam_epsilon;         /* BAM_EPSILON (ngravs.c:45-47); 0 => 1.31e-6                                */
+  int32_t reserved[6];
 } ngravs_config_t;
 
 /* Host- or device-resident particle columns (the fields of struct particle_data the path reads,

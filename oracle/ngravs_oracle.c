@@ -224,6 +224,7 @@ struct orc_tree
   double *len, *center;       /* [maxnodes], [maxnodes][3]            */
   int32_t *suns;              /* [maxnodes][8] (build-time children)  */
   double *s, *nmass;          /* [maxnodes][3][ng], [maxnodes][ng]    */
+  int64_t *npart;             /* [maxnodes][ng]: Nparticles[] of NGRAVS_ACCUMULATOR (allvars.h:645-648, forcetree.c:471-626) */
   int32_t *bitflags, *sibling, *nextnode, *father;
   int32_t *pnext, *pfather;   /* Nextnode[], Father[] of particles    */
   int32_t last;
@@ -293,8 +294,12 @@ static void update_node(orc_tree *t, const ngravs_config_t *cfg, int no, int sib
     suns[j] = t->suns[8 * a + j];
   link_last(t, no);
   double s[3][MAXG], m[MAXG];
+  int64_t np[MAXG];
   for(int g = 0; g < ng; g++)
-    s[0][g] = s[1][g] = s[2][g] = m[g] = 0;
+    {
+      s[0][g] = s[1][g] = s[2][g] = m[g] = 0;
+      np[g] = 0;
+    }
   int maxsofttype = 7, diffsoft = 0;
   for(int j = 0; j < 8; j++)
     {
@@ -314,6 +319,7 @@ static void update_node(orc_tree *t, const ngravs_config_t *cfg, int no, int sib
           int64_t c = p - t->maxpart;
           for(int g = 0; g < ng; g++)
             {
+              np[g] += t->npart[c * ng + g];
               m[g] += t->nmass[c * ng + g];
               s[0][g] += t->nmass[c * ng + g] * t->s[(c * 3 + 0) * ng + g];
               s[1][g] += t->nmass[c * ng + g] * t->s[(c * 3 + 1) * ng + g];
@@ -338,6 +344,7 @@ static void update_node(orc_tree *t, const ngravs_config_t *cfg, int no, int sib
         {
           int ty = t->type[p];
           int g = cfg->type_to_grav[ty];
+          np[g]++;
           m[g] += t->mass[p];
           s[0][g] += t->mass[p] * t->pos[3 * p + 0];
           s[1][g] += t->mass[p] * t->pos[3 * p + 1];
@@ -374,6 +381,7 @@ static void update_node(orc_tree *t, const ngravs_config_t *cfg, int no, int sib
       t->s[(a * 3 + 1) * ng + g] = s[1][g];
       t->s[(a * 3 + 2) * ng + g] = s[2][g];
       t->nmass[a * ng + g] = m[g];
+      t->npart[a * ng + g] = np[g];
     }
   t->bitflags[a] = 4 * maxsofttype + 32 * diffsoft;
   t->sibling[a] = sib;
@@ -404,6 +412,7 @@ orc_tree *orc_tree_build(const ngravs_config_t *cfg, const double *pos, const do
   t->suns = malloc(sizeof(int32_t) * 8 * mn);
   t->s = malloc(sizeof(double) * 3 * ng * mn);
   t->nmass = malloc(sizeof(double) * ng * mn);
+  t->npart = malloc(sizeof(int64_t) * ng * mn);
   t->bitflags = malloc(sizeof(int32_t) * mn);
   t->sibling = malloc(sizeof(int32_t) * mn);
   t->nextnode = malloc(sizeof(int32_t) * mn);
@@ -518,6 +527,7 @@ void orc_tree_free(orc_tree *t)
   free(t->suns);
   free(t->s);
   free(t->nmass);
+  free(t->npart);
   free(t->bitflags);
   free(t->sibling);
   free(t->nextnode);
@@ -551,11 +561,53 @@ void orc_tree_get_node(const orc_tree *t, int64_t i, double *out, int32_t *bitfl
  *   spline(id, source_mass, h, r)             returns fac with the 1/r folded in
  *   greens(law, k2, k), normed(law, k2, k)    k in mesh units / table units
  * ------------------------------------------------------------------------------------------ */
+/* the BAM family (ngravs.c:495-668): `target` is the target particle's mass, N the number of particles of the source species
+ * behind `src` (1 for a particle, Nparticles[g] of a node, allvars.h:645-648).  accel form: |a| * r already folded as the
+ * reference does ("r put back in because forcetree.c divides it out"); spline form: fac with 1/r folded in. */
+static double bam_eps(const ngravs_config_t *c) { return c->bam_epsilon > 0 ? c->bam_epsilon : 1.31e-6; }
+static double bam_eta(const ngravs_config_t *c, int law, double target, double src, long N)
+{
+  switch(law)
+    {
+    case NGRAVS_LAW_BAMBAM:
+      return 4.0 * M_PI * bam_eps(c) / (target + src / N);   /* :506, :542 */
+    case NGRAVS_LAW_SOURCEBAM:
+      return 4.0 * M_PI * bam_eps(c) * N / src;              /* :569, :597 */
+    default:
+      return 4.0 * M_PI * bam_eps(c) / target;               /* :624, :654 */
+    }
+}
+static double bam_accel(const ngravs_config_t *c, int law, double target, double src, double r, long N)
+{
+  double eta = bam_eta(c, law, target, src, N), rho = 2 * target * src / M_PI;
+  double reta = r * eta, reta2 = reta * reta, eta3 = eta * eta * eta;
+  if(reta < 0.1)
+    return rho * eta3 * (2.0 * r / 3.0 - 4.0 * reta2 * r / 5.0 + 6.0 * reta2 * reta2 * r / 7.0);
+  return rho * eta3 * (atan(reta) / (reta2 * eta) - 1.0 / (reta * eta * (1 + reta2)));
+}
+static double bam_spline(const ngravs_config_t *c, int law, double target, double src, double r, long N)
+{
+  double eta = bam_eta(c, law, target, src, N), rho = 2 * target * src / M_PI;
+  double reta = r * eta, reta2 = reta * reta, eta3 = eta * eta * eta;
+  if(reta < 0.1)
+    return rho * eta3 * (2.0 / 3.0 - 4.0 * reta2 / 5.0 + 6.0 * reta2 * reta2 / 7.0);
+  return rho * eta3 * (atan(reta) / (reta2 * reta) - 1.0 / (reta2 * (1 + reta2)));
+}
+
+static double law_accel_tn(const ngravs_config_t *c, int law, double target, double src, double r2, double r, long N);
 static double law_accel(const ngravs_config_t *c, int law, double src, double r2, double r)
+{
+  return law_accel_tn(c, law, 1.0, src, r2, r, 1);
+}
+static double law_accel_tn(const ngravs_config_t *c, int law, double target, double src, double r2, double r, long N)
 {
   double ym;
   switch(law)
     {
+    case NGRAVS_LAW_BAMBAM:
+    case NGRAVS_LAW_SOURCEBAM:
+    case NGRAVS_LAW_TARGETBAM:
+      return bam_accel(c, law, target, src, r, N);
     case NGRAVS_LAW_NEWTON:
       return src / r2; /* ngravs.c:351 */
     case NGRAVS_LAW_NEG_NEWTON:
@@ -570,11 +622,22 @@ static double law_accel(const ngravs_config_t *c, int law, double src, double r2
       return 0.0;
     }
 }
+static double law_spline_tn(const ngravs_config_t *c, int id, double target, double src, double h, double r, long N);
 static double law_spline(int id, double src, double h, double r)
+{
+  return law_spline_tn(NULL, id, 1.0, src, h, r, 1);
+}
+static double law_spline_tn(const ngravs_config_t *c, int id, double target, double src, double h, double r, long N)
 {
   /* plummer (ngravs.c:420-434), literal constants kept */
   if(id == NGRAVS_SPLINE_NONE)
     return 0.0;
+  if(id == NGRAVS_SPLINE_BAMBAM)
+    return bam_spline(c, NGRAVS_LAW_BAMBAM, target, src, r, N);
+  if(id == NGRAVS_SPLINE_SOURCEBAM)
+    return bam_spline(c, NGRAVS_LAW_SOURCEBAM, target, src, r, N);
+  if(id == NGRAVS_SPLINE_TARGETBAM)
+    return bam_spline(c, NGRAVS_LAW_TARGETBAM, target, src, r, N);
   double h_inv = 1 / h, v;
   r *= h_inv;
   if(r < 0.5)
@@ -637,11 +700,79 @@ double orc_law_eval(const ngravs_config_t *cfg, int which, int id, double a3, do
     case 0:
       return law_accel(cfg, id, 1.0, a3, a4);
     case 1:
-      return law_spline(id, 1.0, a3, a4);
+      return law_spline_tn(cfg, id, 1.0, 1.0, a3, a4, 1);
     case 2:
       return law_greens(cfg, cfg_asmth(cfg), id, a3, a4);
     default:
       return law_normed(cfg, cfg_asmth(cfg), id, a3, a4);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * The dynamic tree update between rebuilds (TreeDomainUpdateFrequency > 0), in the reference's semantics:
+ *   node velocities vs[3][g] = mass-weighted mean velocity of the node's particles of species g
+ *       (force_update_node_recursive, forcetree.c:451-743, accumulates them next to s[][]);
+ *   move_particles (predict.c:79-91): s[j][g] += vs[j][g] * dt_drift for every node, then
+ *   force_update_len -> force_update_node_len_local (forcetree.c:1005-1085): a particle that left its father's cell
+ *       enlarges it to len = 2 max_k |Pos_k - center_k|, and the enlargement is handed up the father chain,
+ *       len_p = 2 |center_p.x - center_no.x| + len_no while 0.999999 * that exceeds len_p.
+ * (The node kicks of timestep.c:331-344 are not restated: they add a kicked particle's dv m/M to the node velocities of ALL
+ * species -- a quirk that only matters for N_GRAVS > 1 -- and a pure drift never calls them.)
+ * newpos = the drifted positions (the caller drifts the particles, as move_particles does); vel, dt the velocities and the
+ * drift interval used for it.  The tree then refers to newpos.
+ * ------------------------------------------------------------------------------------------ */
+void orc_tree_drift(orc_tree *t, const ngravs_config_t *cfg, const double *newpos, const double *vel, double dt)
+{
+  const int ng = t->ng;
+  const int64_t nn = t->numnodes;
+  double *vs = calloc((size_t)nn * 3 * ng, sizeof(double));
+  for(int64_t i = 0; i < t->n; i++)
+    {
+      const int g = cfg->type_to_grav[t->type[i]];
+      for(int no = t->pfather[i]; no >= 0; no = t->father[no - t->maxpart])
+        {
+          const int64_t a = no - t->maxpart;
+          for(int j = 0; j < 3; j++)
+            vs[(a * 3 + j) * ng + g] += t->mass[i] * vel[3 * i + j];
+        }
+    }
+  for(int64_t a = 0; a < nn; a++)
+    for(int g = 0; g < ng; g++)
+      if(t->nmass[a * ng + g] > 0)
+        for(int j = 0; j < 3; j++)
+          t->s[(a * 3 + j) * ng + g] += vs[(a * 3 + j) * ng + g] / t->nmass[a * ng + g] * dt;   /* predict.c:83-86 */
+  free(vs);
+  t->pos = newpos;
+  for(int64_t i = 0; i < t->n; i++)   /* force_update_node_len_local, forcetree.c:1043-1085 */
+    {
+      int no = t->pfather[i];
+      int64_t a = no - t->maxpart;
+      double distmax = 0;
+      for(int k = 0; k < 3; k++)
+        {
+          double dist = fabs(newpos[3 * i + k] - t->center[3 * a + k]);
+          if(dist > distmax)
+            distmax = dist;
+        }
+      if(distmax + distmax > t->len[a])
+        {
+          t->len[a] = distmax + distmax;
+          int p = t->father[a];
+          while(p >= 0)
+            {
+              const int64_t b = p - t->maxpart;
+              distmax = fabs(t->center[3 * b] - t->center[3 * a]);
+              distmax = distmax + distmax + t->len[a];
+              if(0.999999 * distmax > t->len[b])
+                {
+                  t->len[b] = distmax;
+                  a = b;
+                  p = t->father[b];
+                }
+              else
+                break;
+            }
+        }
     }
 }
 
@@ -659,6 +790,8 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
   const double px = t->pos[3 * target], py = t->pos[3 * target + 1], pz = t->pos[3 * target + 2];
   const int ptype = t->type[target];
   const int tg = cfg->type_to_grav[ptype];
+  const double pmass = t->mass[target];          /* the BAM laws need the target's mass (forcetree.c:1342, pmass) */
+  long nn[MAXG];                                 /* ... and the particle number behind every source (Nparticles[], :1563) */
   const double aold = cfg->err_tol_force_acc * aold_in;
   double rcut = 0, rcut2 = 0, asmthfac = 0, utor2wpi = 0;
   if(pm)
@@ -681,6 +814,7 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
         {
           sg = cfg->type_to_grav[t->type[no]];
           m[sg] = t->mass[no];
+          nn[sg] = 1;
           dx[sg] = t->pos[3 * no] - px;
           dy[sg] = t->pos[3 * no + 1] - py;
           dz[sg] = t->pos[3 * no + 2] - pz;
@@ -703,6 +837,7 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
           for(int g = 0; g < ng; g++)
             {
               m[g] = t->nmass[a * ng + g];
+              nn[g] = (long)t->npart[a * ng + g];
               summass += m[g];
               dx[g] = t->s[(a * 3 + 0) * ng + g] - px;
               dy[g] = t->s[(a * 3 + 1) * ng + g] - py;
@@ -800,19 +935,19 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
                 continue;
               if(r >= h)
                 {
-                  fac = law_accel(cfg, cfg->law_accel[tg][g], m[g], r2[g], r);
+                  fac = law_accel_tn(cfg, cfg->law_accel[tg][g], pmass, m[g], r2[g], r, nn[g]);
                   fac -= m[g] * utor2wpi * table[((size_t)tg * ng + g) * NTAB + tab];
                   fac /= r;
                 }
               else
-                fac = law_spline(cfg->law_spline[tg][g], m[g], h, r);
+                fac = law_spline_tn(cfg, cfg->law_spline[tg][g], pmass, m[g], h, r, nn[g]);
             }
           else
             {
               if(r >= h)
-                fac = law_accel(cfg, cfg->law_accel[tg][g], m[g], r2[g], r) / r;
+                fac = law_accel_tn(cfg, cfg->law_accel[tg][g], pmass, m[g], r2[g], r, nn[g]) / r;
               else
-                fac = law_spline(cfg->law_spline[tg][g], m[g], h, r);
+                fac = law_spline_tn(cfg, cfg->law_spline[tg][g], pmass, m[g], h, r, nn[g]);
             }
           ax += dx[g] * fac;
           ay += dy[g] * fac;
@@ -1474,9 +1609,9 @@ static void orc_direct_impl(const ngravs_config_t *cfg, const double *pos, const
           double r2 = dx * dx + dy * dy + dz * dz, r = sqrt(r2), u = r * (1 / h), fac;
           int sg = cfg->type_to_grav[type[i]];
           if(u >= 1)
-            fac = law_accel(cfg, cfg->law_accel[tg][sg], mass[i], r2, r) / r;
+            fac = law_accel_tn(cfg, cfg->law_accel[tg][sg], mass[t], mass[i], r2, r, 1) / r;
           else
-            fac = law_spline(cfg->law_spline[tg][sg], mass[i], h, r);
+            fac = law_spline_tn(cfg, cfg->law_spline[tg][sg], mass[t], mass[i], h, r, 1);
           ax += dx * fac;
           ay += dy * fac;
           az += dz * fac;

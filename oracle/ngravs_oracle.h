@@ -36,6 +36,9 @@ int orc_toptree_count(const int64_t *keys, int64_t n, int *ntopleaves);
 orc_tree *orc_tree_build(const ngravs_config_t *cfg, const double *pos, const double *mass,
                          const int32_t *type, int64_t n, const double dom[8]);
 void orc_tree_free(orc_tree *t);
+/* dynamic tree update in the reference's semantics: node drift with node velocities (predict.c:79-91) + force_update_len
+ * (forcetree.c:1005-1085); newpos must outlive the tree */
+void orc_tree_drift(orc_tree *t, const ngravs_config_t *cfg, const double *newpos, const double *vel, double dt);
 int64_t orc_tree_numnodes(const orc_tree *t);
 int orc_tree_ntopleaves(const orc_tree *t);
 /* node record i (0..numnodes): out = len, center[3], then per species g: s[3], mass; flags */

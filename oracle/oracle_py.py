@@ -92,6 +92,13 @@ class Tree:
                                       C.c_int64(self.n), _p(self.dom))
         self.h = C.c_void_p(self.h)
 
+    def drift(self, newpos, vel, dt):
+        """the reference's dynamic tree update (predict.c:79-91 node drift + force_update_len, forcetree.c:1005-1085)"""
+        self.pos = _f64(newpos)
+        self._vel = _f64(vel)
+        lib().orc_tree_drift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        lib().orc_tree_drift(self.h, C.byref(self.cfg), _p(self.pos), _p(self._vel), C.c_double(dt))
+
     @property
     def numnodes(self):
         return int(lib().orc_tree_numnodes(self.h))

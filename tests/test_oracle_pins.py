@@ -118,3 +118,33 @@ def test_force_law_known_answers(pkg, O):
     assert abs(c - (y + 0.25)) < 1e-15
     ym = 60.0 / 100.0
     assert abs(y - np.exp(-2 * ym) * (ym / 2 + 0.25)) < 1e-15
+
+
+def test_bam_law_known_answers(pkg, O):
+    """The BAM family (ngravs.c:495-668) in the oracle: closed forms for unit masses and N = 1, where
+    eta = 4 pi BAM_EPSILON / 2 (bambam) or 4 pi BAM_EPSILON (the two BAM-baryon views), rho = 2/pi:
+      accel(r)  = rho eta^3 (atan(x)/(x^2 eta) - 1/(x eta (1 + x^2))),  x = r eta   (the |a| * r the walk divides by r)
+      spline(r) = accel(r) / r,  and the x < 0.1 Taylor branch joins the closed form continuously;
+    the reference's own third-law probe F[i][j](1,1,0.5,3,1) == F[j][i](...) (ngravs_core.c:371-403) for the BAM-baryon pair."""
+    cfg = pkg.make_config(n_gravs=2, wiring="bam")
+    eps = 1.31e-6
+    for law, eta in ((pkg.LAW_BAMBAM, 4 * np.pi * eps / 2), (pkg.LAW_SOURCEBAM, 4 * np.pi * eps), (pkg.LAW_TARGETBAM, 4 * np.pi * eps)):
+        rho = 2 / np.pi
+        for r in (0.3 / eta, 5.0 / eta, 200.0 / eta):
+            x = r * eta
+            want = rho * eta ** 3 * (np.arctan(x) / (x * x * eta) - 1.0 / (x * eta * (1 + x * x)))
+            got = O.law_eval(cfg, 0, law, r * r, r)
+            assert abs(got - want) <= 1e-14 * abs(want)
+            spl = O.law_eval(cfg, 1, law - pkg.LAW_BAMBAM + 3, 1.0, r)        # spline ids 3,4,5 follow the law ids 5,6,7
+            assert abs(spl - want / r) <= 1e-13 * abs(want / r)
+        lo, hi = O.law_eval(cfg, 0, law, 0, 0.1 / eta * (1 - 1e-9)), O.law_eval(cfg, 0, law, 0, 0.1 / eta * (1 + 1e-9))
+        assert abs(lo - hi) / hi < 2e-6          # Taylor (three terms) vs closed form at x = 0.1: the reference's own join error (8 x^6/9 : 2/3)
+        # far field: Newtonian, |a| r^2 -> rho pi / 2 = 1 for unit masses (corrections O(1/x))
+        far = O.law_eval(cfg, 0, law, 0, 1e6 / eta) * (1e6 / eta) ** 2
+        assert abs(far - rho * np.pi / 2) < 1e-5
+    assert O.law_eval(cfg, 0, pkg.LAW_SOURCEBAM, 0.5, 3.0) == O.law_eval(cfg, 0, pkg.LAW_TARGETBAM, 0.5, 3.0)
+    # wiring rules: the BAM-baryon pair is accepted as symmetric, PM with BAM is refused (their Green's functions are `none`)
+    import ctypes as C
+    h = C.c_void_p()
+    bad = pkg.make_config(n_gravs=2, wiring="bam", periodic=1, pmgrid=32, box_size=1.0)
+    assert pkg.lib().ngravs_create(C.byref(bad), C.byref(h)) == -6
