@@ -96,6 +96,8 @@ struct WalkParams
   // appended to the table buffer (valid while ym * bin width is small, else 0 and exp() is evaluated in full)
   int exp_tab;
   double inv_asmthfac;
+  double ec[4];   // (ym / asmthfac)^k / k!, k = 1..4: the polynomial in the bin fraction
+
 };
 
 struct TreeView

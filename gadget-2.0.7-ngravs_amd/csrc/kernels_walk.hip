@@ -579,7 +579,8 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW_STACK 8192       // fused kernel: pending-node LIFO per wave (global scratch)
 // one pool per wave (the species are evaluated one after the other): 128 x (double4 pos/mass, 4 floats = position relative to
 // the group's box centre and its square for the packed-fp32 reach pre-test, 1 byte = softening type)
-#define GW2_WAVE_LDS ((sizeof(double4) + 4 * sizeof(float) + 1) * 128)
+// per wave: [NULL entry (double4)] [128 x double4 position/mass] [4 x 128 floats] [128 type bytes] -- 16-byte multiple
+#define GW2_WAVE_LDS (sizeof(double4) + (sizeof(double4) + 4 * sizeof(float) + 1) * 128)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
 
 // exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
@@ -685,10 +686,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
   double *expT = reinterpret_cast<double *>(smem + tab_bytes);
   unsigned char *wbase = smem + tab_bytes + 40 * sizeof(double) + (size_t)wave * GW2_WAVE_LDS;
   double *fsT = expT + 32;   // softening length per particle type (8 entries; index 7 = empty node)
-  double4 *lpos = reinterpret_cast<double4 *>(wbase);
-  float *lfx = reinterpret_cast<float *>(wbase + sizeof(double4) * 2 * WAVE);
+  double4 *lpos = reinterpret_cast<double4 *>(wbase) + 1;   // lpos[-1]: the NULL entry
+  float *lfx = reinterpret_cast<float *>(wbase + sizeof(double4) * (2 * WAVE + 1));
   float *lfy = lfx + 2 * WAVE, *lfz = lfx + 4 * WAVE, *le2 = lfx + 6 * WAVE;
-  unsigned char *lty = wbase + (sizeof(double4) + 4 * sizeof(float)) * 2 * WAVE;
+  unsigned char *lty = wbase + sizeof(double4) + (sizeof(double4) + 4 * sizeof(float)) * 2 * WAVE;
   if(MODE != 1)
     {
       if(threadIdx.x < 32)
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       z.x = z.y = z.z = 1e10;
       z.w = 0.0;
       lpos[127] = z;
+      lpos[-1] = z;   // a lane whose mask is exhausted computes index -1 (v_ffbl_b32 of 0), see the force loop
       lty[127] = 7;   // fsT[7] = 0: unsoftened
       lfx[127] = lfy[127] = lfz[127] = 1e10f;
       le2[127] = 3e20f;
@@ -885,8 +887,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       const double hT_min = wave_min(mnh);
       // may sources be wrapped once per group (relative to the box centre) instead of per pair?
       const double bhmax = fmax(bhx, fmax(bhy, bhz));
-      const bool prewrap = wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
-                           (wp.boxhalf - bhmax) > 0;
+      // (wave-uniform by construction; read through an SGPR so that the branches on them are scalar branches)
+      const bool prewrap = __builtin_amdgcn_readfirstlane(
+                               (int)(wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
+                                     (wp.boxhalf - bhmax) > 0)) != 0;
       const bool lanewrap = wp.periodic && !prewrap;
       // packed-fp32 reach pre-test (PM, no per-pair wrapping): positions relative to the box centre in fp32, threshold
       // widened by the worst-case rounding so that no true hit is lost; the force loop re-tests in fp64 (in[k])
@@ -917,10 +921,20 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       // Inactive slots (a lane whose mask is exhausted) point at the pool's NULL entry (index 127: far away, mass 0), so the
       // common path needs no per-slot masking at all; the rare slot that passed the fp32 pre-test but fails the exact
       // r2 < reach2 test is removed under a wave-level branch.
-      auto evalN = [&](auto lw_tag, const int g, const double4 (&e)[ES], const int (&jj)[ES], const bool (&act)[ES]) {
+      // actm[k]: the lane mask of act[k], handed in by the caller (who has it from its loop condition; a second ballot of the
+      // same condition would cost 2 VALU)
+      auto evalN = [&](auto lw_tag, auto et_tag, const int g, const double4 (&e)[ES], const int (&jj)[ES],
+                       const unsigned long long (&actm)[ES]) {
+        // this lane's bit of actm[k], extracted where it is needed (the rare branches) and not in the common path
+        auto is_act = [&](int k) -> bool {
+          unsigned long long am = actm[k];
+          asm volatile("" : "+s"(am));
+          return ((am >> lane) & 1ull) != 0;
+        };
         constexpr bool LW = decltype(lw_tag)::value;
+        constexpr bool ET = decltype(et_tag)::value;   // Yukawa factor through the table bins (wp.exp_tab, hoisted by the caller)
         double dx[ES], dy[ES], dz[ES], r2[ES], rinv[ES], r[ES], fac[ES], mw[ES];
-        bool fpos = false;
+        unsigned long long fpos = 0;   // lane masks, combined on the scalar unit (a ballot of a compound condition costs 2 VALU)
 #pragma unroll
         for(int k = 0; k < ES; k++)
           {
@@ -936,14 +950,17 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             r2[k] = dx[k] * dx[k] + dy[k] * dy[k] + dz[k] * dz[k];
             mw[k] = e[k].w;
             if(PM)
-              fpos |= act[k] && !(r2[k] < wp.reach2);
+              fpos |= actm[k] & __builtin_amdgcn_ballot_w64(!(r2[k] < wp.reach2));
           }
-        if(PM && wave_any(fpos))                                          // rare: beyond the exact cut
+        if(PM && fpos != 0ull)                                            // rare: beyond the exact cut
           {
+            asm volatile("; beyond the exact cut" ::: "memory");          // keeps this a branch (if-converted it costs 6 VALU per slot)
 #pragma unroll
             for(int k = 0; k < ES; k++)
               {
-                const bool out = act[k] && !(r2[k] < wp.reach2);
+                double r2o = r2[k];
+                asm volatile("" : "+v"(r2o));   // opaque copy: the test is redone HERE, not hoisted into the common path as an integer
+                const bool out = is_act(k) && !(r2o < wp.reach2);
                 mw[k] = out ? 0.0 : mw[k];
                 nint -= out ? 1 : 0;
               }
@@ -962,23 +979,26 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             const double ri2 = ri * ri;
             double f = cNg * ri2;
             int tab = 0;
+            double xt = 0;
             if(PM)
               {
-                tab = (int)(wp.asmthfac * rr);                            // saturating conversion, then clamped
+                xt = wp.asmthfac * rr;
+                tab = (int)xt;                                            // saturating conversion, then clamped
                 tab = tab < NTAB - 1 ? tab : NTAB - 1;
               }
             if(YUK)
               {
                 double ex;
-                if(PM && wp.exp_tab)
+                if(PM && ET)
                   {
-                    // exp(-ym r) = E[tab] exp(-u), u = ym (r - tab/asmthfac) in [0, ym/asmthfac) < 1e-3: degree-4 Taylor
-                    // (u^5/120 < 1e-17), Estrin form: every step has at most one non-inline constant, so no register copies
-                    const double u = wp.ym * __builtin_fma(-(double)tab, wp.inv_asmthfac, rr);
-                    const double u2 = u * u;
-                    const double lo = __builtin_fma(u, -1.0, 1.0);                    // 1 - u
-                    const double hi = __builtin_fma(u, -1.0 / 6.0, 0.5);              // 1/2 - u/6
-                    const double pz = __builtin_fma(u2, __builtin_fma(u2, 1.0 / 24.0, hi), lo);
+                    // exp(-ym r) = E[tab] exp(-u), u = ub * (position inside the bin), ub = ym/asmthfac < 1e-3: degree-4 Taylor
+                    // (u^5/120 < 1e-17) in the bin fraction with pre-scaled coefficients ec[k-1] = ub^k/k!, Estrin form.
+                    // (A slot beyond the table, whose fraction belongs to another bin, has been given mass 0 above.)
+                    const double fb = __builtin_amdgcn_fract(xt);
+                    const double f2 = fb * fb;
+                    const double lo = __builtin_fma(fb, -wp.ec[0], 1.0);
+                    const double hi = __builtin_fma(fb, -wp.ec[2], wp.ec[1]);
+                    const double pz = __builtin_fma(f2, __builtin_fma(f2, wp.ec[3], hi), lo);
                     ex = etab[tab] * pz;
                   }
                 else
@@ -992,10 +1012,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           }
         if(wave_any(anysoft))                                             // rare: possibly inside the softening radius
           {
+            asm volatile("; softened pair" ::: "memory");
 #pragma unroll
             for(int k = 0; k < ES; k++)
               {
-                const double h = __builtin_fmax(hT, fsT[lty[jj[k]]]);     // the pair's softening (forcetree.c:1415-1417)
+                const double h = __builtin_fmax(hT, fsT[lty[is_act(k) ? jj[k] : 127]]);     // the pair's softening (forcetree.c:1415-1417)
                 const bool soft = r[k] < h;
                 double h_inv = 1 / h, u = r[k] * h_inv;
                 double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
@@ -1016,8 +1037,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // periodic tree-only: every source also contributes its infinite lattice of images (forcetree.c:1605-1607);
                 // here on the SAME (finer) interaction list as the nearest-image force
                 double fx, fy, fz;
-                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, act[k] ? dx[k] : 0.0, act[k] ? dy[k] : 0.0,
-                           act[k] ? dz[k] : 0.0, fx, fy, fz);
+                const bool a_ = is_act(k);
+                lat_lookup(table + ((size_t)tg * NG + g) * LAT_SZ, wp.fac_intp, a_ ? dx[k] : 0.0, a_ ? dy[k] : 0.0,
+                           a_ ? dz[k] : 0.0, fx, fy, fz);
                 ax = __builtin_fma(mw[k], fx, ax);
                 ay = __builtin_fma(mw[k], fy, ay);
                 az = __builtin_fma(mw[k], fz, az);
@@ -1352,12 +1374,14 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       {
                         st_iters += ES;
                         bool act[ES];
+                        unsigned long long actm[ES];
                         int jj[ES];
                         double4 e[ES];
 #pragma unroll
                         for(int k = 0; k < ES; k++)
                           {
                             act[k] = valid && j0 + k < nc;
+                            actm[k] = __builtin_amdgcn_ballot_w64(act[k]);
                             jj[k] = j0 + k < nc ? j0 + k : 127;   // 127: the NULL entry
                             e[k] = pp[jj[k]];
                           }
@@ -1368,32 +1392,57 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                               e[k].w = 0.0;
                           }
                         if(lanewrap)
-                          evalN(std::true_type{}, g, e, jj, act);
+                          evalN(std::true_type{}, std::false_type{}, g, e, jj, actm);
                         else
-                          evalN(std::false_type{}, g, e, jj, act);
+                          evalN(std::false_type{}, std::false_type{}, g, e, jj, actm);
                       }
                     m = 0;
                   }
-                while(wave_any(m != 0))
+                // The loop exists once per (per-pair wrap, table-bin exp) combination, chosen by scalar branches OUTSIDE it:
+                // inside, the only control flow is the two rare wave-level branches of evalN.
+                auto bit_loop = [&](auto lw_tag, auto et_tag) {
+                  for(;;)
+                    {
+                      unsigned long long actm[ES];
+                      actm[0] = __builtin_amdgcn_ballot_w64(m != 0);
+                      if(actm[0] == 0ull)
+                        break;
+                      st_iters += ES;
+                      int jj[ES];
+#pragma unroll
+                      for(int k = 0; k < ES; k++)
+                        {
+                          if(k > 0)
+                            actm[k] = __builtin_amdgcn_ballot_w64(m != 0);
+                          // lowest set bit; an exhausted mask gives -1 (v_ffbl_b32 of 0 is -1, and -1 | 32 = -1): the NULL
+                          // entry sits at pool index -1, so no select is needed
+                          int jl, jh;
+                          asm("v_ffbl_b32 %0, %1" : "=v"(jl) : "v"((unsigned int)m));
+                          asm("v_ffbl_b32 %0, %1" : "=v"(jh) : "v"((unsigned int)(m >> 32)));
+                          const unsigned int ju = (unsigned int)jl < ((unsigned int)jh | 32u) ? (unsigned int)jl : ((unsigned int)jh | 32u);
+                          jj[k] = (int)ju;
+                          m &= m - 1;
+                        }
+                      double4 e[ES];
+#pragma unroll
+                      for(int k = 0; k < ES; k++)
+                        e[k] = pp[jj[k]];
+                      evalN(lw_tag, et_tag, g, e, jj, actm);
+                    }
+                };
+                if(lanewrap)
                   {
-                    st_iters += ES;
-                    bool act[ES];
-                    int jj[ES];
-#pragma unroll
-                    for(int k = 0; k < ES; k++)
-                      {
-                        act[k] = m != 0;
-                        jj[k] = act[k] ? __builtin_ctzll(m) : 127;   // 127: the NULL entry
-                        m &= m - 1;
-                      }
-                    double4 e[ES];
-#pragma unroll
-                    for(int k = 0; k < ES; k++)
-                      e[k] = pp[jj[k]];
-                    if(lanewrap)
-                      evalN(std::true_type{}, g, e, jj, act);
+                    if(YUK && wp.exp_tab)
+                      bit_loop(std::true_type{}, std::true_type{});
                     else
-                      evalN(std::false_type{}, g, e, jj, act);
+                      bit_loop(std::true_type{}, std::false_type{});
+                  }
+                else
+                  {
+                    if(YUK && wp.exp_tab)
+                      bit_loop(std::false_type{}, std::true_type{});
+                    else
+                      bit_loop(std::false_type{}, std::false_type{});
                   }
                 wave_sync();
                 // move the remainder to the front
@@ -1944,6 +1993,11 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
         wp->inv_asmthfac = 1.0 / wp->asmthfac;
         wp->exp_tab = (wp->ym * wp->inv_asmthfac < 1.0e-3) ? 1 : 0;   // u^5/120 < 1e-17
       }
+    const double ub = wp->ym * wp->inv_asmthfac;   // exponent across one table bin
+    wp->ec[0] = ub;
+    wp->ec[1] = ub * ub / 2.0;
+    wp->ec[2] = ub * ub * ub / 6.0;
+    wp->ec[3] = ub * ub * ub * ub / 24.0;
   }
   wp->fac_intp = cfg.box_size > 0 ? 2.0 * LAT_EN / cfg.box_size : 0.0;   // forcetree.c:3737
   for(int t = 0; t < NGRAVS_NTYPES; t++)
