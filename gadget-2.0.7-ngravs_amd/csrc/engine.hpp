@@ -97,6 +97,7 @@ struct WalkParams
   int exp_tab;
   double inv_asmthfac;
   double ec[4];   // (ym / asmthfac)^k / k!, k = 1..4: the polynomial in the bin fraction
+  int src_in_box;   // every particle (and so every node centre of mass) lies inside [0, BoxSize]: groups away from the faces skip the image arithmetic
 
 };
 
@@ -175,6 +176,7 @@ struct ngravs_ctx
   bool have_particles = false, have_order = false, have_tree = false, have_pm = false, have_acc = false;
   bool pm_parked = false;     // pm_orig holds the caller's GravPM (handed over with ngravs_set_particles)
   double dom[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double pos_lo[3] = {0, 0, 0}, pos_hi[3] = {-1, -1, -1};   // extent of all positions the current decomposition saw (all tasks)
   int64_t shard_first = 0, shard_count = 0;
 
   // inputs (caller order)

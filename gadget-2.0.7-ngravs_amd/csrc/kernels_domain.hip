@@ -88,6 +88,8 @@ int dom_find_extent(ngravs_ctx *c)
   len *= 1.001;
   for(int j = 0; j < 3; j++)
     {
+      c->pos_lo[j] = lo[j];
+      c->pos_hi[j] = hi[j];
       c->dom[3 + j] = 0.5 * (lo[j] + hi[j]);
       c->dom[j] = 0.5 * (lo[j] + hi[j]) - 0.5 * len;
     }
@@ -489,6 +491,8 @@ void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
   len *= 1.001;
   for(int j = 0; j < 3; j++)
     {
+      c->pos_lo[j] = lo[j];
+      c->pos_hi[j] = hi[j];
       c->dom[3 + j] = 0.5 * (lo[j] + hi[j]);
       c->dom[j] = 0.5 * (lo[j] + hi[j]) - 0.5 * len;
     }

@@ -892,6 +892,20 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                                (int)(wp.periodic && PM && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 &&
                                      (wp.boxhalf - bhmax) > 0)) != 0;
       const bool lanewrap = wp.periodic && !prewrap;
+      // A pre-wrapped pool holds positions RELATIVE to the box centre (what the cull computes anyway; adding the centre back
+      // would cost 9 VALU per item and round once more), so the force loop subtracts the target's relative position.
+      const double tpx = prewrap ? px - bcx : px, tpy = prewrap ? py - bcy : py, tpz = prewrap ? pz - bcz : pz;
+      // (1) A group whose whole region [box - reach, box + reach] lies inside the periodic box needs no image arithmetic
+      // at all: with every source inside [0, L] (wp.src_in_box) a plain difference IS the nearest-image difference for
+      // everything within reach, and everything else fails the cull either way.
+      bool nowrap = !wp.periodic;
+      if(PM && wp.periodic && wp.src_in_box)
+        {
+          const double rl_ = __builtin_sqrt(wp.reach2);
+          nowrap = __builtin_amdgcn_readfirstlane((int)(bcx - bhx - rl_ >= 0.0 && bcx + bhx + rl_ <= wp.box && bcy - bhy - rl_ >= 0.0 &&
+                                                        bcy + bhy + rl_ <= wp.box && bcz - bhz - rl_ >= 0.0 &&
+                                                        bcz + bhz + rl_ <= wp.box)) != 0;
+        }
       // packed-fp32 reach pre-test (PM, no per-pair wrapping): positions relative to the box centre in fp32, threshold
       // widened by the worst-case rounding so that no true hit is lost; the force loop re-tests in fp64 (in[k])
       typedef float f2v __attribute__((ext_vector_type(2)));
@@ -938,9 +952,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
 #pragma unroll
         for(int k = 0; k < ES; k++)
           {
-            dx[k] = e[k].x - px;
-            dy[k] = e[k].y - py;
-            dz[k] = e[k].z - pz;
+            dx[k] = e[k].x - tpx;
+            dy[k] = e[k].y - tpy;
+            dz[k] = e[k].z - tpz;
             if(LW)
               {
                 dx[k] = nearest(dx[k], wp.box, wp.boxhalf);
@@ -1197,8 +1211,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           slot = slot >= nq ? slot - nq : slot;
         };
         auto fetch_rec = [&](bool hv, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
-          q.x = q.y = q.z = q.w = 0;
-          hs = 0;
+          // (without a record q and hs keep their previous contents: the consumer tests `have` first)
           if(hv)
             {
               const int k = -1 - item;   // monopole: node * NG + g
@@ -1231,7 +1244,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         fetch_quad(0, qd, nv);
         fetch_quad(1, qd_next, nv_next);
         double4 q1;
-        int hs1;
+        q1.x = q1.y = q1.z = q1.w = 0;
+        int hs1 = 0;
         bool have1 = nv > 0;
         fetch_rec(have1, qd.x, q1, hs1);
         double4 *pp = lpos;
@@ -1239,25 +1253,13 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         for(int cc = 0; cc <= nchunks; cc++)
           {
             const bool last = cc == nchunks;
-            const bool have = have1;
+            // The record of this chunk is consumed (culled, compacted into the pool) BEFORE the next one is requested into
+            // the same registers -- no copies -- and the request is in flight during the mask / force section below.
             double4 q = q1;
             const int hs = hs1;
-            {
-              // chunk cc+1: element (cc+1) & 3 of its quad
-              const int bn = (cc + 1) & 3;
-              if(bn == 0)
-                {
-                  qd = qd_next;
-                  nv = nv_next;
-                  fetch_quad((cc + 1) / 4 + 1, qd_next, nv_next);   // the quad after that one
-                }
-              const int itn = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
-              have1 = cc + 1 < nchunks && bn < nv;
-              fetch_rec(have1, itn, q1, hs1);
-            }
-            bool live = have && q.w != 0.0;
+            bool live = have1 && q.w != 0.0;
             double ex = q.x - bcx, ey = q.y - bcy, ez = q.z - bcz;
-            if(wp.periodic)
+            if(!nowrap)
               {
                 ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
                 ey = nearest_abs(ey, wp.box, invbox);   // a tie (|ey| = box/2) is far beyond any reach
@@ -1271,9 +1273,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               }
             if(prewrap)
               {
-                q.x = bcx + ex;
-                q.y = bcy + ey;
-                q.z = bcz + ez;
+                q.x = ex;
+                q.y = ey;
+                q.z = ez;
               }
             // compact the live entries behind the ones already waiting in the pool (capacity 2 x 64)
             const unsigned long long lm = __ballot(live ? 1 : 0);
@@ -1289,6 +1291,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 le2[o] = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
               }
             npool += __popcll(lm);
+            {
+              // chunk cc+1: element (cc+1) & 3 of its quad
+              const int bn = (cc + 1) & 3;
+              if(bn == 0)
+                {
+                  qd = qd_next;
+                  nv = nv_next;
+                  fetch_quad((cc + 1) / 4 + 1, qd_next, nv_next);   // the quad after that one
+                }
+              const int itn = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
+              have1 = cc + 1 < nchunks && bn < nv;
+              fetch_rec(have1, itn, q1, hs1);
+            }
             wave_sync();
             if(npool >= WAVE || (last && npool > 0))
               {
@@ -1345,7 +1360,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                             if(j < nc)
                               {
                                 const double4 e = pp[j];
-                                double dx = e.x - px, dy = e.y - py, dz = e.z - pz;
+                                double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
                                 if(lanewrap)
                                   {
                                     dx = nearest(dx, wp.box, wp.boxhalf);
@@ -1993,6 +2008,10 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
         wp->inv_asmthfac = 1.0 / wp->asmthfac;
         wp->exp_tab = (wp->ym * wp->inv_asmthfac < 1.0e-3) ? 1 : 0;   // u^5/120 < 1e-17
       }
+    wp->src_in_box = 1;
+    for(int j = 0; j < 3; j++)
+      if(!(c->pos_lo[j] >= 0.0 && c->pos_hi[j] <= cfg.box_size))
+        wp->src_in_box = 0;
     const double ub = wp->ym * wp->inv_asmthfac;   // exponent across one table bin
     wp->ec[0] = ub;
     wp->ec[1] = ub * ub / 2.0;
