@@ -908,7 +908,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         }
       // packed-fp32 reach pre-test (PM, no per-pair wrapping): positions relative to the box centre in fp32, threshold
       // widened by the worst-case rounding so that no true hit is lost; the force loop re-tests in fp64 (in[k])
-      typedef float f2v __attribute__((ext_vector_type(2)));
+      typedef float f16v __attribute__((ext_vector_type(16)));
       const bool fastmask = PM && !lanewrap;
       // r2 - thr = |e|^2 - 2 e.p + |p|^2 - thr with |e|^2 stored per pool entry: three packed FMAs per two entries.
       // Rounding: e and p are fp32 roundings of coordinates relative to the box centre (each component <= bhmax + reach), so
@@ -924,6 +924,28 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         cth = (float)((double)tfx * tfx + (double)tfy * tfy + (double)tfz * tfz - thr);
         cth = cth - 1.2e-7f * __builtin_fabsf(cth);   // the cast may have rounded up: one ulp down
       }
+      // The masks are a 64 x 64 x 4 matrix product on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+      //   D[entry][target] = |e|^2  +  (ex, ey, ez, 1) . (-2 tx, -2 ty, -2 tz, |t|^2 - thr),   hit <=> D < 0.
+      // Rows are pool entries, columns targets, one 32 x 32 tile per (entry block, target block), K = 4 as two instructions.
+      // B operand of lane l = B[k = l >> 5][column l & 31]: the target of column c of block tb is lane 32 tb + c, so every lane
+      // fetches the constants of that lane once per group; mB[tb][0] = (-2 tx | -2 ty), mB[tb][1] = (-2 tz | |t|^2 - thr).
+      float mB[2][2];
+      const int mh = lane >> 5;   // k index this lane supplies = half of the wave
+#pragma unroll
+      for(int tb = 0; tb < 2; tb++)
+        {
+          const int src = 32 * tb + (lane & 31);
+          const float x_ = __shfl(m2x, src), y_ = __shfl(m2y, src), z_ = __shfl(m2z, src), c_ = __shfl(cth, src);
+          mB[tb][0] = mh ? y_ : x_;
+          mB[tb][1] = mh ? c_ : z_;
+        }
+      // A operand of lane l = A[row l & 31][k = l >> 5].  Row i carries pool entry 32 eb + 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3):
+      // with that assignment accumulator register r of a lane holds entry 16 (l >> 5) + r of the block, i.e. its 16 sign bits
+      // are 16 consecutive mask bits and its C input |e|^2 is 16 consecutive floats.
+      const int mrow = 16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3);
+      const float *const mA0 = (mh ? lfy : lfx) + mrow;   // (ex | ey)
+      const float *const mA1 = lfz + mrow;                 // (ez | 1): the upper half is replaced by the constant
+      const float *const mC = le2 + 16 * mh;
 
       double ax = 0, ay = 0, az = 0;
       int nint = 0;
@@ -1317,26 +1339,41 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                   }
                 else if(fastmask && !wp.exact_reach)   // tuning "walk_exact_reach": use the exact fp64 test below instead (tests)
                   {
-                    // two entries per instruction (v_pk_add/fma_f32); the sign of r2 - threshold is shifted into the word
-                    // (v_alignbit), highest entry first so that entry j ends up in bit j
-                    const f2v p_x = {m2x, m2x}, p_y = {m2y, m2y}, p_z = {m2z, m2z}, c2 = {cth, cth};
+                    // one 32-entry block per mask word: two tiles (target blocks), each two chained MFMAs on the C input
+                    // |e|^2; the sign of every result is shifted into a 16-bit word (v_alignbit, highest register first), and one
+                    // v_permlane32_swap hands the words to the lanes that own the targets
 #pragma unroll
                     for(int w = 0; w < 2; w++)
                       {
-                        unsigned int word = 0;
+                        const float a0 = mA0[32 * w];
+                        const float a1r = mA1[32 * w];
+                        const float a1 = mh ? 1.0f : a1r;
+                        unsigned int wt[2];
 #pragma unroll
-                        for(int b = 15; b >= 0; b--)
+                        for(int tb = 0; tb < 2; tb++)
                           {
-                            const f2v e_x = *reinterpret_cast<const f2v *>(lfx + 32 * w + 2 * b);
-                            const f2v e_y = *reinterpret_cast<const f2v *>(lfy + 32 * w + 2 * b);
-                            const f2v e_z = *reinterpret_cast<const f2v *>(lfz + 32 * w + 2 * b);
-                            f2v r = *reinterpret_cast<const f2v *>(le2 + 32 * w + 2 * b) + c2;
-                            r = __builtin_elementwise_fma(e_x, p_x, r);
-                            r = __builtin_elementwise_fma(e_y, p_y, r);
-                            r = __builtin_elementwise_fma(e_z, p_z, r);
-                            word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.y), 31);
-                            word = __builtin_amdgcn_alignbit(word, __float_as_uint(r.x), 31);
+                            f16v acc;
+#pragma unroll
+                            for(int q = 0; q < 4; q++)
+                              {
+                                const float4 c4 = *reinterpret_cast<const float4 *>(mC + 32 * w + 4 * q);
+                                acc[4 * q + 0] = c4.x;
+                                acc[4 * q + 1] = c4.y;
+                                acc[4 * q + 2] = c4.z;
+                                acc[4 * q + 3] = c4.w;
+                              }
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, mB[tb][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mB[tb][1], acc, 0, 0, 0);
+                            unsigned int word = 0;
+#pragma unroll
+                            for(int r = 15; r >= 0; r--)
+                              word = __builtin_amdgcn_alignbit(word, __float_as_uint(acc[r]), 31);
+                            wt[tb] = word;
                           }
+                        // lanes 32-63 of wt[0] <-> lanes 0-31 of wt[1]: afterwards [0] = this lane's target against entries
+                        // 0-15 of the block, [1] = against entries 16-31
+                        const auto sw = __builtin_amdgcn_permlane32_swap(wt[0], wt[1], false, false);
+                        const unsigned int word = sw[0] | (sw[1] << 16);
                         if(w == 0)
                           mlo = word;
                         else
