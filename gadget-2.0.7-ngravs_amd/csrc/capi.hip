@@ -352,6 +352,7 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->n_mom.release();
   c->n_npart.release();
   c->scan_out.release();
+  c->tb_count.release();
   c->scan_tmp.release();
   c->d_counters.release();
   c->d_levels.release();
@@ -455,6 +456,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.pm_fused_gather = iv != 0;
   else if(k == "pm_tile_gather")
     t.pm_tile_gather = iv != 0;
+  else if(k == "tree_levelwise")
+    t.tree_levelwise = iv != 0;
   else
     {
       ngravs_report(c, NGRAVS_ERR_ARG, "ngravs_set_tuning: unknown name or value out of range: " + k);

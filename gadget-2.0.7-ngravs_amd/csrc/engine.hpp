@@ -119,6 +119,7 @@ struct Tuning
   int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0, walk_sg = 0, walk_nleaf = -1;
   long long walk_batch = 0;
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0;
+  int tree_levelwise = 0;   // build the tree level by level (the multi-task path) also for single-task trees
 };
 
 // The global top of the tree for multi-task runs (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996,
@@ -210,6 +211,7 @@ struct ngravs_ctx
   int64_t level_start[MAX_LEVELS + 2];
   DevBuf<int> n_first, n_count, n_child, n_flags, n_nchild;
   DevBuf<double4> n_geo, n_mom;
+  DevBuf<int> tb_count;   // one-pass build: per-level node counts of every block of particles
   DevBuf<int> n_npart;        // [nodes][NG] particle counts per species (BAM wirings only)
   DevBuf<int> scan_out;
   DevBuf<unsigned char> scan_tmp;
@@ -273,7 +275,7 @@ int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
 // ---- kernels_tree.hip
 int tree_build(ngravs_ctx *c);
-int tree_moments(ngravs_ctx *c, bool refit);
+int tree_moments(ngravs_ctx *c, bool refit, bool counts = false);
 int dom_regather(ngravs_ctx *c);
 static inline bool cfg_has_bam(const ngravs_config_t &cfg)
 {

@@ -251,6 +251,251 @@ __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, i
     }
 }
 
+
+// =============================================================================================
+//  One-pass build (single-task trees).  In the key-sorted array two neighbours i, i+1 share their first d_i key digits; a cell
+//  of level l is a node iff it holds at least two particles, i.e. iff it contains a neighbouring pair with d >= l.  Hence
+//  particle i is the FIRST particle of exactly the nodes of levels (d_{i-1}, d_i] (a chain when that interval holds more than
+//  one level), every node is started by exactly one particle, and the level-contiguous node numbering of the level-by-level
+//  build above (nodes of a level in the order of their ranges) is  level_start[l] + #{starts of level l before i}.  So the whole
+//  topology follows from ONE pass over the keys plus per-level prefix counts -- 5 launches instead of 63:
+//    k_tb_count   per block of 256 particles, the number of nodes each level gets from it (22 packed counters)
+//    k_tb_scan    exclusive scan over the blocks, one workgroup per level
+//    k_tb_levels  level table (first node, count) and the out-of-nodes check
+//    k_tb_fill    empty child slots of all nodes
+//    k_tb_nodes   every particle writes the nodes it starts (first particle, cell from the reference's centre recurrence
+//                 replayed from the root, flags), hooks each into its parent's child slot, and hooks itself as a particle
+//                 leaf into the deepest node that contains it.
+//  The parent of a node of level l started at i is the level-(l-1) node containing i: the one i itself starts, or -- when
+//  l - 1 = d_{i-1} -- the last level-(l-1) node started before i.  Particle counts of the nodes come from the moments pass
+//  (children's counts + particle leaves); buckets (level TREE_BITS: identical keys) count their run of equal keys here.
+// =============================================================================================
+#define TBN 256
+struct LvPack
+{
+  unsigned long long w[4];   // level l: bits [10 (l % 6), 10 (l % 6) + 10) of word l / 6 (at most 256 starts per block and level)
+};
+__device__ __forceinline__ int common_digits(unsigned long long a, unsigned long long b)
+{
+  const unsigned long long x = a ^ b;
+  if(x == 0)
+    return TREE_BITS;
+  return (__clzll((long long)x) - (64 - 3 * TREE_BITS)) / 3;
+}
+__device__ __forceinline__ void tb_neighbours(const unsigned long long *__restrict__ key, long long n, long long i, unsigned long long &k,
+                                              int &dprev, int &dcur)
+{
+  k = key[i];
+  dprev = i > 0 ? common_digits(key[i - 1], k) : -1;
+  dcur = i + 1 < n ? common_digits(k, key[i + 1]) : -1;
+}
+__device__ __forceinline__ LvPack tb_starts(int dprev, int dcur)
+{
+  LvPack v;
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    v.w[q] = 0;
+  for(int l = dprev + 1; l <= dcur; l++)
+    {
+      const unsigned long long one = 1ull << (10 * (l % 6));
+#pragma unroll
+      for(int q = 0; q < 4; q++)
+        v.w[q] += (l / 6 == q) ? one : 0ull;
+    }
+  return v;
+}
+__device__ __forceinline__ int tb_field(const LvPack &v, int l)
+{
+  const int q = l / 6;
+  const unsigned long long w = q == 0 ? v.w[0] : (q == 1 ? v.w[1] : (q == 2 ? v.w[2] : v.w[3]));
+  return (int)((w >> (10 * (l % 6))) & 1023ull);
+}
+
+__global__ __launch_bounds__(TBN) void k_tb_count(const unsigned long long *__restrict__ key, long long n, int *__restrict__ bcount, int nblk)
+{
+  __shared__ LvPack wsum[TBN / 64];
+  const long long i = (long long)blockIdx.x * TBN + threadIdx.x;
+  LvPack v;
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    v.w[q] = 0;
+  if(i < n)
+    {
+      unsigned long long k;
+      int dprev, dcur;
+      tb_neighbours(key, n, i, k, dprev, dcur);
+      v = tb_starts(dprev, dcur);
+    }
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    for(int off = 32; off > 0; off >>= 1)
+      v.w[q] += __shfl_xor(v.w[q], off);
+  if((threadIdx.x & 63) == 0)
+    wsum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if(threadIdx.x <= TREE_BITS)
+    {
+      int tot = 0;
+      for(int w = 0; w < TBN / 64; w++)
+        tot += tb_field(wsum[w], threadIdx.x);
+      bcount[(size_t)threadIdx.x * nblk + blockIdx.x] = tot;
+    }
+}
+
+// one workgroup per level: exclusive scan of the level's block counts in place, total to lvcnt[level]
+__global__ __launch_bounds__(1024) void k_tb_scan(int *__restrict__ bcount, int nblk, int *__restrict__ lvcnt)
+{
+  __shared__ int part[1024];
+  int *row = bcount + (size_t)blockIdx.x * nblk;
+  const int per = (nblk + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = lo + per < nblk ? lo + per : nblk;
+  int s = 0;
+  for(int i = lo; i < hi; i++)
+    s += row[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for(int off = 1; off < 1024; off <<= 1)
+    {
+      const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for(int i = lo; i < hi; i++)
+    {
+      const int v = row[i];
+      row[i] = run;
+      run += v;
+    }
+  if(threadIdx.x == 0)
+    lvcnt[blockIdx.x] = part[1023];
+}
+
+__global__ void k_tb_levels(const int *__restrict__ lvcnt, int *__restrict__ lv, int maxn)
+{
+  if(threadIdx.x != 0 || blockIdx.x != 0)
+    return;
+  long long run = 0;
+  bool bad = false;
+  for(int l = 0; l <= TREE_BITS; l++)
+    run += lvcnt[l];
+  if(run > (long long)maxn)
+    bad = true;   // maximum number of tree nodes reached (forcetree.c:247)
+  run = 0;
+  for(int l = 0; l <= MAX_LEVELS + 1; l++)
+    {
+      const int cnt = (!bad && l <= TREE_BITS) ? lvcnt[l] : 0;
+      lv[2 * l] = (int)run;
+      lv[2 * l + 1] = cnt;
+      run += cnt;
+    }
+  lv[2 * (MAX_LEVELS + 2)] = bad ? 1 : 0;
+}
+
+__global__ void k_tb_fill(int4 *__restrict__ n_child4, const int *__restrict__ lv)
+{
+  const long long total = (long long)lv[2 * (TREE_BITS + 1)];   // first node beyond the last level = number of nodes
+  const int4 e = {-1, -1, -1, -1};
+  for(long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < 2 * total; t += (long long)gridDim.x * blockDim.x)
+    n_child4[t] = e;
+}
+
+__global__ __launch_bounds__(TBN) void k_tb_nodes(const unsigned long long *__restrict__ key, const double4 *__restrict__ s_pm, long long n,
+                                                  const int *__restrict__ bbase, int nblk, const int *__restrict__ lv,
+                                                  int *__restrict__ n_first, int *__restrict__ n_count, int *__restrict__ n_child,
+                                                  double4 *__restrict__ n_geo, int *__restrict__ n_flags, double4 root, double cx,
+                                                  double cy, double cz, double fac21)
+{
+  __shared__ LvPack wsum[TBN / 64];
+  __shared__ int base[TREE_BITS + 1];   // index of the first node this block starts, per level
+  if(lv[2 * (MAX_LEVELS + 2)])
+    return;
+  if(threadIdx.x <= TREE_BITS)
+    base[threadIdx.x] = lv[2 * threadIdx.x] + bbase[(size_t)threadIdx.x * nblk + blockIdx.x];
+  const long long i = (long long)blockIdx.x * TBN + threadIdx.x;
+  unsigned long long k = 0;
+  int dprev = -1, dcur = -1;
+  LvPack mine;
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    mine.w[q] = 0;
+  if(i < n)
+    {
+      tb_neighbours(key, n, i, k, dprev, dcur);
+      mine = tb_starts(dprev, dcur);
+    }
+  // exclusive block scan of the packed per-level start counts
+  LvPack inc = mine;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    for(int off = 1; off < 64; off <<= 1)
+      {
+        const unsigned long long y = __shfl_up(inc.w[q], off);
+        inc.w[q] += lane >= off ? y : 0ull;
+      }
+  if(lane == 63)
+    wsum[wave] = inc;
+  __syncthreads();
+  LvPack exc;
+#pragma unroll
+  for(int q = 0; q < 4; q++)
+    {
+      unsigned long long p = 0;
+      for(int w = 0; w < TBN / 64; w++)
+        p += w < wave ? wsum[w].w[q] : 0ull;
+      exc.w[q] = inc.w[q] - mine.w[q] + p;
+    }
+  if(i >= n)
+    return;
+  const int dtop = dprev > dcur ? dprev : dcur;   // level of the deepest node that contains this particle (>= 0 for n >= 2)
+  // the last node of level dprev started before this particle: it contains the pair (i - 1, i)
+  const int anc = dprev >= 0 ? base[dprev] + tb_field(exc, dprev) - 1 : -1;
+  int leaf_parent = anc;
+  if(dcur > dprev)
+    {
+      const double4 p = s_pm[i];
+      const int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
+      const int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
+      const int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
+      double4 g = root;
+      int parent = anc;
+      for(int l = 0; l <= dcur; l++)
+        {
+          if(l > 0)
+            {
+              // centre recurrence of forcetree.c:190-206 (centre +- 0.25 * len of the parent), replayed from the root
+              const int sh = TREE_BITS - l;
+              const double q = 0.25 * g.w;
+              g.x = ((ix >> sh) & 1) ? g.x + q : g.x - q;
+              g.y = ((iy >> sh) & 1) ? g.y + q : g.y - q;
+              g.z = ((iz >> sh) & 1) ? g.z + q : g.z - q;
+              g.w = 0.5 * g.w;
+            }
+          if(l <= dprev)
+            continue;
+          const int idx = base[l] + tb_field(exc, l);
+          n_first[idx] = (int)i;
+          n_geo[idx] = g;
+          n_flags[idx] = l >= TREE_BITS ? FLAG_BUCKET : 0;
+          if(l >= TREE_BITS)
+            {
+              int c = 1;
+              while(i + c < n && key[i + c] == k)
+                c++;
+              n_count[idx] = c;
+            }
+          if(l > 0)
+            n_child[8 * (long long)parent + key_digit(k, l - 1)] = idx;
+          parent = idx;
+        }
+      leaf_parent = parent;
+    }
+  if(dtop < TREE_BITS)   // members of a bucket are reached through its range
+    n_child[8 * (long long)leaf_parent + key_digit(k, dtop)] = -2 - (int)i;
+}
+
 struct SoftAcc
 {
   int maxsofttype, diff;
@@ -278,7 +523,8 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
                           const int *__restrict__ n_first, const int *__restrict__ n_count,
                           const int *__restrict__ n_child, const double4 *__restrict__ n_geo,
                           double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level,
-                          WalkParams wp, double4 *__restrict__ geo_rw = nullptr, int *__restrict__ n_npart = nullptr)
+                          WalkParams wp, double4 *__restrict__ geo_rw = nullptr, int *__restrict__ n_npart = nullptr,
+                          int *__restrict__ n_count_rw = nullptr)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
@@ -295,6 +541,7 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
   SoftAcc sa;
   sa.maxsofttype = 7;
   sa.diff = 0;
+  int cnt_acc = 0;   // particles below this node (one-pass build: the counts are not known before this pass)
   int fl = n_flags[node];
   // refit of a drifted tree (geo_rw != 0): the node keeps its centre but its side grows to enclose whatever its particles
   // and (already grown) child cells now reach, the role of force_update_len() (forcetree.c:1005-1122)
@@ -317,6 +564,7 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
           sz[g] += v.w * v.z;
         }
     soft_merge(sa, ty, 0, wp.fsoft);
+    cnt_acc++;
   };
   if(fl & FLAG_BUCKET)
     {
@@ -348,6 +596,8 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
                 }
               int cf = n_flags[c];
               soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
+              if(n_count_rw)
+                cnt_acc += n_count_rw[c];
               if(geo_rw)
                 {
                   const double4 cg = n_geo[c];
@@ -384,6 +634,8 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
         n_npart[(long long)node * NG + g] = np[g];
     }
   n_flags[node] = (fl & (FLAG_BUCKET | FLAG_PSEUDO | FLAG_PARTIAL)) | (4 * sa.maxsofttype + 32 * sa.diff);
+  if(n_count_rw && !(fl & FLAG_BUCKET))
+    n_count_rw[node] = cnt_acc;
 }
 
 // Global top of a multi-task tree: monopoles and softening flags of the nodes of one top level from the all-reduced cell sums
@@ -467,7 +719,7 @@ static int tree_top_moments(ngravs_ctx *c)
 }
 
 // multipole moments, softening flags (and, for a refit, grown cell sides) of all nodes, bottom-up, one launch per level
-int tree_moments(ngravs_ctx *c, bool refit)
+int tree_moments(ngravs_ctx *c, bool refit, bool counts)
 {
   const int ng = c->cfg.n_gravs;
   const int bs = 128;
@@ -481,6 +733,7 @@ int tree_moments(ngravs_ctx *c, bool refit)
     }
   WalkParams wp;
   make_walk_params(c, &wp);
+  int *cntp = counts ? c->n_count.p : nullptr;
   for(int l = c->nlevels - 1; l >= 0; l--)
     {
       long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
@@ -491,15 +744,15 @@ int tree_moments(ngravs_ctx *c, bool refit)
         {
         case 1:
           hipLaunchKernelGGL(k_moments<1>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
           break;
         case 2:
           hipLaunchKernelGGL(k_moments<2>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
           break;
         default:
           hipLaunchKernelGGL(k_moments<3>, dim3(nb), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p,
-                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp);
+                             c->n_count.p, c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
           break;
         }
     }
@@ -551,10 +804,31 @@ int tree_build(ngravs_ctx *c)
   int h_lv[2 * (MAX_LEVELS + 2) + 2];
   memset(h_lv, 0, sizeof(h_lv));
   h_lv[1] = 1;   // the root
-  HIP_TRY(c, hipMemcpyAsync(c->d_levels.p, h_lv, sizeof(int) * LVN, hipMemcpyHostToDevice, c->stream));
+  const bool onepass = top.level == 0 && n >= 2 && !c->tune.tree_levelwise;
+  if(onepass)
+    {
+      // the whole topology from one pass over the sorted keys (see k_tb_nodes)
+      const int nblk = (int)((n + TBN - 1) / TBN);
+      if(c->tb_count.ensure((size_t)(TREE_BITS + 1) * nblk + 64))
+        return NGRAVS_ERR_NOMEM;
+      int *lvcnt = c->tb_count.p + (size_t)(TREE_BITS + 1) * nblk;
+      hipLaunchKernelGGL(k_tb_count, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, n, c->tb_count.p, nblk);
+      hipLaunchKernelGGL(k_tb_scan, dim3(TREE_BITS + 1), dim3(1024), 0, c->stream, c->tb_count.p, nblk, lvcnt);
+      hipLaunchKernelGGL(k_tb_levels, dim3(1), dim3(64), 0, c->stream, lvcnt, c->d_levels.p, (int)(maxn > 2147483647ll ? 2147483647ll : maxn));
+      {
+        long long guess = c->nnodes > 0 ? c->nnodes + c->nnodes / 8 : n / 2;
+        unsigned nbf = (unsigned)((2 * guess + 255) / 256);
+        nbf = nbf < 1 ? 1 : (nbf > 262144u ? 262144u : nbf);
+        hipLaunchKernelGGL(k_tb_fill, dim3(nbf), dim3(256), 0, c->stream, reinterpret_cast<int4 *>(c->n_child.p), c->d_levels.p);
+      }
+      hipLaunchKernelGGL(k_tb_nodes, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, c->s_pm.p, n, c->tb_count.p, nblk, c->d_levels.p,
+                         c->n_first.p, c->n_count.p, c->n_child.p, c->n_geo.p, c->n_flags.p, h_geo, c->dom[0], c->dom[1], c->dom[2], fac21);
+    }
+  else
+    HIP_TRY(c, hipMemcpyAsync(c->d_levels.p, h_lv, sizeof(int) * LVN, hipMemcpyHostToDevice, c->stream));
   // No host round trip between levels: every level's launches are issued blindly, with grids sized from the level populations of
   // the previous build (any grid is correct: the kernels loop over virtual blocks); levels beyond the deepest find count 0.
-  for(int level = 0; level < TREE_BITS; level++)
+  for(int level = 0; level < TREE_BITS && !onepass; level++)
     {
       long long guess = c->level_hint[level] > 0 ? c->level_hint[level] + c->level_hint[level] / 8 : ((level < 8) ? (1ll << (3 * level)) : (n + 1) / 2);
       if(guess > (n + 1) / 2 + 1 && level > 0 && top.level == 0)
@@ -591,7 +865,7 @@ int tree_build(ngravs_ctx *c)
   c->nnodes = (long long)h_lv[2 * (nl - 1)] + h_lv[2 * (nl - 1) + 1];
   for(int l = nl; l <= MAX_LEVELS + 1; l++)
     c->level_start[l] = c->nnodes;
-  int rcm = tree_moments(c, false);
+  int rcm = tree_moments(c, false, onepass);
   if(rcm)
     return rcm;
   HIP_TRY(c, hipGetLastError());

@@ -411,6 +411,42 @@ def test_inactive_particles_and_buckets(pkg, O):
         eng.close()
 
 
+def test_one_pass_build_is_the_levelwise_tree(pkg, O):
+    """The one-pass build (every particle starts the nodes of levels (d_prev, d_cur]) and the level-by-level build (the
+    multi-task path) give the SAME tree: same node count, and the reference walk on them returns bitwise equal accelerations
+    and equal interaction counts -- clustered, uniform, coincident particles (buckets), two species."""
+    rng = np.random.default_rng(2024)
+    cases = []
+    pos, _, _ = pkg.ic.plummer_sphere(30000, seed=5)
+    cases.append((pos, np.ones(30000, dtype=np.int32)))
+    pos = rng.uniform(0, 1, (20000, 3))
+    pos[500:520] = pos[500]                       # a bucket of 20
+    pos[7000:7003] = pos[7000]
+    cases.append((pos, (1 + (np.arange(20000) % 2)).astype(np.int32)))
+    pos = rng.uniform(0, 1, (2, 3))
+    cases.append((pos, np.ones(2, dtype=np.int32)))
+    for pos, typ in cases:
+        n = len(pos)
+        mass = rng.uniform(0.5, 1.5, n) / n
+        ng = 2 if typ.max() > 1 else 1
+        kw = dict(n_gravs=ng, G=1.0, theta=0.5, softening=[0.005] * 6, tree_alloc_factor=2.5)
+        if ng == 2:
+            kw.update(type_to_grav=[0, 0, 1, 1, 1, 1], wiring="coloyuk", yukawa_imass=3.0, box_size=1.0)
+        cfg = pkg.make_config(**kw)
+        cfg.walk_mode = pkg.WALK_STRICT
+        res = []
+        for levelwise in (0, 1):
+            eng = _engine(pkg, cfg, pos, mass, typ, tuning=dict(tree_levelwise=levelwise))
+            eng.compute_accelerations(pm_step=False)
+            acc, old, cost = eng.get_accel()
+            res.append((acc.copy(), cost.copy(), eng.stats().n_nodes))
+            eng.close()
+        assert res[0][2] == res[1][2] and res[0][2] >= 1
+        assert np.array_equal(res[0][1], res[1][1])
+        assert np.array_equal(res[0][0], res[1][0])
+        print("one-pass == level-wise: n=%d, %d nodes" % (n, res[0][2]))
+
+
 def test_grav_pm_handed_over_with_the_particles(pkg, O):
     """A PM step followed by a non-PM step that goes through set_particles again (TreeDomainUpdateFrequency = 0: the glue
     re-decomposes every step).  P[].GravPM lives in the host's P[] between PM steps; handed over with the particles it must
