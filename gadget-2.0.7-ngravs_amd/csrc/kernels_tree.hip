@@ -270,11 +270,8 @@ __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, i
 //  l - 1 = d_{i-1} -- the last level-(l-1) node started before i.  Particle counts of the nodes come from the moments pass
 //  (children's counts + particle leaves); buckets (level TREE_BITS: identical keys) count their run of equal keys here.
 // =============================================================================================
-#define TBN 256
-struct LvPack
-{
-  unsigned long long w[4];   // level l: bits [10 (l % 6), 10 (l % 6) + 10) of word l / 6 (at most 256 starts per block and level)
-};
+#define TBN 256   // threads per block of the one-pass kernels
+#define TBCH 8    // chunks of TBN consecutive particles per block
 __device__ __forceinline__ int common_digits(unsigned long long a, unsigned long long b)
 {
   const unsigned long long x = a ^ b;
@@ -285,91 +282,93 @@ __device__ __forceinline__ int common_digits(unsigned long long a, unsigned long
 __device__ __forceinline__ void tb_neighbours(const unsigned long long *__restrict__ key, long long n, long long i, unsigned long long &k,
                                               int &dprev, int &dcur)
 {
-  k = key[i];
-  dprev = i > 0 ? common_digits(key[i - 1], k) : -1;
-  dcur = i + 1 < n ? common_digits(k, key[i + 1]) : -1;
-}
-__device__ __forceinline__ LvPack tb_starts(int dprev, int dcur)
-{
-  LvPack v;
-#pragma unroll
-  for(int q = 0; q < 4; q++)
-    v.w[q] = 0;
-  for(int l = dprev + 1; l <= dcur; l++)
-    {
-      const unsigned long long one = 1ull << (10 * (l % 6));
-#pragma unroll
-      for(int q = 0; q < 4; q++)
-        v.w[q] += (l / 6 == q) ? one : 0ull;
-    }
-  return v;
-}
-__device__ __forceinline__ int tb_field(const LvPack &v, int l)
-{
-  const int q = l / 6;
-  const unsigned long long w = q == 0 ? v.w[0] : (q == 1 ? v.w[1] : (q == 2 ? v.w[2] : v.w[3]));
-  return (int)((w >> (10 * (l % 6))) & 1023ull);
-}
-
-__global__ __launch_bounds__(TBN) void k_tb_count(const unsigned long long *__restrict__ key, long long n, int *__restrict__ bcount, int nblk)
-{
-  __shared__ LvPack wsum[TBN / 64];
-  const long long i = (long long)blockIdx.x * TBN + threadIdx.x;
-  LvPack v;
-#pragma unroll
-  for(int q = 0; q < 4; q++)
-    v.w[q] = 0;
+  k = 0;
+  dprev = dcur = -1;   // beyond the end: starts nothing
   if(i < n)
     {
+      k = key[i];
+      dprev = i > 0 ? common_digits(key[i - 1], k) : -1;
+      dcur = i + 1 < n ? common_digits(k, key[i + 1]) : -1;
+    }
+}
+__device__ __forceinline__ int wave_imin(int v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      const int o = __shfl_xor(v, off);
+      v = o < v ? o : v;
+    }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_imax(int v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      const int o = __shfl_xor(v, off);
+      v = o > v ? o : v;
+    }
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+// per block (TBCH x TBN consecutive particles): how many nodes every level gets from it.  Which lanes start a node of level l
+// is one ballot, the count its population count -- no per-lane counters.
+__global__ __launch_bounds__(TBN) void k_tb_count(const unsigned long long *__restrict__ key, long long n, int *__restrict__ bcount, int nblk_pad)
+{
+  __shared__ int tot[TREE_BITS + 1];
+  if(threadIdx.x <= TREE_BITS)
+    tot[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for(int ch = 0; ch < TBCH; ch++)
+    {
+      const long long i = ((long long)blockIdx.x * TBCH + ch) * TBN + threadIdx.x;
       unsigned long long k;
       int dprev, dcur;
       tb_neighbours(key, n, i, k, dprev, dcur);
-      v = tb_starts(dprev, dcur);
+      const int l0 = wave_imin(dprev) + 1, l1 = wave_imax(dcur);
+      for(int l = l0; l <= l1; l++)
+        {
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(dprev < l && l <= dcur);
+          if(lane == 0 && m)
+            atomicAdd(&tot[l], __popcll(m));
+        }
     }
-#pragma unroll
-  for(int q = 0; q < 4; q++)
-    for(int off = 32; off > 0; off >>= 1)
-      v.w[q] += __shfl_xor(v.w[q], off);
-  if((threadIdx.x & 63) == 0)
-    wsum[threadIdx.x >> 6] = v;
   __syncthreads();
   if(threadIdx.x <= TREE_BITS)
-    {
-      int tot = 0;
-      for(int w = 0; w < TBN / 64; w++)
-        tot += tb_field(wsum[w], threadIdx.x);
-      bcount[(size_t)threadIdx.x * nblk + blockIdx.x] = tot;
-    }
+    bcount[(size_t)threadIdx.x * nblk_pad + blockIdx.x] = tot[threadIdx.x];
 }
 
-// one workgroup per level: exclusive scan of the level's block counts in place, total to lvcnt[level]
-__global__ __launch_bounds__(1024) void k_tb_scan(int *__restrict__ bcount, int nblk, int *__restrict__ lvcnt)
+// one workgroup per level: exclusive scan of the level's block counts in place (tiles of 4096, coalesced), total to lvcnt[level]
+__global__ __launch_bounds__(1024) void k_tb_scan(int *__restrict__ bcount, int nblk_pad, int *__restrict__ lvcnt)
 {
-  __shared__ int part[1024];
-  int *row = bcount + (size_t)blockIdx.x * nblk;
-  const int per = (nblk + 1023) / 1024;
-  const int lo = threadIdx.x * per, hi = lo + per < nblk ? lo + per : nblk;
-  int s = 0;
-  for(int i = lo; i < hi; i++)
-    s += row[i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  for(int off = 1; off < 1024; off <<= 1)
+  typedef hipcub::BlockScan<int, 1024> BlockScan;
+  __shared__ typename BlockScan::TempStorage tmp;
+  int4 *row = reinterpret_cast<int4 *>(bcount + (size_t)blockIdx.x * nblk_pad);
+  const int nq = nblk_pad / 4;
+  int carry = 0;
+  for(int t0 = 0; t0 < nq; t0 += 1024)
     {
-      const int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      const int q = t0 + threadIdx.x;
+      int4 v = {0, 0, 0, 0};
+      if(q < nq)
+        v = row[q];
+      const int s = v.x + v.y + v.z + v.w;
+      int ex, total;
+      BlockScan(tmp).ExclusiveSum(s, ex, total);
       __syncthreads();
-      part[threadIdx.x] += v;
-      __syncthreads();
-    }
-  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-  for(int i = lo; i < hi; i++)
-    {
-      const int v = row[i];
-      row[i] = run;
-      run += v;
+      if(q < nq)
+        {
+          int4 o;
+          o.x = carry + ex;
+          o.y = o.x + v.x;
+          o.z = o.y + v.y;
+          o.w = o.z + v.z;
+          row[q] = o;
+        }
+      carry += total;
     }
   if(threadIdx.x == 0)
-    lvcnt[blockIdx.x] = part[1023];
+    lvcnt[blockIdx.x] = carry;
 }
 
 __global__ void k_tb_levels(const int *__restrict__ lvcnt, int *__restrict__ lv, int maxn)
@@ -402,98 +401,108 @@ __global__ void k_tb_fill(int4 *__restrict__ n_child4, const int *__restrict__ l
 }
 
 __global__ __launch_bounds__(TBN) void k_tb_nodes(const unsigned long long *__restrict__ key, const double4 *__restrict__ s_pm, long long n,
-                                                  const int *__restrict__ bbase, int nblk, const int *__restrict__ lv,
+                                                  const int *__restrict__ bbase, int nblk_pad, const int *__restrict__ lv,
                                                   int *__restrict__ n_first, int *__restrict__ n_count, int *__restrict__ n_child,
                                                   double4 *__restrict__ n_geo, int *__restrict__ n_flags, double4 root, double cx,
                                                   double cy, double cz, double fac21)
 {
-  __shared__ LvPack wsum[TBN / 64];
-  __shared__ int base[TREE_BITS + 1];   // index of the first node this block starts, per level
+  __shared__ int base[TREE_BITS + 1];              // index of the next node of every level (running over the chunks)
+  __shared__ int wtot[TBN / 64][TREE_BITS + 1];    // starts per wave and level, current chunk
   if(lv[2 * (MAX_LEVELS + 2)])
     return;
   if(threadIdx.x <= TREE_BITS)
-    base[threadIdx.x] = lv[2 * threadIdx.x] + bbase[(size_t)threadIdx.x * nblk + blockIdx.x];
-  const long long i = (long long)blockIdx.x * TBN + threadIdx.x;
-  unsigned long long k = 0;
-  int dprev = -1, dcur = -1;
-  LvPack mine;
-#pragma unroll
-  for(int q = 0; q < 4; q++)
-    mine.w[q] = 0;
-  if(i < n)
-    {
-      tb_neighbours(key, n, i, k, dprev, dcur);
-      mine = tb_starts(dprev, dcur);
-    }
-  // exclusive block scan of the packed per-level start counts
-  LvPack inc = mine;
+    base[threadIdx.x] = lv[2 * threadIdx.x] + bbase[(size_t)threadIdx.x * nblk_pad + blockIdx.x];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for(int q = 0; q < 4; q++)
-    for(int off = 1; off < 64; off <<= 1)
-      {
-        const unsigned long long y = __shfl_up(inc.w[q], off);
-        inc.w[q] += lane >= off ? y : 0ull;
-      }
-  if(lane == 63)
-    wsum[wave] = inc;
-  __syncthreads();
-  LvPack exc;
-#pragma unroll
-  for(int q = 0; q < 4; q++)
+  for(int ch = 0; ch < TBCH; ch++)
     {
-      unsigned long long p = 0;
-      for(int w = 0; w < TBN / 64; w++)
-        p += w < wave ? wsum[w].w[q] : 0ull;
-      exc.w[q] = inc.w[q] - mine.w[q] + p;
-    }
-  if(i >= n)
-    return;
-  const int dtop = dprev > dcur ? dprev : dcur;   // level of the deepest node that contains this particle (>= 0 for n >= 2)
-  // the last node of level dprev started before this particle: it contains the pair (i - 1, i)
-  const int anc = dprev >= 0 ? base[dprev] + tb_field(exc, dprev) - 1 : -1;
-  int leaf_parent = anc;
-  if(dcur > dprev)
-    {
-      const double4 p = s_pm[i];
-      const int ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
-      const int iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
-      const int iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
-      double4 g = root;
-      int parent = anc;
-      for(int l = 0; l <= dcur; l++)
+      const long long i = ((long long)blockIdx.x * TBCH + ch) * TBN + threadIdx.x;
+      unsigned long long k;
+      int dprev, dcur;
+      tb_neighbours(key, n, i, k, dprev, dcur);
+      const bool starter = dcur > dprev;
+      // the levels this wave touches: ancestors at level dprev, starts in (dprev, dcur]
+      const int l0 = wave_imin(dprev < 0 ? 0 : dprev), l1 = wave_imax(dcur > dprev ? dcur : dprev);
+      if(lane <= TREE_BITS)
+        wtot[wave][lane] = 0;
+      for(int l = l0; l <= l1; l++)
         {
-          if(l > 0)
-            {
-              // centre recurrence of forcetree.c:190-206 (centre +- 0.25 * len of the parent), replayed from the root
-              const int sh = TREE_BITS - l;
-              const double q = 0.25 * g.w;
-              g.x = ((ix >> sh) & 1) ? g.x + q : g.x - q;
-              g.y = ((iy >> sh) & 1) ? g.y + q : g.y - q;
-              g.z = ((iz >> sh) & 1) ? g.z + q : g.z - q;
-              g.w = 0.5 * g.w;
-            }
-          if(l <= dprev)
-            continue;
-          const int idx = base[l] + tb_field(exc, l);
-          n_first[idx] = (int)i;
-          n_geo[idx] = g;
-          n_flags[idx] = l >= TREE_BITS ? FLAG_BUCKET : 0;
-          if(l >= TREE_BITS)
-            {
-              int c = 1;
-              while(i + c < n && key[i + c] == k)
-                c++;
-              n_count[idx] = c;
-            }
-          if(l > 0)
-            n_child[8 * (long long)parent + key_digit(k, l - 1)] = idx;
-          parent = idx;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(dprev < l && l <= dcur);
+          if(lane == 0)
+            wtot[wave][l] = __popcll(m);
         }
-      leaf_parent = parent;
+      __syncthreads();   // wtot of all waves, and base[] of this chunk
+      int ix = 0, iy = 0, iz = 0;
+      if(starter)
+        {
+          const double4 p = s_pm[i];
+          ix = (int)__dmul_rn(__dsub_rn(p.x, cx), fac21);
+          iy = (int)__dmul_rn(__dsub_rn(p.y, cy), fac21);
+          iz = (int)__dmul_rn(__dsub_rn(p.z, cz), fac21);
+        }
+      // centre recurrence of forcetree.c:190-206 (centre +- 0.25 * len of the parent), replayed from the root: every lane
+      // follows the cells of its own particle, one level per step
+      double4 g = root;
+      auto step = [&](int l) {
+        const int sh = TREE_BITS - l;
+        const double q = 0.25 * g.w;
+        g.x = ((ix >> sh) & 1) ? g.x + q : g.x - q;
+        g.y = ((iy >> sh) & 1) ? g.y + q : g.y - q;
+        g.z = ((iz >> sh) & 1) ? g.z + q : g.z - q;
+        g.w = 0.5 * g.w;
+      };
+      for(int l = 1; l < l0; l++)
+        step(l);
+      int anc = -1;      // the last node of level dprev started before this particle: it holds the pair (i - 1, i)
+      int parent = -1;
+      for(int l = l0; l <= l1; l++)
+        {
+          if(l > 0 && l >= l0)
+            {
+              if(l > 0)
+                step(l);
+            }
+          const bool st = dprev < l && l <= dcur;
+          const unsigned long long m = __builtin_amdgcn_ballot_w64(st);
+          int wb = base[l];
+          for(int w = 0; w < TBN / 64; w++)
+            wb += w < wave ? wtot[w][l] : 0;
+          const int rank = wb + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+          if(l == dprev)
+            {
+              anc = rank - 1;
+              parent = anc;
+            }
+          if(st)
+            {
+              const int idx = rank;
+              n_first[idx] = (int)i;
+              n_geo[idx] = g;
+              n_flags[idx] = l >= TREE_BITS ? FLAG_BUCKET : 0;
+              if(l >= TREE_BITS)
+                {
+                  int c = 1;
+                  while(i + c < n && key[i + c] == k)
+                    c++;
+                  n_count[idx] = c;
+                }
+              if(l > 0)
+                n_child[8 * (long long)parent + key_digit(k, l - 1)] = idx;
+              parent = idx;
+            }
+        }
+      const int dtop = dprev > dcur ? dprev : dcur;   // level of the deepest node that contains this particle
+      if(i < n && dtop < TREE_BITS)                     // (members of a bucket are reached through its range)
+        n_child[8 * (long long)parent + key_digit(k, dtop)] = -2 - (int)i;
+      __syncthreads();
+      if(threadIdx.x <= TREE_BITS)
+        {
+          int t = 0;
+          for(int w = 0; w < TBN / 64; w++)
+            t += wtot[w][threadIdx.x];
+          base[threadIdx.x] += t;
+        }
+      __syncthreads();
     }
-  if(dtop < TREE_BITS)   // members of a bucket are reached through its range
-    n_child[8 * (long long)leaf_parent + key_digit(k, dtop)] = -2 - (int)i;
 }
 
 struct SoftAcc
@@ -547,6 +556,23 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
   // and (already grown) child cells now reach, the role of force_update_len() (forcetree.c:1005-1122)
   const double4 geo0 = n_geo[node];
   double need = 0;
+  auto add_particle_v = [&](const double4 v, const int ty) {
+    if(geo_rw)
+      need = fmax(need, fmax(fabs(v.x - geo0.x), fmax(fabs(v.y - geo0.y), fabs(v.z - geo0.z))));
+    int gg = wp.t2g[ty];
+#pragma unroll
+    for(int g = 0; g < NG; g++)
+      if(g == gg)
+        {
+          np[g]++;
+          m[g] += v.w;
+          sx[g] += v.w * v.x;
+          sy[g] += v.w * v.y;
+          sz[g] += v.w * v.z;
+        }
+    soft_merge(sa, ty, 0, wp.fsoft);
+    cnt_acc++;
+  };
   auto add_particle = [&](int p) {
     double4 v = s_pm[p];
     if(geo_rw)
@@ -574,34 +600,68 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
     }
   else
     {
-      for(int k = 0; k < 8; k++)
-        {
-          int c = n_child[8 * (long long)node + k];
-          if(c == -1)
-            continue;
-          if(c <= -2)
-            add_particle(-2 - c);
-          else
-            {
+      // The records of a batch of children are requested first and summed afterwards, in child order (the summation order of
+      // the level-by-level recursion, forcetree.c:560-640): the kernel is bound by the latency of these scattered loads, and a
+      // load inside the branch that consumes it would serialise them.
+      const int4 *cp = reinterpret_cast<const int4 *>(n_child + 8 * (long long)node);
+      const int4 c_lo = cp[0], c_hi = cp[1];
+      const int ch[8] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w, c_hi.x, c_hi.y, c_hi.z, c_hi.w};
+      constexpr int B = NG == 1 ? 8 : (NG == 2 ? 4 : 2);
 #pragma unroll
-              for(int g = 0; g < NG; g++)
+      for(int k0 = 0; k0 < 8; k0 += B)
+        {
+          double4 rec[B][NG];   // particle: [0] = position and mass; node: its NG monopoles
+          int aux[B], cnt_c[B];  // particle: type; node: flags
+#pragma unroll
+          for(int q = 0; q < B; q++)
+            {
+              const int c = ch[k0 + q];
+              aux[q] = 0;
+              cnt_c[q] = 0;
+              if(c <= -2)
                 {
-                  double4 cm = n_mom[(long long)c * NG + g];
-                  if(n_npart)
-                    np[g] += n_npart[(long long)c * NG + g];
-                  m[g] += cm.w;
-                  sx[g] += cm.w * cm.x;
-                  sy[g] += cm.w * cm.y;
-                  sz[g] += cm.w * cm.z;
+                  rec[q][0] = s_pm[-2 - c];
+                  aux[q] = s_type[-2 - c];
                 }
-              int cf = n_flags[c];
-              soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
-              if(n_count_rw)
-                cnt_acc += n_count_rw[c];
-              if(geo_rw)
+              else if(c >= 0)
                 {
-                  const double4 cg = n_geo[c];
-                  need = fmax(need, fmax(fabs(cg.x - geo0.x), fmax(fabs(cg.y - geo0.y), fabs(cg.z - geo0.z))) + 0.5 * cg.w);
+#pragma unroll
+                  for(int g = 0; g < NG; g++)
+                    rec[q][g] = n_mom[(long long)c * NG + g];
+                  aux[q] = n_flags[c];
+                  if(n_count_rw)
+                    cnt_c[q] = n_count_rw[c];
+                }
+            }
+#pragma unroll
+          for(int q = 0; q < B; q++)
+            {
+              const int c = ch[k0 + q];
+              if(c == -1)
+                continue;
+              if(c <= -2)
+                add_particle_v(rec[q][0], aux[q]);
+              else
+                {
+#pragma unroll
+                  for(int g = 0; g < NG; g++)
+                    {
+                      const double4 cm = rec[q][g];
+                      if(n_npart)
+                        np[g] += n_npart[(long long)c * NG + g];
+                      m[g] += cm.w;
+                      sx[g] += cm.w * cm.x;
+                      sy[g] += cm.w * cm.y;
+                      sz[g] += cm.w * cm.z;
+                    }
+                  const int cf = aux[q];
+                  soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
+                  cnt_acc += cnt_c[q];
+                  if(geo_rw)
+                    {
+                      const double4 cg = n_geo[c];
+                      need = fmax(need, fmax(fabs(cg.x - geo0.x), fmax(fabs(cg.y - geo0.y), fabs(cg.z - geo0.z))) + 0.5 * cg.w);
+                    }
                 }
             }
         }
@@ -808,12 +868,15 @@ int tree_build(ngravs_ctx *c)
   if(onepass)
     {
       // the whole topology from one pass over the sorted keys (see k_tb_nodes)
-      const int nblk = (int)((n + TBN - 1) / TBN);
-      if(c->tb_count.ensure((size_t)(TREE_BITS + 1) * nblk + 64))
+      const int nblk = (int)((n + (long long)TBN * TBCH - 1) / ((long long)TBN * TBCH));
+      const int nblk_pad = (nblk + 3) & ~3;   // rows of the count table are scanned as int4
+      if(c->tb_count.ensure((size_t)(TREE_BITS + 1) * nblk_pad + 64))
         return NGRAVS_ERR_NOMEM;
-      int *lvcnt = c->tb_count.p + (size_t)(TREE_BITS + 1) * nblk;
-      hipLaunchKernelGGL(k_tb_count, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, n, c->tb_count.p, nblk);
-      hipLaunchKernelGGL(k_tb_scan, dim3(TREE_BITS + 1), dim3(1024), 0, c->stream, c->tb_count.p, nblk, lvcnt);
+      int *lvcnt = c->tb_count.p + (size_t)(TREE_BITS + 1) * nblk_pad;
+      if(nblk_pad != nblk)
+        HIP_TRY(c, hipMemsetAsync(c->tb_count.p, 0, sizeof(int) * (size_t)(TREE_BITS + 1) * nblk_pad, c->stream));
+      hipLaunchKernelGGL(k_tb_count, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, n, c->tb_count.p, nblk_pad);
+      hipLaunchKernelGGL(k_tb_scan, dim3(TREE_BITS + 1), dim3(1024), 0, c->stream, c->tb_count.p, nblk_pad, lvcnt);
       hipLaunchKernelGGL(k_tb_levels, dim3(1), dim3(64), 0, c->stream, lvcnt, c->d_levels.p, (int)(maxn > 2147483647ll ? 2147483647ll : maxn));
       {
         long long guess = c->nnodes > 0 ? c->nnodes + c->nnodes / 8 : n / 2;
@@ -821,7 +884,7 @@ int tree_build(ngravs_ctx *c)
         nbf = nbf < 1 ? 1 : (nbf > 262144u ? 262144u : nbf);
         hipLaunchKernelGGL(k_tb_fill, dim3(nbf), dim3(256), 0, c->stream, reinterpret_cast<int4 *>(c->n_child.p), c->d_levels.p);
       }
-      hipLaunchKernelGGL(k_tb_nodes, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, c->s_pm.p, n, c->tb_count.p, nblk, c->d_levels.p,
+      hipLaunchKernelGGL(k_tb_nodes, dim3(nblk), dim3(TBN), 0, c->stream, c->s_key.p, c->s_pm.p, n, c->tb_count.p, nblk_pad, c->d_levels.p,
                          c->n_first.p, c->n_count.p, c->n_child.p, c->n_geo.p, c->n_flags.p, h_geo, c->dom[0], c->dom[1], c->dom[2], fac21);
     }
   else
