@@ -129,6 +129,67 @@ __global__ void k_force_mesh(const double *__restrict__ grid, int N, double fac,
                            (1.0 / 6) * (at(x, y, wrap(z - 2)) - at(x, y, wrap(z + 2))));
 }
 
+// The same force mesh by marching along x: a block of 8 (y) x 32 (z) threads owns a column of FM_XB planes, every thread keeps
+// the five potentials x-2 .. x+2 of its (y, z) in registers, so each potential is read from memory once as the new "x+2" value
+// (the one-thread-per-cell kernel above re-reads every plane five times from far apart: measured 3.2 GB fetched per species
+// for a 1.07 GB mesh); the y and z neighbours are neighbours' lines of the plane just loaded (cache hits).  Same expressions.
+#define FM_XB 64
+__global__ __launch_bounds__(256) void k_force_mesh_march(const double *__restrict__ grid, int N, double fac, double *__restrict__ fm)
+{
+  const long long NZ = N + 2;
+  const int z = blockIdx.x * 32 + (threadIdx.x & 31), y = blockIdx.y * 8 + (threadIdx.x >> 5);
+  const int x0 = blockIdx.z * FM_XB;
+  if(z >= N || y >= N)
+    return;
+  auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
+  const int ym1 = wrap(y - 1), yp1 = wrap(y + 1), ym2 = wrap(y - 2), yp2 = wrap(y + 2);
+  const int zm1 = wrap(z - 1), zp1 = wrap(z + 1), zm2 = wrap(z - 2), zp2 = wrap(z + 2);
+  auto at = [&](int xx, int yy, int zz) { return grid[((long long)xx * N + yy) * NZ + zz]; };
+  double pm2 = at(wrap(x0 - 2), y, z), pm1 = at(wrap(x0 - 1), y, z), p0 = at(wrap(x0), y, z), pp1 = at(wrap(x0 + 1), y, z);
+  const int x1 = x0 + FM_XB < N ? x0 + FM_XB : N;
+  // the three components of a cell are 24 contiguous bytes: a wave (2 rows x 32 cells) turns its 2 x 768 bytes through LDS
+  // and stores them as 16-byte pieces, lane after lane (three 8-byte stores at stride 24 touch every line three times)
+  __shared__ double stage[4][2][96];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, zl = threadIdx.x & 31, rw = (threadIdx.x >> 5) & 1;
+  const bool full = blockIdx.x * 32 + 32 <= N && blockIdx.y * 8 + 8 <= N && (N % 2) == 0;   // whole tile inside the mesh
+  for(int x = x0; x < x1; x++)
+    {
+      const double pp2 = at(wrap(x + 2), y, z);
+      const double fy = fac * ((4.0 / 3) * (at(x, ym1, z) - at(x, yp1, z)) - (1.0 / 6) * (at(x, ym2, z) - at(x, yp2, z)));
+      const double fz = fac * ((4.0 / 3) * (at(x, y, zm1) - at(x, y, zp1)) - (1.0 / 6) * (at(x, y, zm2) - at(x, y, zp2)));
+      const double fx = fac * ((4.0 / 3) * (pm1 - pp1) - (1.0 / 6) * (pm2 - pp2));
+      const long long idx = ((long long)x * N + y) * N + z;
+      if(full)
+        {
+          stage[wave][rw][3 * zl + 0] = fx;
+          stage[wave][rw][3 * zl + 1] = fy;
+          stage[wave][rw][3 * zl + 2] = fz;
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int yw = blockIdx.y * 8 + 2 * wave;   // first of this wave's two rows
+#pragma unroll
+          for(int q = lane; q < 96; q += 64)
+            {
+              const int r = q / 48, o = q - 48 * r;
+              const double2 v = *reinterpret_cast<const double2 *>(&stage[wave][r][2 * o]);
+              *reinterpret_cast<double2 *>(fm + 3 * (((long long)x * N + yw + r) * N + blockIdx.x * 32) + 2 * o) = v;
+            }
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      else
+        {
+          fm[3 * idx + 0] = fx;
+          fm[3 * idx + 1] = fy;
+          fm[3 * idx + 2] = fz;
+        }
+      pm2 = pm1;
+      pm1 = p0;
+      p0 = pp1;
+      pp1 = pp2;
+    }
+}
+
 __global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
                                const unsigned char *__restrict__ s_flag, long long first, long long n, double to_slab, int N,
                                const int *__restrict__ t2g_tab, int species, const double *__restrict__ fm,
@@ -155,15 +216,51 @@ __global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned 
   double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
   double acc[3] = {0, 0, 0};
   auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
+  // the corners (x, y, z) and (x, y, z + 1) are 48 contiguous bytes (except across the periodic seam): three 16-byte loads per
+  // pair instead of six 8-byte ones -- the kernel is bound by the number of scattered load instructions.  Corner order and
+  // expressions as in k_gradient_gather: (0,0,0) (0,1,0) (0,0,1) (0,1,1) (1,0,0) ...
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  const int z1 = wrap(sz + 1);
+  const bool zpair = z1 == sz + 1;
+  double fv[8][3];
+#pragma unroll
+  for(int cx = 0; cx < 2; cx++)
+#pragma unroll
+    for(int cy = 0; cy < 2; cy++)
+      {
+        const int x = wrap(sx + cx), y = wrap(sy + cy);
+        const double *f0 = fm + 3 * (((long long)x * N + y) * N + sz);
+        const int c0 = 4 * cx + cy, c1 = 4 * cx + cy + 2;   // the two corners of this (x, y): z offset 0 and 1
+        if(zpair)
+          {
+            const d2u a = *reinterpret_cast<const d2u *>(f0), b_ = *reinterpret_cast<const d2u *>(f0 + 2),
+                      c_ = *reinterpret_cast<const d2u *>(f0 + 4);
+            fv[c0][0] = a.x;
+            fv[c0][1] = a.y;
+            fv[c0][2] = b_.x;
+            fv[c1][0] = b_.y;
+            fv[c1][1] = c_.x;
+            fv[c1][2] = c_.y;
+          }
+        else
+          {
+            const double *f1 = fm + 3 * (((long long)x * N + y) * N + z1);
+#pragma unroll
+            for(int d = 0; d < 3; d++)
+              {
+                fv[c0][d] = f0[d];
+                fv[c1][d] = f1[d];
+              }
+          }
+      }
   const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+#pragma unroll
   for(int c = 0; c < 8; c++)
     {
-      const int x = wrap(sx + ox[c]), y = wrap(sy + oy[c]), z = wrap(sz + oz[c]);
       const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
-      const double *f = fm + 3 * (((long long)x * N + y) * N + z);
-      acc[0] += f[0] * w;
-      acc[1] += f[1] * w;
-      acc[2] += f[2] * w;
+      acc[0] += fv[c][0] * w;
+      acc[1] += fv[c][1] * w;
+      acc[2] += fv[c][2] * w;
     }
   r_pm[3 * i + 0] = acc[0];
   r_pm[3 * i + 1] = acc[1];
@@ -183,8 +280,8 @@ __global__ void k_gather_force(const double4 *__restrict__ s_pm, const unsigned 
 #define PM_TILE_THREADS 1024
 
 
-template <int NG>
-__global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
+template <int NG, int DT>
+__global__ __launch_bounds__(DT > 10 ? PM_TILE_THREADS : 256) void k_cic_deposit_tiled(
     const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const unsigned char *__restrict__ s_flag,
     const int *__restrict__ n_first, const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0,
     double to_slab, int N, const int *__restrict__ t2g_tab, double *__restrict__ rho)
@@ -201,7 +298,7 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
     o[1] = (int)floor((geo.y - h) * to_slab);
     o[2] = (int)floor((geo.z - h) * to_slab);
   }
-  for(int t = threadIdx.x; t < NG * PM_DT * PM_DT * PM_DT; t += blockDim.x)
+  for(int t = threadIdx.x; t < NG * DT * DT * DT; t += blockDim.x)
     tile[t] = 0.0;
   __syncthreads();
   for(int k = threadIdx.x; k < count; k += blockDim.x)
@@ -220,12 +317,12 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
                            m * (dx) * (1.0 - dy) * (1.0 - dz),       m * (dx)*dy * (1.0 - dz),
                            m * (dx) * (1.0 - dy) * dz,               m * (dx)*dy * dz};   // pm_periodic.c:322-329
       const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
-      if(lx >= 0 && ly >= 0 && lz >= 0 && lx < PM_DT - 1 && ly < PM_DT - 1 && lz < PM_DT - 1)
+      if(lx >= 0 && ly >= 0 && lz >= 0 && lx < DT - 1 && ly < DT - 1 && lz < DT - 1)
         {
-          double *tg = tile + (size_t)g * PM_DT * PM_DT * PM_DT;
+          double *tg = tile + (size_t)g * DT * DT * DT;
 #pragma unroll
           for(int c = 0; c < 8; c++)
-            atomicAdd(&tg[((lx + ox[c]) * PM_DT + (ly + oy[c])) * PM_DT + (lz + oz[c])], w[c]);
+            atomicAdd(&tg[((lx + ox[c]) * DT + (ly + oy[c])) * DT + (lz + oz[c])], w[c]);
         }
       else
         {
@@ -236,13 +333,13 @@ __global__ __launch_bounds__(PM_TILE_THREADS) void k_cic_deposit_tiled(
         }
     }
   __syncthreads();
-  for(int t = threadIdx.x; t < NG * PM_DT * PM_DT * PM_DT; t += blockDim.x)
+  for(int t = threadIdx.x; t < NG * DT * DT * DT; t += blockDim.x)
     {
       const double v = tile[t];
       if(v != 0.0)
         {
-          const int g = t / (PM_DT * PM_DT * PM_DT), r = t % (PM_DT * PM_DT * PM_DT);
-          const int lx = r / (PM_DT * PM_DT), ly = (r / PM_DT) % PM_DT, lz = r % PM_DT;
+          const int g = t / (DT * DT * DT), r = t % (DT * DT * DT);
+          const int lx = r / (DT * DT), ly = (r / DT) % DT, lz = r % DT;
           atomicAdd(&rho[(size_t)g * N * N * NZ + ((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)], v);
         }
     }
@@ -460,18 +557,27 @@ int pm_deposit(ngravs_ctx *c)
   HIP_TRY(c, hipMemsetAsync(c->pm_rho.p, 0, sizeof(double) * real_elems * ng, c->stream));
   const int bs = 256;
   unsigned nbp = (unsigned)((n + bs - 1) / bs);
-  const int tl = pm_tile_level(c, to_slab);
+  // tiles: tree cells at most 16 mesh cells wide (18^3 patch per species, one 1024-thread workgroup per CU), or -- tuning
+  // "pm_tile8" -- at most 8 (10^3 patches, 256 threads, several workgroups per CU overlap their phases)
+  const bool t8 = c->tune.pm_tile8 != 0;
+  const int tl = pm_tile_level(c, to_slab, t8 ? 8.0 : 16.0);
   const long long tl0 = tl >= 0 ? c->level_start[tl] : 0, tln = tl >= 0 ? c->level_start[tl + 1] - tl0 : 0;
   if(tl >= 0)
     {
-      const size_t lds = sizeof(double) * ng * PM_DT * PM_DT * PM_DT;
+      const int dt = t8 ? 10 : PM_DT;
+      const size_t lds = sizeof(double) * ng * dt * dt * dt;
       auto launch_dep = [&](auto kern) -> int {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
+        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(t8 ? 256 : PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
                            c->n_first.p, c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
         return NGRAVS_OK;
       };
-      int rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2>) : launch_dep(k_cic_deposit_tiled<3>));
+      int rc;
+      if(t8)
+        rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, 10>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, 10>) : launch_dep(k_cic_deposit_tiled<3, 10>));
+      else
+        rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, PM_DT>)
+                     : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, PM_DT>) : launch_dep(k_cic_deposit_tiled<3, PM_DT>));
       if(rc)
         return rc;
       if(tl0 > 0)
@@ -559,8 +665,8 @@ int pm_finish(ngravs_ctx *c)
       if(all_resident)
         {
           for(int b = 0; b < ng; b++)
-            hipLaunchKernelGGL(k_force_mesh, dim3((unsigned)((NN + bs - 1) / bs)), dim3(bs), 0, c->stream, c->pm_phi.p + real_elems * b, N,
-                               fac, c->pm_force.p + (size_t)3 * NN * b);
+            hipLaunchKernelGGL(k_force_mesh_march, dim3((N + 31) / 32, (N + 7) / 8, (N + FM_XB - 1) / FM_XB), dim3(256), 0, c->stream,
+                               c->pm_phi.p + real_elems * b, N, fac, c->pm_force.p + (size_t)3 * NN * b);
           hipLaunchKernelGGL(k_gather_force, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
                              (long long)c->shard_first, (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, -1, c->pm_force.p,
                              c->r_pm.p);
@@ -568,8 +674,8 @@ int pm_finish(ngravs_ctx *c)
       else
       for(int b = 0; b < ng; b++)
         {
-          hipLaunchKernelGGL(k_force_mesh, dim3((unsigned)((NN + bs - 1) / bs)), dim3(bs), 0, c->stream, c->pm_phi.p + real_elems * b, N,
-                             fac, c->pm_force.p);
+          hipLaunchKernelGGL(k_force_mesh_march, dim3((N + 31) / 32, (N + 7) / 8, (N + FM_XB - 1) / FM_XB), dim3(256), 0, c->stream,
+                             c->pm_phi.p + real_elems * b, N, fac, c->pm_force.p);
           hipLaunchKernelGGL(k_gather_force, dim3(nbg), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
                              (long long)c->shard_first, (long long)c->shard_count, to_slab, N, c->d_counters.p + 8, b, c->pm_force.p,
                              c->r_pm.p);
