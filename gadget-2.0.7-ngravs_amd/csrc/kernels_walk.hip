@@ -625,6 +625,12 @@ __device__ __forceinline__ double wave_min(double v)
     }
   return v;
 }
+// a wave-uniform double (every lane holds the same value) moved into SGPRs: frees two VGPRs per value that lives as long as the group
+__device__ __forceinline__ double wave_uniform(double v)
+{
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
   for(int off = 32; off > 0; off >>= 1)
@@ -881,8 +887,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       double lox = wave_min(mnx), hix = wave_max(mxx);
       double loy = wave_min(mny), hiy = wave_max(mxy);
       double loz = wave_min(mnz), hiz = wave_max(mxz);
-      const double bcx = 0.5 * (lox + hix), bcy = 0.5 * (loy + hiy), bcz = 0.5 * (loz + hiz);
-      const double bhx = 0.5 * (hix - lox), bhy = 0.5 * (hiy - loy), bhz = 0.5 * (hiz - loz);
+      const double bcx = wave_uniform(0.5 * (lox + hix)), bcy = wave_uniform(0.5 * (loy + hiy)), bcz = wave_uniform(0.5 * (loz + hiz));
+      const double bhx = wave_uniform(0.5 * (hix - lox)), bhy = wave_uniform(0.5 * (hiy - loy)), bhz = wave_uniform(0.5 * (hiz - loz));
       const double aold_min = wave_min(mna);
       const double hT_min = wave_min(mnh);
       // may sources be wrapped once per group (relative to the box centre) instead of per pair?
@@ -942,10 +948,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       // A operand of lane l = A[row l & 31][k = l >> 5].  Row i carries pool entry 32 eb + 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3):
       // with that assignment accumulator register r of a lane holds entry 16 (l >> 5) + r of the block, i.e. its 16 sign bits
       // are 16 consecutive mask bits and its C input |e|^2 is 16 consecutive floats.
+      // One per-lane LDS address serves all three operand reads: mA0 = (ex | ey) of the lane's row; mA0 + 4 WAVE floats is ez
+      // for the lower half (the upper half lands in |e|^2 and is replaced by the constant 1); the C rows follow from mh.
       const int mrow = 16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3);
-      const float *const mA0 = (mh ? lfy : lfx) + mrow;   // (ex | ey)
-      const float *const mA1 = lfz + mrow;                 // (ez | 1): the upper half is replaced by the constant
-      const float *const mC = le2 + 16 * mh;
+      const float *const mA0 = (mh ? lfy : lfx) + mrow;
 
       double ax = 0, ay = 0, az = 0;
       int nint = 0;
@@ -1261,10 +1267,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 }
             }
         };
-        int4 qd, qd_next;          // item quads of the current and the next four chunks
-        int nv, nv_next;
-        fetch_quad(0, qd, nv);
-        fetch_quad(1, qd_next, nv_next);
+        int4 qd;                   // item quad of the current four chunks (the next one is requested when this one is used up:
+        int nv;                    // a second register set for it costs more in spills than the exposed latency, which the
+        fetch_quad(0, qd, nv);     // other waves of the SIMD cover)
         double4 q1;
         q1.x = q1.y = q1.z = q1.w = 0;
         int hs1 = 0;
@@ -1317,11 +1322,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               // chunk cc+1: element (cc+1) & 3 of its quad
               const int bn = (cc + 1) & 3;
               if(bn == 0)
-                {
-                  qd = qd_next;
-                  nv = nv_next;
-                  fetch_quad((cc + 1) / 4 + 1, qd_next, nv_next);   // the quad after that one
-                }
+                fetch_quad((cc + 1) / 4, qd, nv);
               const int itn = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
               have1 = cc + 1 < nchunks && bn < nv;
               fetch_rec(have1, itn, q1, hs1);
@@ -1346,8 +1347,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     for(int w = 0; w < 2; w++)
                       {
                         const float a0 = mA0[32 * w];
-                        const float a1r = mA1[32 * w];
+                        const float a1r = mA0[4 * WAVE + 32 * w];   // lfz[row] for the lower half (lfz = lfx + 4 WAVE floats)
                         const float a1 = mh ? 1.0f : a1r;
+                        const float *const mC = le2 + 16 * mh;
                         unsigned int wt[2];
 #pragma unroll
                         for(int tb = 0; tb < 2; tb++)
