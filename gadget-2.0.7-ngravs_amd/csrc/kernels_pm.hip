@@ -504,9 +504,11 @@ static int pm_tile_level(const ngravs_ctx *c, double to_slab, double max_cells =
 {
   if(!c->have_tree || c->tune.pm_notile)
     return -1;
+  // (the tree's root cube is 1.001 x the particle extent, domain.c:909-923: a "16-cell" node of a full box is 16.016 cells wide.
+  // The patches have one point of slack for that; the rare particle beyond it takes the direct path.)
   double len = c->dom[6];
   for(int l = 0; l < c->nlevels && l < TREE_BITS; l++, len *= 0.5)
-    if(len * to_slab <= max_cells)
+    if(len * to_slab <= max_cells * 1.002)
       return (c->level_start[l + 1] - c->level_start[l] > 0) ? l : -1;
   return -1;
 }
