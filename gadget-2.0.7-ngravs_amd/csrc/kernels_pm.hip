@@ -634,7 +634,7 @@ int pm_finish(ngravs_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->r_pm.p, 0, sizeof(double) * 3 * n, c->stream));
   unsigned nbg = (unsigned)((c->shard_count + bs - 1) / bs);
   // tiled gather (cells at most 8 mesh cells wide, all species' potential patches in LDS): measured at C4 it LOSES to the
-  // per-particle gather (73 ms vs 13.3 ms -- 14 GB of short-row patch loads; the 16-cell one-species variant took 24.6 ms),
+  // two-pass gather below (13 ms against 3.0 + 3.3 ms: 15^3 patches for 8^3 cells re-read the mesh 6.6 times in short rows),
   // so it is opt-in for tuning only
   const int gl = c->tune.pm_tile_gather ? pm_tile_level(c, to_slab, 8.0) : -1;
   if(gl >= 0)
