@@ -57,12 +57,28 @@ __global__ void k_minmax(const double *__restrict__ pos, long long n, double *__
     }
 }
 
+// PERIODIC: the reference maps the particles back onto the box before it decomposes (do_box_wrapping, domain.c:81), so every
+// position it hands to this path lies in [0, BoxSize]; the walk's start table and the wrap-free shortcut of the evaluation
+// kernel rely on it.  Anything else is refused loudly rather than computed wrongly.
+static int dom_check_periodic_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
+{
+  if(!c->cfg.periodic || c->cfg.box_size <= 0)
+    return NGRAVS_OK;
+  for(int j = 0; j < 3; j++)
+    if(!(lo[j] >= 0.0 && hi[j] <= c->cfg.box_size) && lo[j] <= hi[j])
+      {
+        ngravs_report(c, NGRAVS_ERR_ARG, "PERIODIC: a position lies outside [0, BoxSize] (wrap the particles first: do_box_wrapping(), domain.c:81)");
+        return NGRAVS_ERR_ARG;
+      }
+  return NGRAVS_OK;
+}
+
 int dom_find_extent(ngravs_ctx *c)
 {
   if(c->extent_override)   // multi-task: the all-reduced extent (domain.c:906-907) was handed in by the host
     {
       dd_apply_extent(c, c->ext_lo, c->ext_hi);
-      return NGRAVS_OK;
+      return dom_check_periodic_extent(c, c->ext_lo, c->ext_hi);
     }
   const int nb = 1024, bs = 256;
   if(c->red_tmp.ensure(nb * 6))
@@ -80,6 +96,8 @@ int dom_find_extent(ngravs_ctx *c)
         if(h[b * 6 + 3 + j] > hi[j])
           hi[j] = h[b * 6 + 3 + j];
       }
+  if(int rc = dom_check_periodic_extent(c, lo, hi))
+    return rc;
   // domain.c:909-923, same operation order
   double len = 0;
   for(int j = 0; j < 3; j++)

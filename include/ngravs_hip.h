@@ -187,6 +187,7 @@ int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
  *   "walk_sg" n: groups of 64 targets per traversal unit = per shared item list (0 = auto: 4 with TreePM, else 1)
  *   "walk_nleaf" k: an opened node with <= k particles hands its particles over instead of its children (0..8, -1 = default 8)
  *   "pm_notile" 1: per-particle CIC deposit     "pm_fused_gather" 1: one-pass gradient+gather    "pm_tile_gather" 1: LDS-tiled gather
+ *   "pm_tile8" 1: deposit tiles of 8 instead of 16 mesh cells    "tree_levelwise" 1: level-by-level tree build for single-task trees too
  * Returns NGRAVS_ERR_ARG for an unknown name or a value out of range. */
 int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
 /* Plain copies for hosts that do not link HIP themselves (a C/MPI host staging exchange buffers through host memory):
@@ -194,7 +195,8 @@ int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
 int ngravs_memcpy(ngravs_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
 
 /* ---- data hand-over ---------------------------------------------------------------------- */
-/* Replace the engine's particle set (the role of P[] + NumPart). */
+/* Replace the engine's particle set (the role of P[] + NumPart).  PERIODIC runs: positions must lie in [0, BoxSize], as they do
+ * in the reference after do_box_wrapping() (domain.c:81); the next decomposition fails with NGRAVS_ERR_ARG otherwise. */
 int ngravs_set_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
 /* Drifted tree (TreeDomainUpdateFrequency > 0: domain.c:76, predict.c:79-91): the same particles (same n, same order
  * in the caller's arrays) with new positions / OldAcc / active flags.  Keeps the last decomposition and tree topology;

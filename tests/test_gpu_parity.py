@@ -233,6 +233,26 @@ def test_group_walk_treepm_accuracy_vs_ewald(pkg, O, wiring, ng, reach):
     eng.close()
 
 
+def test_positions_outside_the_periodic_box_are_refused(pkg):
+    """PERIODIC: the reference wraps the particles onto the box before it decomposes (do_box_wrapping, domain.c:81) and the
+    glue does the same; the walk's start table and the evaluation kernel's shortcut for groups away from the faces rely on
+    positions in [0, BoxSize].  A caller that skips the wrapping gets an error, not wrong forces."""
+    pos, mass, typ = pkg.ic.uniform_box(4096, box=1.0, n_gravs=1, seed=3)
+    cfg = pkg.make_config(n_gravs=1, periodic=1, pmgrid=32, box_size=1.0, G=1.0, theta=0.5, softening=[0.002] * 6)
+    below, above = pos.copy(), pos.copy()
+    below[7, 1] = -1e-9
+    above[11, 2] = 1.0 + 1e-9
+    for bad in (pos + 0.37, below, above):
+        eng = pkg.Engine(cfg)
+        eng.set_particles(bad, mass, typ)
+        with pytest.raises(Exception):
+            eng.compute_accelerations(pm_step=True)
+        eng.close()
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=True)
+    eng.close()
+
+
 def test_group_walk_sparse_active_set_vs_ewald(pkg, O):
     """individual timesteps: only ~3 % of the particles are active (gravtree.c:113).  The group walk compacts the active
     targets of the Peano order into groups of 64 (boxes ~3x wider than a 64-particle stretch); accuracy against the Ewald
