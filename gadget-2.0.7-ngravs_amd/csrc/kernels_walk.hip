@@ -1591,7 +1591,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               const double len = geo.w, half = 0.5 * len;
               double cx = geo.x - bcx, cy = geo.y - bcy, cz = geo.z - bcz;   // plain (inside-cell test has no NEAREST)
               double wx = cx, wy = cy, wz = cz;
-              if(wp.periodic)
+              if(!nowrap)   // (a unit whose whole region lies inside the box needs no images: see `nowrap` above)
                 {
                   wx = nearest_abs(cx, wp.box, invbox);
                   wy = nearest_abs(cy, wp.box, invbox);
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       summass += mom.w;
                       massmask |= (mom.w != 0.0) ? (1u << g) : 0u;
                       double dx = mom.x - bcx, dy = mom.y - bcy, dz = mom.z - bcz;
-                      if(wp.periodic)
+                      if(!nowrap)
                         {
                           dx = nearest_abs(dx, wp.box, invbox);
                           dy = nearest_abs(dy, wp.box, invbox);
