@@ -271,7 +271,7 @@ __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, i
 //  (children's counts + particle leaves); buckets (level TREE_BITS: identical keys) count their run of equal keys here.
 // =============================================================================================
 #define TBN 256   // threads per block of the one-pass kernels
-#define TBCH 8    // chunks of TBN consecutive particles per block
+#define TBCH 2    // chunks of TBN consecutive particles per block
 __device__ __forceinline__ int common_digits(unsigned long long a, unsigned long long b)
 {
   const unsigned long long x = a ^ b;
@@ -606,7 +606,7 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
       const int4 *cp = reinterpret_cast<const int4 *>(n_child + 8 * (long long)node);
       const int4 c_lo = cp[0], c_hi = cp[1];
       const int ch[8] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w, c_hi.x, c_hi.y, c_hi.z, c_hi.w};
-      constexpr int B = NG == 1 ? 8 : (NG == 2 ? 4 : 2);
+      constexpr int B = NG == 1 ? 4 : 2;   // (measured at C4, N_GRAVS = 2: 2 -> see DESIGN; 4 costs occupancy: 125 VGPRs)
 #pragma unroll
       for(int k0 = 0; k0 < 8; k0 += B)
         {
