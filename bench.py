@@ -322,6 +322,8 @@ def main():
     for _ in range(args.warmup):
         eng.compute_accelerations(pm_step=True)
     walk_ms, phases, eval_ms = [], [], []
+    if domain:
+        eng.reset_wall()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -381,6 +383,25 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_provenance"] = walk_traffic(args, n, world, split["launches_per_step"] if split else 1)
+        if domain:
+            # rank 0's host wall clock per step: the three stages of compute_accelerations() and the part of each spent inside
+            # collectives (waiting for the slowest task included); payloads of the last step
+            w = eng.wall
+            k = max(1, w["steps"])
+            out["config"]["rank0_wall_ms_per_step"] = {
+                "decomposition": w["decomposition_s"] / k * 1e3, "decomposition_in_collectives": w["decomposition_collectives_s"] / k * 1e3,
+                "pm": w["pm_s"] / k * 1e3, "pm_in_collectives": w["pm_collectives_s"] / k * 1e3,
+                "gravity_tree": w["gravity_tree_s"] / k * 1e3, "collective_calls": w["collective_calls"] / k}
+            out["config"]["rank0_last_step"] = {
+                "n_local": int(eng.info.n_local), "n_imported": int(eng.info.n_halo), "n_migrated_in": int(eng.info.n_migrated_in),
+                "work_balance": float(eng.info.work_balance), "memory_balance": float(eng.info.memory_balance),
+                "bytes_migration": float(eng.info.bytes_migration), "bytes_import": float(eng.info.bytes_halo),
+                "pm_exchange_bytes": eng.pm_bytes() if not treeonly else None,
+                "pm_stage_ms": (lambda v: {"deposit+boxes": v[0], "pack": [v[1], v[4], v[7], v[10]], "alltoallv": [v[2], v[5], v[8], v[11]],
+                                           "unpack": [v[3], v[6], v[9], v[12]]})([1e3 * x for x in eng.pm_seconds()]) if not treeonly else None,
+                "decomposition_stage_ms": dict(zip(["extent+histogram+split", "migration", "top_cell_sums", "need_test_host", "requests+pack",
+                                                    "import_exchange+unpack", "global_top", "local_decomposition"],
+                                                   [1e3 * float(v) for v in eng.info.seconds]))}
         if world == 1 and not treeonly and not args.no_accuracy:
             out["accuracy"] = accuracy_block(pkg, eng, n, dev)
         else:

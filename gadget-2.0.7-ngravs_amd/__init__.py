@@ -41,7 +41,8 @@ EXPORTS = [
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
 HOST_EXPORTS = ["ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
-                "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split"]
+                "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
+                "ngravs_host_pm_seconds"]
 
 
 class NgravsError(RuntimeError):

@@ -1294,7 +1294,13 @@ extern "C" int ngravs_pm_slab_begin(ngravs_ctx *c, int rank, int world, int32_t 
   if(!c->have_order)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  if(c->tree_stale)   // drifted particles: the sorted columns are refreshed by the refit
+  if(!c->have_tree)   // the patches of the tiled brick deposit are the cells of one tree level (as in ngravs_pmforce_periodic)
+    {
+      int64_t nn = ngravs_force_treebuild(c);
+      if(nn < 0)
+        return (int)nn;
+    }
+  else if(c->tree_stale)   // drifted particles: the sorted columns are refreshed by the refit
     {
       int rc = ngravs_force_update_tree(c);
       if(rc)

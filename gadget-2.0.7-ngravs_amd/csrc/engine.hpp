@@ -151,7 +151,7 @@ struct PmSlab
   std::vector<int> bbox;                   // lo[3], ext[3] of every task's brick
   std::vector<int64_t> scount, rcount;     // doubles per peer of the stage being exchanged
   long long edesc_off = 0;                 // stage 3: where the extended-brick plane descriptors start in desc
-  DevBuf<double> brick, slab, tbuf, ebrick, send, recv;
+  DevBuf<double> brick, slab, tbuf, ebrick, fmesh, send, recv;
   DevBuf<long long> desc;
   void *plan2f = nullptr, *plan2i = nullptr, *plan1 = nullptr;
   int plan_N = 0, plan_nx = 0, plan_ny = 0;

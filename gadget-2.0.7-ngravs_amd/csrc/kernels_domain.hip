@@ -369,20 +369,32 @@ __global__ void k_dd_owner(const double *__restrict__ pos, long long n, double c
   dest[i] = owner_ph[cell];
 }
 
+// One atomic per wave and destination, not per particle: 8 M particles adding to the same counter serialise in the memory
+// controller (measured 30 ms for the "stays here" counter alone).  The bits any lane of the wave holds are visited on the
+// scalar unit; a ballot gives the lanes of one destination, its population count their number, mbcnt a lane's rank.
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    v |= __shfl_xor(v, off);
+  return v;
+}
 __global__ void k_dd_count(const unsigned long long *__restrict__ mask, long long n, int nranks, unsigned long long *__restrict__ counts)
 {
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  unsigned long long m = mask[i];
-  while(m)
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = i < n ? mask[i] : 0ull;
+  unsigned long long any = wave_or64(m);
+  while(any)
     {
-      int r = __builtin_ctzll(m);
-      m &= m - 1;
-      atomicAdd(&counts[r], 1ull);
+      const int r = __builtin_ctzll(any);
+      any &= any - 1;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(((m >> r) & 1ull) != 0);
+      if(lane == 0)
+        atomicAdd(&counts[r], (unsigned long long)__popcll(b));
     }
-  if(mask[i] == 0)
-    atomicAdd(&counts[nranks], 1ull);   // stays / not exported
+  const unsigned long long stay = __builtin_amdgcn_ballot_w64(i < n && m == 0);
+  if(lane == 0 && stay)
+    atomicAdd(&counts[nranks], (unsigned long long)__popcll(stay));   // stays / not exported
 }
 
 __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
@@ -391,26 +403,37 @@ __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long
                           const unsigned long long *__restrict__ offs, unsigned long long *__restrict__ cursor,
                           DDRecord *__restrict__ out)
 {
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  unsigned long long m = mask[i];
-  if(!m)
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = i < n ? mask[i] : 0ull;
+  unsigned long long any = wave_or64(m);
+  if(!any)
     return;
   DDRecord rec;
-  rec.x = pos[3 * i + 0];
-  rec.y = pos[3 * i + 1];
-  rec.z = pos[3 * i + 2];
-  rec.m = mass[i];
-  rec.oldacc = oldacc[i];
-  rec.cost = cost[i];
-  rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
-  while(m)
+  rec.x = rec.y = rec.z = rec.m = rec.oldacc = rec.cost = 0;
+  rec.meta = 0;
+  if(m)
     {
-      int r = __builtin_ctzll(m);
-      m &= m - 1;
-      unsigned long long k = atomicAdd(&cursor[r], 1ull);
-      out[offs[r] + k] = rec;
+      rec.x = pos[3 * i + 0];
+      rec.y = pos[3 * i + 1];
+      rec.z = pos[3 * i + 2];
+      rec.m = mass[i];
+      rec.oldacc = oldacc[i];
+      rec.cost = cost[i];
+      rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
+    }
+  while(any)
+    {
+      const int r = __builtin_ctzll(any);
+      any &= any - 1;
+      const bool mine = ((m >> r) & 1ull) != 0;
+      const unsigned long long b = __builtin_amdgcn_ballot_w64(mine);
+      unsigned long long base = 0;
+      if(lane == 0)
+        base = atomicAdd(&cursor[r], (unsigned long long)__popcll(b));
+      base = __shfl(base, 0);
+      if(mine)
+        out[offs[r] + base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = rec;
     }
 }
 
@@ -423,9 +446,15 @@ __global__ void k_dd_keep(const unsigned long long *__restrict__ mask, long long
                           long long *__restrict__ id2, double *__restrict__ cost2)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n || mask[i])
+  const bool keep = i < n && mask[i] == 0;
+  const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);   // one atomic per wave (see k_dd_count)
+  unsigned long long kbase = 0;
+  if((threadIdx.x & 63) == 0 && kb)
+    kbase = atomicAdd(cursor, (unsigned long long)__popcll(kb));
+  kbase = __shfl(kbase, 0);
+  if(!keep)
     return;
-  unsigned long long k = atomicAdd(cursor, 1ull);
+  unsigned long long k = kbase + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0));
   pos2[3 * k + 0] = pos[3 * i + 0];
   pos2[3 * k + 1] = pos[3 * i + 1];
   pos2[3 * k + 2] = pos[3 * i + 2];

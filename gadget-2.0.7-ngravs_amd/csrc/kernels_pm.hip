@@ -284,13 +284,12 @@ template <int NG, int DT>
 __global__ __launch_bounds__(DT > 10 ? PM_TILE_THREADS : 256) void k_cic_deposit_tiled(
     const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type, const unsigned char *__restrict__ s_flag,
     const int *__restrict__ n_first, const int *__restrict__ n_count, const double4 *__restrict__ n_geo, int node0,
-    double to_slab, int N, const int *__restrict__ t2g_tab, double *__restrict__ rho)
+    double to_slab, int N, const int *__restrict__ t2g_tab, double *__restrict__ rho, MeshAddr ma)
 {
   extern __shared__ double tile[];   // [NG][DT][DT][DT]
   const int node = node0 + blockIdx.x;
   const double4 geo = n_geo[node];
   const int first = n_first[node], count = n_count[node];
-  const long long NZ = N + 2;
   int o[3];
   {
     const double h = 0.5 * geo.w;
@@ -326,10 +325,10 @@ __global__ __launch_bounds__(DT > 10 ? PM_TILE_THREADS : 256) void k_cic_deposit
         }
       else
         {
-          double *grid = rho + (size_t)g * N * N * NZ;   // outside the patch (cannot happen for in-cell particles): direct
+          double *grid = rho + (size_t)g * ma.species_stride();   // outside the patch (a cell wider than the patch allows for): direct
 #pragma unroll
           for(int c = 0; c < 8; c++)
-            atomicAdd(&grid[((long long)wrapN(sx + ox[c], N) * N + wrapN(sy + oy[c], N)) * NZ + wrapN(sz + oz[c], N)], w[c]);
+            atomicAdd(&grid[ma.cell(sx + ox[c], sy + oy[c], sz + oz[c])], w[c]);
         }
     }
   __syncthreads();
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(DT > 10 ? PM_TILE_THREADS : 256) void k_cic_deposit
         {
           const int g = t / (DT * DT * DT), r = t % (DT * DT * DT);
           const int lx = r / (DT * DT), ly = (r / DT) % DT, lz = r % DT;
-          atomicAdd(&rho[(size_t)g * N * N * NZ + ((long long)wrapN(o[0] + lx, N) * N + wrapN(o[1] + ly, N)) * NZ + wrapN(o[2] + lz, N)], v);
+          atomicAdd(&rho[(size_t)g * ma.species_stride() + ma.cell(o[0] + lx, o[1] + ly, o[2] + lz)], v);
         }
     }
 }
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(DT > 10 ? PM_TILE_THREADS : 256) void k_cic_deposit
 __global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
                                     const unsigned char *__restrict__ s_flag,
                                     const int *__restrict__ n_child, int nnodes_above, double to_slab, int N,
-                                    const int *__restrict__ t2g_tab, double *__restrict__ rho)
+                                    const int *__restrict__ t2g_tab, double *__restrict__ rho, MeshAddr ma)
 {
   long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(t >= 8ll * nnodes_above)
@@ -362,20 +361,18 @@ __global__ void k_cic_deposit_loose(const double4 *__restrict__ s_pm, const unsi
     return;
   double4 p = s_pm[i];
   int g = t2g_tab[s_type[i]];
-  const long long NZ = N + 2;
-  double *grid = rho + (size_t)g * N * N * NZ;
+  double *grid = rho + (size_t)g * ma.species_stride();
   double dx, dy, dz;
   int sx = cell_of(p.x, to_slab, N, &dx), sy = cell_of(p.y, to_slab, N, &dy), sz = cell_of(p.z, to_slab, N, &dz);
-  int sxx = sx + 1 == N ? 0 : sx + 1, syy = sy + 1 == N ? 0 : sy + 1, szz = sz + 1 == N ? 0 : sz + 1;
   double m = p.w;
-  atomicAdd(&grid[((long long)sx * N + sy) * NZ + sz], m * (1.0 - dx) * (1.0 - dy) * (1.0 - dz));
-  atomicAdd(&grid[((long long)sx * N + syy) * NZ + sz], m * (1.0 - dx) * dy * (1.0 - dz));
-  atomicAdd(&grid[((long long)sx * N + sy) * NZ + szz], m * (1.0 - dx) * (1.0 - dy) * dz);
-  atomicAdd(&grid[((long long)sx * N + syy) * NZ + szz], m * (1.0 - dx) * dy * dz);
-  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + sz], m * (dx) * (1.0 - dy) * (1.0 - dz));
-  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + sz], m * (dx)*dy * (1.0 - dz));
-  atomicAdd(&grid[((long long)sxx * N + sy) * NZ + szz], m * (dx) * (1.0 - dy) * dz);
-  atomicAdd(&grid[((long long)sxx * N + syy) * NZ + szz], m * (dx)*dy * dz);
+  atomicAdd(&grid[ma.cell(sx, sy, sz)], m * (1.0 - dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[ma.cell(sx, sy + 1, sz)], m * (1.0 - dx) * dy * (1.0 - dz));
+  atomicAdd(&grid[ma.cell(sx, sy, sz + 1)], m * (1.0 - dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[ma.cell(sx, sy + 1, sz + 1)], m * (1.0 - dx) * dy * dz);
+  atomicAdd(&grid[ma.cell(sx + 1, sy, sz)], m * (dx) * (1.0 - dy) * (1.0 - dz));
+  atomicAdd(&grid[ma.cell(sx + 1, sy + 1, sz)], m * (dx)*dy * (1.0 - dz));
+  atomicAdd(&grid[ma.cell(sx + 1, sy, sz + 1)], m * (dx) * (1.0 - dy) * dz);
+  atomicAdd(&grid[ma.cell(sx + 1, sy + 1, sz + 1)], m * (dx)*dy * dz);
 }
 
 // gather: one workgroup per node of the level whose cells are at most 8 mesh cells wide; the potential patches of
@@ -530,6 +527,43 @@ void pm_release(ngravs_ctx *c)
   c->pm_plan_n = 0;
 }
 
+// CIC deposit of the working set's own particles into `dst` (zeroed by the caller), a full mesh or a brick (MeshAddr), by tiles:
+// tree cells at most 16 mesh cells wide (18^3 patch per species, one 1024-thread workgroup per CU), or -- tuning "pm_tile8" -- at
+// most 8 (10^3 patches, 256 threads).  Returns 1 if the tree has no such level (caller deposits per particle), 0, or an error.
+// Expects the type -> species table in d_counters[8..13].
+int pm_deposit_tiles(ngravs_ctx *c, const MeshAddr &ma, double *dst)
+{
+  const int N = c->cfg.pmgrid, ng = c->cfg.n_gravs;
+  const double to_slab = N / c->cfg.box_size;
+  const int bs = 256;
+  const bool t8 = c->tune.pm_tile8 != 0;
+  const int tl = pm_tile_level(c, to_slab, t8 ? 8.0 : 16.0);
+  if(tl < 0)
+    return 1;
+  const long long tl0 = c->level_start[tl], tln = c->level_start[tl + 1] - tl0;
+  const int dt = t8 ? 10 : PM_DT;
+  const size_t lds = sizeof(double) * ng * dt * dt * dt;
+  auto launch_dep = [&](auto kern) -> int {
+    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(t8 ? 256 : PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
+                       c->n_first.p, c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, dst, ma);
+    return NGRAVS_OK;
+  };
+  int rc;
+  if(t8)
+    rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, 10>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, 10>) : launch_dep(k_cic_deposit_tiled<3, 10>));
+  else
+    rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, PM_DT>)
+                 : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, PM_DT>) : launch_dep(k_cic_deposit_tiled<3, PM_DT>));
+  if(rc)
+    return rc;
+  if(tl0 > 0)
+    hipLaunchKernelGGL(k_cic_deposit_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p,
+                       c->s_active.p, c->n_child.p, (int)tl0, to_slab, N, c->d_counters.p + 8, dst, ma);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
 int pm_deposit(ngravs_ctx *c)
 {
   const int N = c->cfg.pmgrid, ng = c->cfg.n_gravs;
@@ -559,36 +593,20 @@ int pm_deposit(ngravs_ctx *c)
   HIP_TRY(c, hipMemsetAsync(c->pm_rho.p, 0, sizeof(double) * real_elems * ng, c->stream));
   const int bs = 256;
   unsigned nbp = (unsigned)((n + bs - 1) / bs);
-  // tiles: tree cells at most 16 mesh cells wide (18^3 patch per species, one 1024-thread workgroup per CU), or -- tuning
-  // "pm_tile8" -- at most 8 (10^3 patches, 256 threads, several workgroups per CU overlap their phases)
-  const bool t8 = c->tune.pm_tile8 != 0;
-  const int tl = pm_tile_level(c, to_slab, t8 ? 8.0 : 16.0);
-  const long long tl0 = tl >= 0 ? c->level_start[tl] : 0, tln = tl >= 0 ? c->level_start[tl + 1] - tl0 : 0;
-  if(tl >= 0)
+  MeshAddr ma;
+  ma.N = N;
+  ma.brick = 0;
+  for(int j = 0; j < 3; j++)
     {
-      const int dt = t8 ? 10 : PM_DT;
-      const size_t lds = sizeof(double) * ng * dt * dt * dt;
-      auto launch_dep = [&](auto kern) -> int {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)tln), dim3(t8 ? 256 : PM_TILE_THREADS), lds, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p,
-                           c->n_first.p, c->n_count.p, c->n_geo.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
-        return NGRAVS_OK;
-      };
-      int rc;
-      if(t8)
-        rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, 10>) : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, 10>) : launch_dep(k_cic_deposit_tiled<3, 10>));
-      else
-        rc = ng == 1 ? launch_dep(k_cic_deposit_tiled<1, PM_DT>)
-                     : (ng == 2 ? launch_dep(k_cic_deposit_tiled<2, PM_DT>) : launch_dep(k_cic_deposit_tiled<3, PM_DT>));
-      if(rc)
-        return rc;
-      if(tl0 > 0)
-        hipLaunchKernelGGL(k_cic_deposit_loose, dim3((unsigned)((8 * tl0 + bs - 1) / bs)), dim3(bs), 0, c->stream, c->s_pm.p,
-                           c->s_type.p, c->s_active.p, c->n_child.p, (int)tl0, to_slab, N, c->d_counters.p + 8, c->pm_rho.p);
+      ma.lo[j] = 0;
+      ma.ext[j] = N;
     }
-  else
+  int rct = pm_deposit_tiles(c, ma, c->pm_rho.p);
+  if(rct == 1)   // no tree level to tile by: one thread per particle
     hipLaunchKernelGGL(k_cic_deposit, dim3(nbp), dim3(bs), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, to_slab, N, ng,
                        c->d_counters.p + 8, c->pm_rho.p);
+  else if(rct)
+    return rct;
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }

@@ -276,6 +276,106 @@ __global__ void k_gradient_gather_brick(const double4 *__restrict__ s_pm, const 
   r_pm[3 * i + 2] = acc[2];
 }
 
+// The same gather in two passes, as on the single mesh (kernels_pm.hip: k_force_mesh + k_gather_force): (1) the 4-point force of
+// every cell of the extended brick whose +-2 neighbours it holds, 3 doubles per cell; (2) the CIC gather of 8 cell forces per
+// particle, the two z-neighbour corners as 48 contiguous bytes.  Same expressions and the same corner order as the fused kernel
+// above, hence bitwise the same GravPM; 8 + 12 loads per particle instead of 96, each with three index wraps.
+__global__ void k_force_mesh_brick(Brick E, int ng, const double *__restrict__ eb, double fac, double *__restrict__ fm)
+{
+  const long long cells = E.cells();
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(idx >= cells * ng)
+    return;
+  const int g = (int)(idx / cells);
+  const long long cell = idx - (long long)g * cells;
+  const int lz = (int)(cell % E.ext[2]), ly = (int)((cell / E.ext[2]) % E.ext[1]), lx = (int)(cell / ((long long)E.ext[1] * E.ext[2]));
+  const double *grid = eb + (size_t)g * cells;
+  // neighbour in local coordinates: a brick that spans the box in a direction (ext = N) wraps, any other must hold it
+  auto nb = [&](int l, int d, int ext) -> int {
+    int v = l + d;
+    if(ext == E.N)
+      v = v < 0 ? v + E.N : (v >= E.N ? v - E.N : v);
+    return (v >= 0 && v < ext) ? v : -1;
+  };
+  const int xm1 = nb(lx, -1, E.ext[0]), xp1 = nb(lx, 1, E.ext[0]), xm2 = nb(lx, -2, E.ext[0]), xp2 = nb(lx, 2, E.ext[0]);
+  const int ym1 = nb(ly, -1, E.ext[1]), yp1 = nb(ly, 1, E.ext[1]), ym2 = nb(ly, -2, E.ext[1]), yp2 = nb(ly, 2, E.ext[1]);
+  const int zm1 = nb(lz, -1, E.ext[2]), zp1 = nb(lz, 1, E.ext[2]), zm2 = nb(lz, -2, E.ext[2]), zp2 = nb(lz, 2, E.ext[2]);
+  if((xm1 | xp1 | xm2 | xp2 | ym1 | yp1 | ym2 | yp2 | zm1 | zp1 | zm2 | zp2) < 0)
+    return;   // a ghost cell: no particle's CIC cloud reaches it
+  auto at = [&](int x, int y, int z) { return grid[((long long)x * E.ext[1] + y) * E.ext[2] + z]; };
+  double *f = fm + 3 * idx;
+  f[0] = fac * ((4.0 / 3) * (at(xm1, ly, lz) - at(xp1, ly, lz)) - (1.0 / 6) * (at(xm2, ly, lz) - at(xp2, ly, lz)));
+  f[1] = fac * ((4.0 / 3) * (at(lx, ym1, lz) - at(lx, yp1, lz)) - (1.0 / 6) * (at(lx, ym2, lz) - at(lx, yp2, lz)));
+  f[2] = fac * ((4.0 / 3) * (at(lx, ly, zm1) - at(lx, ly, zp1)) - (1.0 / 6) * (at(lx, ly, zm2) - at(lx, ly, zp2)));
+}
+
+__global__ void k_gather_force_brick(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                     const unsigned char *__restrict__ s_flag, long long n, double to_slab, WalkParams wp, Brick E,
+                                     const double *__restrict__ fm, double *__restrict__ r_pm)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  if(s_flag[i] & 2)
+    {
+      r_pm[3 * i + 0] = r_pm[3 * i + 1] = r_pm[3 * i + 2] = 0.0;
+      return;
+    }
+  const double4 p = s_pm[i];
+  const double *f = fm + (size_t)wp.t2g[s_type[i]] * 3 * E.cells();
+  double dx, dy, dz;
+  const int sx = cell_of(p.x, to_slab, E.N, &dx), sy = cell_of(p.y, to_slab, E.N, &dy), sz = cell_of(p.z, to_slab, E.N, &dz);
+  const double wx[2] = {1.0 - dx, dx}, wy[2] = {1.0 - dy, dy}, wz[2] = {1.0 - dz, dz};
+  const int lx[2] = {wrapd(sx - E.lo[0], E.N), wrapd(sx + 1 - E.lo[0], E.N)}, ly[2] = {wrapd(sy - E.lo[1], E.N), wrapd(sy + 1 - E.lo[1], E.N)};
+  const int lz0 = wrapd(sz - E.lo[2], E.N), lz1 = wrapd(sz + 1 - E.lo[2], E.N);
+  typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+  const bool zpair = lz1 == lz0 + 1;
+  double fv[8][3];
+#pragma unroll
+  for(int cx = 0; cx < 2; cx++)
+#pragma unroll
+    for(int cy = 0; cy < 2; cy++)
+      {
+        const double *f0 = f + 3 * (((long long)lx[cx] * E.ext[1] + ly[cy]) * E.ext[2] + lz0);
+        const int c0 = 4 * cx + cy, c1 = 4 * cx + cy + 2;   // the two corners of this (x, y): z offset 0 and 1
+        if(zpair)
+          {
+            const d2u a = *reinterpret_cast<const d2u *>(f0), b_ = *reinterpret_cast<const d2u *>(f0 + 2),
+                      c_ = *reinterpret_cast<const d2u *>(f0 + 4);
+            fv[c0][0] = a.x;
+            fv[c0][1] = a.y;
+            fv[c0][2] = b_.x;
+            fv[c1][0] = b_.y;
+            fv[c1][1] = c_.x;
+            fv[c1][2] = c_.y;
+          }
+        else
+          {
+            const double *f1 = f + 3 * (((long long)lx[cx] * E.ext[1] + ly[cy]) * E.ext[2] + lz1);
+#pragma unroll
+            for(int d = 0; d < 3; d++)
+              {
+                fv[c0][d] = f0[d];
+                fv[c1][d] = f1[d];
+              }
+          }
+      }
+  // corner order of the reference's gather (x outer, then y/z as written at pm_periodic.c:749-757)
+  const int ox[8] = {0, 0, 0, 0, 1, 1, 1, 1}, oy[8] = {0, 1, 0, 1, 0, 1, 0, 1}, oz[8] = {0, 0, 1, 1, 0, 0, 1, 1};
+  double acc[3] = {0, 0, 0};
+#pragma unroll
+  for(int c = 0; c < 8; c++)
+    {
+      const double w = wx[ox[c]] * wy[oy[c]] * wz[oz[c]];
+      acc[0] += fv[c][0] * w;
+      acc[1] += fv[c][1] * w;
+      acc[2] += fv[c][2] * w;
+    }
+  r_pm[3 * i + 0] = acc[0];
+  r_pm[3 * i + 1] = acc[1];
+  r_pm[3 * i + 2] = acc[2];
+}
+
 // =============================================================================================================================
 //  host side
 // =============================================================================================================================
@@ -302,6 +402,7 @@ void pmslab_release(ngravs_ctx *c)
   s.slab.release();
   s.tbuf.release();
   s.ebrick.release();
+  s.fmesh.release();
   s.send.release();
   s.recv.release();
   s.desc.release();
@@ -441,9 +542,25 @@ int pmslab_begin(ngravs_ctx *c, int rank, int world, int bbox[6])
   if(bc > 0)
     {
       HIP_TRY(c, hipMemsetAsync(s.brick.p, 0, sizeof(double) * bc * ng, c->stream));
-      WalkParams wp;
-      make_walk_params(c, &wp);
-      hipLaunchKernelGGL(k_cic_deposit_brick, GRIDN(n), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, to_slab, wp, B, s.brick.p);
+      // by tiles (LDS patches of one tree level, as on the single mesh) when the tree is there; else 8 global atomics per particle
+      MeshAddr ma;
+      ma.N = N;
+      ma.brick = 1;
+      for(int j = 0; j < 3; j++)
+        {
+          ma.lo[j] = B.lo[j];
+          ma.ext[j] = B.ext[j];
+        }
+      HIP_TRY(c, hipMemcpyAsync(c->d_counters.p + 8, c->cfg.type_to_grav, sizeof(int) * 6, hipMemcpyHostToDevice, c->stream));
+      const int rct = pm_deposit_tiles(c, ma, s.brick.p);
+      if(rct == 1)
+        {
+          WalkParams wp;
+          make_walk_params(c, &wp);
+          hipLaunchKernelGGL(k_cic_deposit_brick, GRIDN(n), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, to_slab, wp, B, s.brick.p);
+        }
+      else if(rct)
+        return rct;
     }
   HIP_TRY(c, hipGetLastError());
   s.stage = 0;
@@ -744,9 +861,19 @@ int pmslab_unpack(ngravs_ctx *c, int stage)
       WalkParams wp;
       make_walk_params(c, &wp);
       const long long n = c->n;
-      if(n > 0)
+      if(n > 0 && ecells > 0 && c->tune.pm_fused_gather)
         hipLaunchKernelGGL(k_gradient_gather_brick, GRIDN(n), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, N / L, wp, E, s.ebrick.p,
                            fac, c->r_pm.p);
+      else if(n > 0 && ecells > 0)
+        {
+          if(s.fmesh.ensure((size_t)3 * ecells * ng + 1))
+            return NGRAVS_ERR_NOMEM;
+          hipLaunchKernelGGL(k_force_mesh_brick, GRIDN(ecells * ng), 0, c->stream, E, ng, s.ebrick.p, fac, s.fmesh.p);
+          hipLaunchKernelGGL(k_gather_force_brick, GRIDN(n), 0, c->stream, c->s_pm.p, c->s_type.p, c->s_active.p, n, N / L, wp, E, s.fmesh.p,
+                             c->r_pm.p);
+        }
+      else if(n > 0)
+        HIP_TRY(c, hipMemsetAsync(c->r_pm.p, 0, sizeof(double) * 3 * n, c->stream));
       c->have_pm = true;
     }
   HIP_TRY(c, hipGetLastError());

@@ -15,6 +15,24 @@ __device__ __forceinline__ int cell_of(double x, double to_slab, int N, double *
 
 __device__ __forceinline__ int wrapN(int a, int N) { return a < 0 ? a + N : (a >= N ? a - N : a); }
 
+// Where a mesh cell lives: in the full padded mesh [N][N][N+2] of the single-task path, or in a task's brick [ext0][ext1][ext2]
+// of the cells (lo + i) mod N (slab-decomposed path, kernels_pmslab.hip).  The deposit kernels are written once over this.
+struct MeshAddr
+{
+  int N, brick;
+  int lo[3], ext[3];
+  __device__ __forceinline__ long long cell(int x, int y, int z) const   // periodic mesh coordinates, each within [-N, 2N)
+  {
+    if(brick)
+      return ((long long)wrapN(wrapN(x, N) - lo[0], N) * ext[1] + wrapN(wrapN(y, N) - lo[1], N)) * ext[2] + wrapN(wrapN(z, N) - lo[2], N);
+    return ((long long)wrapN(x, N) * N + wrapN(y, N)) * (N + 2) + wrapN(z, N);
+  }
+  __host__ __device__ long long species_stride() const
+  {
+    return brick ? (long long)ext[0] * ext[1] * ext[2] : (long long)N * N * (N + 2);
+  }
+};
+
 struct GreenParams
 {
   int ng, N;
@@ -107,3 +125,5 @@ static inline void make_green_params(const ngravs_ctx *c, GreenParams *gpp)
     }                                                                                       \
   while(0)
 
+// kernels_pm.hip: tiled CIC deposit into a full mesh or a brick (see there)
+int pm_deposit_tiles(ngravs_ctx *c, const MeshAddr &ma, double *dst);

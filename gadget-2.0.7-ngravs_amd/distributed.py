@@ -35,7 +35,7 @@ class DDInfo(C.Structure):
     """struct ngravs_dd_info (include/ngravs_host.h)"""
     _fields_ = [("level", C.c_int32), ("reserved", C.c_int32), ("n_local", C.c_int64), ("n_halo", C.c_int64),
                 ("n_migrated_in", C.c_int64), ("work_balance", C.c_double), ("memory_balance", C.c_double),
-                ("bytes_migration", C.c_double), ("bytes_halo", C.c_double)]
+                ("bytes_migration", C.c_double), ("bytes_halo", C.c_double), ("seconds", C.c_double * 8)]
 
 
 class _DevArray:
@@ -59,16 +59,22 @@ class TorchComm:
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.error = None
+        self.seconds, self.calls = 0.0, 0
         self._cb = (_ALLREDUCE(self._allreduce), _ALLGATHER(self._allgather), _ALLTOALLV(self._alltoallv))
         self.c = Comm(self.rank, self.size, 1, 0, None, *self._cb)
 
     def _guard(self, fn, *a):
+        import time
+        t0 = time.perf_counter()
         try:
             fn(*a)
             return 0
         except Exception as e:          # never let an exception cross the C frame
             self.error = e
             return 1
+        finally:
+            self.seconds += time.perf_counter() - t0     # wall time inside collectives (incl. waiting for the slowest task)
+            self.calls += 1
 
     def _allreduce(self, user, buf, count, dtype, op):
         def run():
@@ -139,6 +145,7 @@ class DistributedEngine(Engine):
         self.level = level
         self.info = DDInfo()
         self.timings = {}
+        self.reset_wall()
         L = self._L = lib()
         L.ngravs_dd_num_local.restype = C.c_int64
         L.ngravs_dd_num_local.argtypes = [C.c_void_p]
@@ -178,6 +185,12 @@ class DistributedEngine(Engine):
     def pmforce_periodic(self):
         self._host(self._L.ngravs_host_pmforce_periodic(self._h, C.byref(self.comm.c)), "ngravs_host_pmforce_periodic")
 
+    def pm_seconds(self):
+        """host wall-clock seconds of the stages of the last slab PM step (ngravs_host_pm_seconds)"""
+        b = (C.c_double * 13)()
+        self._L.ngravs_host_pm_seconds(b)
+        return list(b)
+
     def pm_bytes(self):
         """payload this task sent to other tasks in the four mesh exchanges of the last PM step (bytes)"""
         b = (C.c_double * 4)()
@@ -185,10 +198,33 @@ class DistributedEngine(Engine):
         return list(b)
 
     def compute_accelerations(self, pm_step=True):
+        """One force computation; self.wall = host wall-clock seconds of its three stages and of the collectives inside them
+        (decomposition incl. migration + tree-node import, PM incl. the four plane exchanges, tree walk), summed over the steps
+        since the last reset_wall()."""
+        import time
+        w = self.wall
+        c0, n0 = self.comm.seconds, self.comm.calls
+        t0 = time.perf_counter()
         self.domain_Decomposition()
+        t1 = time.perf_counter()
+        c1 = self.comm.seconds
         if pm_step and self.cfg.pmgrid:
             self.pmforce_periodic()
+        t2 = time.perf_counter()
+        c2 = self.comm.seconds
         self.gravity_tree()
+        t3 = time.perf_counter()
+        w["steps"] += 1
+        w["decomposition_s"] += t1 - t0
+        w["decomposition_collectives_s"] += c1 - c0
+        w["pm_s"] += t2 - t1
+        w["pm_collectives_s"] += c2 - c1
+        w["gravity_tree_s"] += t3 - t2
+        w["collective_calls"] += self.comm.calls - n0
+
+    def reset_wall(self):
+        self.wall = {"steps": 0, "decomposition_s": 0.0, "decomposition_collectives_s": 0.0, "pm_s": 0.0, "pm_collectives_s": 0.0,
+                     "gravity_tree_s": 0.0, "collective_calls": 0}
 
     def get_accel(self, want_pm=False):
         """rows of this task's OWN particles (ids from local_ids()); halo rows are dropped"""

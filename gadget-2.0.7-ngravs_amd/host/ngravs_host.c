@@ -3,10 +3,12 @@
  * same code runs under MPI (host/gadget_glue.c), under RCCL through torch.distributed (distributed.py) and under the
  * shared-memory communicator of host/host_shim_test.c.
  */
+#define _POSIX_C_SOURCE 199309L
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "ngravs_host.h"
 
 #define CHECK(expr)            \
@@ -19,6 +21,13 @@
   while(0)
 
 /* all-to-all-v of library device buffers; counts in bytes.  Without device-capable transport the blocks go through host memory. */
+static double wall_now(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 static int exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const void *dsend, const int64_t *sbytes, void *drecv, const int64_t *rbytes)
 {
   const int W = cm->size;
@@ -231,6 +240,7 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
     info = &local;
   memset(info, 0, sizeof(*info));
   memset(plan, 0, sizeof(*plan));
+  info->seconds[0] = -wall_now();
   CHECK(ngravs_get_config(ctx, &cfg));
   CHECK(ngravs_dd_local_extent(ctx, lo, hi));
   CHECK(cm->allreduce(cm->user, lo, 3, NGRAVS_T_F64, NGRAVS_OP_MIN));
@@ -295,6 +305,7 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
   free(work);
   free(owner_ph);
   free(twork);
+  info->seconds[0] += wall_now();
   return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
 }
 
@@ -515,11 +526,18 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
     rc = NGRAVS_ERR_NOMEM;
   /* top-leaf sums of all tasks (DomainMoment[], forcetree.c:766-850), then every coarser level */
   if(!rc)
-    rc = ngravs_dd_cell_sums(ctx, L, sums + (size_t)off[L] * cw);
+    {
+      info->seconds[2] = -wall_now();
+      rc = ngravs_dd_cell_sums(ctx, L, sums + (size_t)off[L] * cw);
+    }
   if(!rc)
     rc = cm->allreduce(cm->user, sums + (size_t)off[L] * cw, ncell * cw, NGRAVS_T_F64, NGRAVS_OP_SUM);
   if(!rc)
-    rc = ngravs_dd_target_bounds(ctx, bounds);
+    {
+      info->seconds[2] += wall_now();
+      info->seconds[3] = -wall_now();
+      rc = ngravs_dd_target_bounds(ctx, bounds);
+    }
   if(!rc)
     {
       for(d = L - 1; d >= 0; d--)
@@ -599,6 +617,8 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
       for(i = 0; i < ncell; i++)
         if(plan->owner_ph[i] == me)
           need[i] = 0;   /* own cells are here already */
+      info->seconds[3] += wall_now();
+      info->seconds[4] = -wall_now();
       rc = cm->allgather(cm->user, need, allneed, ncell);
     }
   if(!rc)
@@ -626,22 +646,29 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
             }
           rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
         }
+      info->seconds[4] += wall_now();
+      info->seconds[5] = -wall_now();
       if(!rc)
         rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
       if(!rc)
         rc = ngravs_dd_set_halo(ctx, recvbuf, nrecv);
+      info->seconds[5] += wall_now();
       info->n_halo = nrecv;
     }
   if(!rc)
     {
+      info->seconds[6] = -wall_now();
       for(i = 0; i < ncell; i++)
         present[i] = (plan->owner_ph[i] == me || need[i]) ? 1 : 0;
       rc = ngravs_dd_set_top(ctx, L, sums + (size_t)off[L] * cw, present);
+      info->seconds[6] += wall_now();
     }
   if(!rc)
     {
       info->n_local = ngravs_dd_num_local(ctx);
+      info->seconds[7] = -wall_now();
       rc = ngravs_domain_decomposition(ctx);
+      info->seconds[7] += wall_now();
     }
   free(off);
   free(sums);
@@ -664,7 +691,9 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int
   if(!info)
     info = &local;
   CHECK(ngravs_host_domain_owners(ctx, cm, level, paf, &plan, info));
+  info->seconds[1] = -wall_now();
   rc = record_exchange(ctx, cm, &plan, 0, info);
+  info->seconds[1] += wall_now();
   if(!rc)
     rc = ngravs_host_domain_halo(ctx, cm, &plan, info);
   ngravs_host_plan_free(&plan);
@@ -672,6 +701,15 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int
 }
 
 /* ---- pmforce_periodic on the slab-decomposed mesh -------------------------------------------------------------------------- */
+static double pm_seconds[13];   /* last call: [0] deposit + bounding boxes, then per stage s: [1+3s] pack, [2+3s] exchange, [3+3s] unpack */
+
+void ngravs_host_pm_seconds(double out[13])
+{
+  int i;
+  for(i = 0; i < 13; i++)
+    out[i] = pm_seconds[i];
+}
+
 int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
 {
   const int W = cm->size;
@@ -690,21 +728,30 @@ int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
       return NGRAVS_ERR_NOMEM;
     }
   rc_ = sc + W;
+  memset(pm_seconds, 0, sizeof(pm_seconds));
+  pm_seconds[0] = -wall_now();
   rc = ngravs_pm_slab_begin(ctx, cm->rank, W, bb);
   if(!rc)
     rc = cm->allgather(cm->user, bb, all, (int64_t)sizeof(bb));   /* meshmin/meshmax lists, pm_periodic.c:285-291 */
+  pm_seconds[0] += wall_now();
   for(stage = 0; stage < 4 && !rc; stage++)
     {
+      double t0 = wall_now(), t1;
       rc = ngravs_pm_slab_pack(ctx, stage, all, sc, rc_, &send, &recv);
       for(r = 0; r < W; r++)
         {
           sc[r] *= (int64_t)sizeof(double);
           rc_[r] *= (int64_t)sizeof(double);
         }
+      t1 = wall_now();
+      pm_seconds[1 + 3 * stage] = t1 - t0;
       if(!rc)
         rc = exchange(ctx, cm, send, sc, recv, rc_);
+      t0 = wall_now();
+      pm_seconds[2 + 3 * stage] = t0 - t1;
       if(!rc)
         rc = ngravs_pm_slab_unpack(ctx, stage);
+      pm_seconds[3 + 3 * stage] = wall_now() - t0;
     }
   free(all);
   free(sc);

@@ -54,6 +54,10 @@ typedef struct ngravs_dd_info
   double work_balance;        /* max over tasks of the work sum / mean (the reference's "work-load balance")     */
   double memory_balance;      /* max over tasks of the particle count / mean ("memory-balance")                  */
   double bytes_migration, bytes_halo;   /* payload this task sent to other tasks                                 */
+  /* host wall-clock seconds of the stages of the last decomposition (collectives inside them included): 0 extent + histogram +
+   * split, 1 migration, 2 top-cell sums + all-reduce, 3 need test (host), 4 request all-gather + pack of the requested cells,
+   * 5 import exchange + unpack, 6 global top, 7 local decomposition (keys, sort, gather) */
+  double seconds[8];
 } ngravs_dd_info;
 
 /* The cut of the curve: owner of every decomposition cell, in Peano-cell order and in [x][y][z] order */
@@ -81,6 +85,10 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *comm, int leve
 int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *comm, const ngravs_dd_plan *plan, ngravs_dd_info *info);
 void ngravs_host_plan_free(ngravs_dd_plan *plan);
 int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *comm);
+/* host wall-clock seconds of the last ngravs_host_pmforce_periodic() of this process: [0] brick deposit + bounding-box all-gather,
+ * then for the four exchanges s = 0..3: [1+3s] pack (incl. the FFTs and the Green's function that precede it), [2+3s] the
+ * all-to-all-v, [3+3s] unpack (stage 3: + gradient and gather) */
+void ngravs_host_pm_seconds(double out[13]);
 int ngravs_host_compute_accelerations(ngravs_ctx *ctx, const ngravs_comm *comm, int pm_step, ngravs_dd_info *info);
 
 /* The split alone (host arrays, no communication): owner[cell] for the 8^level cells in Peano order, from the global count
