@@ -111,28 +111,11 @@ __global__ void k_gradient_gather(const double4 *__restrict__ s_pm, const unsign
 // streamed; (2) the CIC gather of 8 cell forces per particle (8 x 24 contiguous bytes instead of 96 scattered potential
 // reads).  Same expressions and the same corner order as k_gradient_gather, hence identical results.
 // ---------------------------------------------------------------------------------------------------
-__global__ void k_force_mesh(const double *__restrict__ grid, int N, double fac, double *__restrict__ fm)
-{
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const long long NN = (long long)N * N * N;
-  if(idx >= NN)
-    return;
-  const int z = (int)(idx % N), y = (int)((idx / N) % N), x = (int)(idx / ((long long)N * N));
-  const long long NZ = N + 2;
-  auto wrap = [N](int a) { return a < 0 ? a + N : (a >= N ? a - N : a); };
-  auto at = [&](int xx, int yy, int zz) { return grid[((long long)xx * N + yy) * NZ + zz]; };
-  fm[3 * idx + 0] = fac * ((4.0 / 3) * (at(wrap(x - 1), y, z) - at(wrap(x + 1), y, z)) -
-                           (1.0 / 6) * (at(wrap(x - 2), y, z) - at(wrap(x + 2), y, z)));
-  fm[3 * idx + 1] = fac * ((4.0 / 3) * (at(x, wrap(y - 1), z) - at(x, wrap(y + 1), z)) -
-                           (1.0 / 6) * (at(x, wrap(y - 2), z) - at(x, wrap(y + 2), z)));
-  fm[3 * idx + 2] = fac * ((4.0 / 3) * (at(x, y, wrap(z - 1)) - at(x, y, wrap(z + 1))) -
-                           (1.0 / 6) * (at(x, y, wrap(z - 2)) - at(x, y, wrap(z + 2))));
-}
-
-// The same force mesh by marching along x: a block of 8 (y) x 32 (z) threads owns a column of FM_XB planes, every thread keeps
+// The force mesh by marching along x: a block of 8 (y) x 32 (z) threads owns a column of FM_XB planes, every thread keeps
 // the five potentials x-2 .. x+2 of its (y, z) in registers, so each potential is read from memory once as the new "x+2" value
-// (the one-thread-per-cell kernel above re-reads every plane five times from far apart: measured 3.2 GB fetched per species
-// for a 1.07 GB mesh); the y and z neighbours are neighbours' lines of the plane just loaded (cache hits).  Same expressions.
+// (a one-thread-per-cell kernel re-reads every plane five times from far apart: measured 3.2 GB fetched per species for a
+// 1.07 GB mesh); the y and z neighbours are neighbours' lines of the plane just loaded (cache hits).  Same expressions as
+// k_gradient_gather.
 #define FM_XB 64
 __global__ __launch_bounds__(256) void k_force_mesh_march(const double *__restrict__ grid, int N, double fac, double *__restrict__ fm)
 {
@@ -676,7 +659,7 @@ int pm_finish(ngravs_ctx *c)
     }
   else if(nbg > 0 && c->cfg.world_size <= 2 && !c->tune.pm_fused_gather)
     {
-      // two passes per target species (see k_force_mesh); with many tasks the (replicated) force-mesh pass would cost more
+      // two passes per target species (see k_force_mesh_march); with many tasks the (replicated) force-mesh pass would cost more
       // than the sharded fused gather below
       const long long NN = (long long)N * N * N;
       const bool all_resident = (size_t)3 * NN * ng * sizeof(double) <= ((size_t)16 << 30);   // C4: 6.4 GB; C5 (77 GB): per species

@@ -276,7 +276,7 @@ __global__ void k_gradient_gather_brick(const double4 *__restrict__ s_pm, const 
   r_pm[3 * i + 2] = acc[2];
 }
 
-// The same gather in two passes, as on the single mesh (kernels_pm.hip: k_force_mesh + k_gather_force): (1) the 4-point force of
+// The same gather in two passes, as on the single mesh (kernels_pm.hip: k_force_mesh_march + k_gather_force): (1) the 4-point force of
 // every cell of the extended brick whose +-2 neighbours it holds, 3 doubles per cell; (2) the CIC gather of 8 cell forces per
 // particle, the two z-neighbour corners as 48 contiguous bytes.  Same expressions and the same corner order as the fused kernel
 // above, hence bitwise the same GravPM; 8 + 12 loads per particle instead of 96, each with three index wraps.
