@@ -662,7 +662,13 @@ int pm_finish(ngravs_ctx *c)
       // two passes per target species (see k_force_mesh_march); with many tasks the (replicated) force-mesh pass would cost more
       // than the sharded fused gather below
       const long long NN = (long long)N * N * N;
-      const bool all_resident = (size_t)3 * NN * ng * sizeof(double) <= ((size_t)16 << 30);   // C4: 6.4 GB; C5 (77 GB): per species
+      // all species' force meshes at once (one gather pass) when the device has the room beside what the walk will ask for:
+      // C4 6.4 GB; C5 77 GB, which a 288 GB device holds
+      const size_t fm_all = (size_t)3 * NN * ng * sizeof(double), fm_have = c->pm_force.cap * sizeof(double);
+      size_t free_b = 0, total_b = 0;
+      bool all_resident = fm_all <= ((size_t)16 << 30) || fm_have >= fm_all;
+      if(!all_resident && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        all_resident = free_b + fm_have >= fm_all + ((size_t)48 << 30);
       if(c->pm_force.ensure((size_t)(3 * NN) * (all_resident ? ng : 1)))
         return NGRAVS_ERR_NOMEM;
       if(all_resident)
