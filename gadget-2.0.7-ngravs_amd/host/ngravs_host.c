@@ -20,7 +20,38 @@
     }                          \
   while(0)
 
-/* all-to-all-v of library device buffers; counts in bytes.  Without device-capable transport the blocks go through host memory. */
+/* Peano-Hilbert key of every cell (x, y, z) of level d, [x][y][z] order: depends on the level only, so it is computed once per
+ * process (three loops over 8^level cells per step cost 3 ms each at level 5).  Lock-free publication: a second thread that
+ * raced builds the same table and drops it. */
+static int32_t *ph_tables[8];
+static const int32_t *ph_table(int d)
+{
+  int32_t *t;
+  int x, y, z, nc;
+  if(d < 0 || d > 7)
+    return NULL;
+  t = __atomic_load_n(&ph_tables[d], __ATOMIC_ACQUIRE);
+  if(t)
+    return t;
+  nc = 1 << d;
+  t = malloc(sizeof(int32_t) * ((size_t)nc * nc * nc));
+  if(!t)
+    return NULL;
+  for(x = 0; x < nc; x++)
+    for(y = 0; y < nc; y++)
+      for(z = 0; z < nc; z++)
+        t[((size_t)x * nc + y) * nc + z] = (int32_t)ngravs_peano_hilbert_key(x, y, z, d);
+  {
+    int32_t *expected = NULL;
+    if(!__atomic_compare_exchange_n(&ph_tables[d], &expected, t, 0, __ATOMIC_RELEASE, __ATOMIC_ACQUIRE))
+      {
+        free(t);
+        t = expected;
+      }
+  }
+  return t;
+}
+
 static double wall_now(void)
 {
   struct timespec ts;
@@ -28,6 +59,7 @@ static double wall_now(void)
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+/* all-to-all-v of library device buffers; counts in bytes.  Without device-capable transport the blocks go through host memory. */
 static int exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const void *dsend, const int64_t *sbytes, void *drecv, const int64_t *rbytes)
 {
   const int W = cm->size;
@@ -291,10 +323,16 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
         }
       info->work_balance = wtot > 0 ? wmax / (wtot / W) : 1.0;
       info->memory_balance = total > 0 ? cmax / (total / W) : 1.0;
-      for(x = 0; x < nc; x++)
-        for(y = 0; y < nc; y++)
-          for(z = 0; z < nc; z++)
-            owner_xyz[((size_t)x * nc + y) * nc + z] = owner_ph[ngravs_peano_hilbert_key(x, y, z, level)];
+      {
+        const int32_t *pht = ph_table(level);
+        if(!pht)
+          rc = NGRAVS_ERR_NOMEM;
+        else
+          for(x = 0; x < nc; x++)
+            for(y = 0; y < nc; y++)
+              for(z = 0; z < nc; z++)
+                owner_xyz[((size_t)x * nc + y) * nc + z] = owner_ph[pht[((size_t)x * nc + y) * nc + z]];
+      }
       plan->level = level;
       plan->ncell = ncell;
       plan->owner_ph = owner_ph;
@@ -545,22 +583,32 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
           for(k = 0; k < 8; k++)
             for(j = 0; j < cw; j++)
               sums[(size_t)(off[d] + i) * cw + j] += sums[(size_t)(off[d + 1] + i * 8 + k) * cw + j];
-      for(d = 0; d <= L; d++)
-        for(x = 0; x < (1 << d); x++)
-          for(y = 0; y < (1 << d); y++)
-            for(z = 0; z < (1 << d); z++)
-              xyz[off[d] + ngravs_peano_hilbert_key(x, y, z, d)] = x | (y << 10) | (z << 20);
+      for(d = 0; d <= L && !rc; d++)
+        {
+          const int32_t *pht = ph_table(d);
+          const int ncd = 1 << d;
+          if(!pht)
+            {
+              rc = NGRAVS_ERR_NOMEM;
+              break;
+            }
+          for(x = 0; x < ncd; x++)
+            for(y = 0; y < ncd; y++)
+              for(z = 0; z < ncd; z++)
+                xyz[off[d] + pht[((size_t)x * ncd + y) * ncd + z]] = x | (y << 10) | (z << 20);
+        }
       /* boxes around the own cells that hold particles, one per coarse (<= 4^3) block of the domain grid */
       {
         const int csh = L > 2 ? L - 2 : 0;
         const double cl = dom[6] / nc;
+        const int32_t *phL = ph_table(L);
         for(k = 0; k < 64; k++)
           used[k] = 0;
         for(x = 0; x < nc; x++)
           for(y = 0; y < nc; y++)
             for(z = 0; z < nc; z++)
               {
-                const int64_t cell = ngravs_peano_hilbert_key(x, y, z, L);
+                const int64_t cell = phL ? phL[((size_t)x * nc + y) * nc + z] : ngravs_peano_hilbert_key(x, y, z, L);
                 const int cxyz[3] = {x, y, z};
                 if(plan->owner_ph[cell] != me || sums[(size_t)(off[L] + cell) * cw] < 0.5)
                   continue;
