@@ -456,6 +456,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.pm_fused_gather = iv != 0;
   else if(k == "pm_tile_gather")
     t.pm_tile_gather = iv != 0;
+  else if(k == "sort_full")
+    t.sort_full = iv != 0;
   else if(k == "pm_tile8")
     t.pm_tile8 = iv != 0;
   else if(k == "tree_levelwise")

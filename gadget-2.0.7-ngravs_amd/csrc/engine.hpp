@@ -119,6 +119,7 @@ struct Tuning
   int walk_fused = 0, walk_waves = 0, walk_lcap = 0, walk_root = 0, walk_compact = 1, walk_spread = 0, walk_exact_reach = 0, walk_sg = 0, walk_nleaf = -1;
   long long walk_batch = 0;
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0, pm_tile8 = 0;
+  int sort_full = 0;        // Peano order by one radix sort on all 63 key bits (default: top 42 bits + fix-up of the rare ties)
   int tree_levelwise = 0;   // build the tree level by level (the multi-task path) also for single-task trees
 };
 

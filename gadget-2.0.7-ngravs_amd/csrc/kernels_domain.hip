@@ -182,6 +182,48 @@ __global__ void k_gather(const unsigned int *__restrict__ idx, long long n, cons
   s_active[i] = (unsigned char)((meta >> 8) & 255);
 }
 
+// Two-stage sort: a stable radix sort on the TOP bits of the key only (SORT_TOP_BITS of the 63: 6 passes instead of 9), then every run of
+// equal top bits -- rare and short: 2^42 cells for the particles to share -- is put in order of its low bits by the thread that
+// finds its head (stable insertion sort of the (key, index) pairs in place).  The result is exactly that of a stable sort on all
+// 63 bits.  A run longer than SORT_RUN_MAX (a pathological clump below 1/16384 of the domain) raises a flag and the caller
+// sorts again on all bits.
+#define SORT_LOW_BITS 21
+#define SORT_RUN_MAX 64
+__global__ void k_sort_fixup(unsigned long long *__restrict__ key, unsigned int *__restrict__ idx, long long n, int *__restrict__ flag)
+{
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  const unsigned long long top = key[i] >> SORT_LOW_BITS;
+  if(i > 0 && (key[i - 1] >> SORT_LOW_BITS) == top)
+    return;   // not the head of a run
+  long long e = i + 1;
+  while(e < n && e - i <= SORT_RUN_MAX && (key[e] >> SORT_LOW_BITS) == top)
+    e++;
+  const int r = (int)(e - i);
+  if(r < 2)
+    return;
+  if(r > SORT_RUN_MAX)
+    {
+      *flag = 1;
+      return;
+    }
+  for(int a = 1; a < r; a++)   // stable insertion sort by the full key
+    {
+      const unsigned long long k = key[i + a];
+      const unsigned int v = idx[i + a];
+      int b = a - 1;
+      while(b >= 0 && key[i + b] > k)
+        {
+          key[i + b + 1] = key[i + b];
+          idx[i + b + 1] = idx[i + b];
+          b--;
+        }
+      key[i + b + 1] = k;
+      idx[i + b + 1] = v;
+    }
+}
+
 int dom_keys_and_sort(ngravs_ctx *c)
 {
   const long long n = c->n;
@@ -197,10 +239,23 @@ int dom_keys_and_sort(ngravs_ctx *c)
   size_t tmp_bytes = 0;
   (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p, c->s_idx.p, (int)n, 0,
                                      3 * TREE_BITS, c->stream);
-  if(c->sort_tmp.ensure(tmp_bytes))
+  if(c->sort_tmp.ensure(tmp_bytes) || c->d_counters.ensure(16))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
-                                                c->s_idx.p, (int)n, 0, 3 * TREE_BITS, c->stream));
+  bool full = c->tune.sort_full != 0 || n < 4096;
+  if(!full)
+    {
+      int h_flag = 0;
+      HIP_TRY(c, hipMemsetAsync(c->d_counters.p + 15, 0, sizeof(int), c->stream));
+      HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
+                                                    c->s_idx.p, (int)n, SORT_LOW_BITS, 3 * TREE_BITS, c->stream));
+      hipLaunchKernelGGL(k_sort_fixup, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->s_idx.p, n, c->d_counters.p + 15);
+      HIP_TRY(c, hipMemcpyAsync(&h_flag, c->d_counters.p + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      full = h_flag != 0;   // a clump too dense for the fix-up: sort on all bits
+    }
+  if(full)
+    HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
+                                                  c->s_idx.p, (int)n, 0, 3 * TREE_BITS, c->stream));
   hipLaunchKernelGGL(k_gather, dim3(nb), dim3(bs), 0, c->stream, c->s_idx.p, n, c->in_rec.p, c->s_pm.p, c->s_type.p,
                      c->s_oldacc.p, c->s_active.p);
   HIP_TRY(c, hipGetLastError());

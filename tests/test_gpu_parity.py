@@ -467,6 +467,33 @@ def test_one_pass_build_is_the_levelwise_tree(pkg, O):
         print("one-pass == level-wise: n=%d, %d nodes" % (n, res[0][2]))
 
 
+def test_two_stage_sort_is_the_full_sort(pkg, O):
+    """Peano order by a radix sort on the top 42 key bits + a stable fix-up of the runs that tie there == a stable radix sort on
+    all 63 bits (tuning sort_full): bitwise equal reference-walk forces, equal interaction counts and node counts -- with
+    pairs that share their top bits (particles 1e-6 apart), a clump of 40 coincident particles (fixed up in place) and a clump of
+    300 (longer than the fix-up allows: falls back to the full sort)."""
+    rng = np.random.default_rng(11)
+    n = 60000
+    pos = rng.uniform(0, 1, (n, 3))
+    pos[1000:1400] = pos[500:900] + rng.uniform(0, 1e-6, (400, 3))   # close pairs: equal top bits, different low bits
+    for clump in (40, 300):
+        p2 = pos.copy()
+        p2[2000:2000 + clump] = p2[2000]
+        mass = rng.uniform(0.5, 1.5, n) / n
+        typ = np.ones(n, dtype=np.int32)
+        cfg = pkg.make_config(n_gravs=1, G=1.0, theta=0.5, softening=[0.004] * 6, tree_alloc_factor=2.5)
+        cfg.walk_mode = pkg.WALK_STRICT
+        res = []
+        for full in (0, 1):
+            eng = _engine(pkg, cfg, p2, mass, typ, tuning=dict(sort_full=full))
+            eng.compute_accelerations(pm_step=False)
+            acc, old, cost = eng.get_accel()
+            res.append((acc.copy(), cost.copy(), eng.stats().n_nodes))
+            eng.close()
+        assert res[0][2] == res[1][2]
+        assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0], res[1][0])
+
+
 def test_grav_pm_handed_over_with_the_particles(pkg, O):
     """A PM step followed by a non-PM step that goes through set_particles again (TreeDomainUpdateFrequency = 0: the glue
     re-decomposes every step).  P[].GravPM lives in the host's P[] between PM steps; handed over with the particles it must
