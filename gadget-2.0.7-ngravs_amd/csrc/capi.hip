@@ -139,27 +139,6 @@ __global__ void k_map_idx(const int *inv, const int *in, long long n, int *out)
   if(i < n)
     out[i] = inv[in[i]];
 }
-__global__ void k_sum_active(const unsigned char *act, const int *nint, long long first, long long count, double *out)
-{
-  double s = 0, a = 0;
-  for(long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < count; k += (long long)gridDim.x * blockDim.x)
-    if(act[first + k] & 1)
-      {
-        s += nint[first + k];
-        a += 1;
-      }
-  for(int off = 32; off > 0; off >>= 1)
-    {
-      s += __shfl_down(s, off);
-      a += __shfl_down(a, off);
-    }
-  if((threadIdx.x & 63) == 0)
-    {
-      atomicAdd(&out[0], s);
-      atomicAdd(&out[1], a);
-    }
-}
-
 #define GRID1(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
 // ---- lifecycle --------------------------------------------------------------------------------
@@ -812,12 +791,7 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
   (void)hipEventElapsedTime(&kms, c->evk0, c->evk1);
   c->stats.walk_kernel_ms = kms;
   // Nf and interaction sum (gravtree.c:74-78, 408-447)
-  if(c->red_tmp.ensure(2))
-    return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(c->red_tmp.p, 0, 2 * sizeof(double), c->stream));
-  hipLaunchKernelGGL(k_sum_active, dim3(512), dim3(256), 0, c->stream, c->s_active.p, c->r_nint.p, (long long)c->shard_first,
-                     (long long)c->shard_count, c->red_tmp.p);
-  double h[2] = {0, 0};
+  double h[2] = {0, 0};   // summed by k_finish
   HIP_TRY(c, hipMemcpyAsync(h, c->red_tmp.p, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->stats.interactions = h[0];

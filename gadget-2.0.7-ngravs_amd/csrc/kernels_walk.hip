@@ -1893,15 +1893,27 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
 // =============================================================================================
 //  post-processing (gravtree.c:318-341): OldAcc = |GravAccel + GravPM/G|, GravAccel *= G
 // =============================================================================================
+// (also Nf and the interaction sum of gravtree.c:74-78, 408-447: sums[0] += interactions of the walked particles, sums[1] += their
+// number, one pair of atomics per wave)
 __global__ void k_finish(long long t_first, long long t_count, const unsigned char *__restrict__ s_active,
                          double *__restrict__ r_acc, const double *__restrict__ r_pm, double *__restrict__ r_oldacc,
-                         double G, int have_pm)
+                         double G, int have_pm, const int *__restrict__ r_nint, double *__restrict__ sums)
 {
   long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(k >= t_count)
-    return;
-  long long i = t_first + k;
-  if(!(s_active[i] & 1))
+  const long long i = t_first + k;
+  const bool act = k < t_count && (s_active[i] & 1);
+  {
+    double s = act ? (double)r_nint[i] : 0.0;
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+    for(int off = 32; off > 0; off >>= 1)
+      s += __shfl_down(s, off);
+    if((threadIdx.x & 63) == 0 && am)
+      {
+        atomicAdd(&sums[0], s);
+        atomicAdd(&sums[1], (double)__popcll(am));
+      }
+  }
+  if(!act)
     return;
   double ax = r_acc[3 * i], ay = r_acc[3 * i + 1], az = r_acc[3 * i + 2];
   double bx = ax, by = ay, bz = az;
@@ -2601,10 +2613,14 @@ int walk_finish(ngravs_ctx *c)
 {
   const int bs = 256;
   unsigned nb = (unsigned)((c->shard_count + bs - 1) / bs);
+  if(c->red_tmp.ensure(2))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->red_tmp.p, 0, 2 * sizeof(double), c->stream));   // read back by ngravs_gravity_tree
   if(nb == 0)
     return NGRAVS_OK;
   hipLaunchKernelGGL(k_finish, dim3(nb), dim3(bs), 0, c->stream, (long long)c->shard_first, (long long)c->shard_count,
-                     c->s_active.p, c->r_acc.p, c->r_pm.p, c->r_oldacc.p, c->cfg.G, (c->have_pm && c->cfg.pmgrid) ? 1 : 0);
+                     c->s_active.p, c->r_acc.p, c->r_pm.p, c->r_oldacc.p, c->cfg.G, (c->have_pm && c->cfg.pmgrid) ? 1 : 0,
+                     c->r_nint.p, c->red_tmp.p);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }
