@@ -1894,39 +1894,43 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
 //  post-processing (gravtree.c:318-341): OldAcc = |GravAccel + GravPM/G|, GravAccel *= G
 // =============================================================================================
 // (also Nf and the interaction sum of gravtree.c:74-78, 408-447: sums[0] += interactions of the walked particles, sums[1] += their
-// number, one pair of atomics per wave)
+// number.  Grid-stride over the targets with a few thousand waves, so that the two atomics per wave at the end stay a few
+// thousand: one pair per 64 particles -- a million atomics on two addresses -- cost 25 ms.)
 __global__ void k_finish(long long t_first, long long t_count, const unsigned char *__restrict__ s_active,
                          double *__restrict__ r_acc, const double *__restrict__ r_pm, double *__restrict__ r_oldacc,
                          double G, int have_pm, const int *__restrict__ r_nint, double *__restrict__ sums)
 {
-  long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const long long i = t_first + k;
-  const bool act = k < t_count && (s_active[i] & 1);
-  {
-    double s = act ? (double)r_nint[i] : 0.0;
-    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
-    for(int off = 32; off > 0; off >>= 1)
-      s += __shfl_down(s, off);
-    if((threadIdx.x & 63) == 0 && am)
-      {
-        atomicAdd(&sums[0], s);
-        atomicAdd(&sums[1], (double)__popcll(am));
-      }
-  }
-  if(!act)
-    return;
-  double ax = r_acc[3 * i], ay = r_acc[3 * i + 1], az = r_acc[3 * i + 2];
-  double bx = ax, by = ay, bz = az;
-  if(have_pm)
+  double s = 0, na = 0;
+  for(long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < t_count; k += (long long)gridDim.x * blockDim.x)
     {
-      bx += r_pm[3 * i] / G;
-      by += r_pm[3 * i + 1] / G;
-      bz += r_pm[3 * i + 2] / G;
+      const long long i = t_first + k;
+      if(!(s_active[i] & 1))
+        continue;
+      s += (double)r_nint[i];
+      na += 1.0;
+      double ax = r_acc[3 * i], ay = r_acc[3 * i + 1], az = r_acc[3 * i + 2];
+      double bx = ax, by = ay, bz = az;
+      if(have_pm)
+        {
+          bx += r_pm[3 * i] / G;
+          by += r_pm[3 * i + 1] / G;
+          bz += r_pm[3 * i + 2] / G;
+        }
+      r_oldacc[i] = sqrt(bx * bx + by * by + bz * bz);
+      r_acc[3 * i] = ax * G;
+      r_acc[3 * i + 1] = ay * G;
+      r_acc[3 * i + 2] = az * G;
     }
-  r_oldacc[i] = sqrt(bx * bx + by * by + bz * bz);
-  r_acc[3 * i] = ax * G;
-  r_acc[3 * i + 1] = ay * G;
-  r_acc[3 * i + 2] = az * G;
+  for(int off = 32; off > 0; off >>= 1)
+    {
+      s += __shfl_down(s, off);
+      na += __shfl_down(na, off);
+    }
+  if((threadIdx.x & 63) == 0 && na > 0)
+    {
+      atomicAdd(&sums[0], s);
+      atomicAdd(&sums[1], na);
+    }
 }
 
 // =============================================================================================
@@ -2613,6 +2617,7 @@ int walk_finish(ngravs_ctx *c)
 {
   const int bs = 256;
   unsigned nb = (unsigned)((c->shard_count + bs - 1) / bs);
+  nb = nb > 4096u ? 4096u : nb;   // grid-stride: see k_finish
   if(c->red_tmp.ensure(2))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->red_tmp.p, 0, 2 * sizeof(double), c->stream));   // read back by ngravs_gravity_tree
