@@ -1197,13 +1197,18 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         // items are neighbours in space, so element b of 64 quads spread over the list is still an even sample of the whole
         // neighbourhood, and the list is read with a quarter of the cache lines a 4-byte gather per chunk touches), quads in a
         // golden-ratio stride order: quad (i * s) mod nq is visited i-th, s coprime with nq.
+        // (The stride runs over M = 64 * nsuper slots, the quads padded to whole super-chunks: an ODD stride is coprime with 64, so only
+        // the small factor nsuper is left for Euclid -- integer remainders are long instruction sequences on this hardware, and the
+        // golden-ratio neighbourhood is its worst case; the at most 63 empty slots are skipped.)
         const int nq = (n + 3) >> 2;
-        int s_ = (int)(0.6180339887498949 * nq) | 1;
-        if(s_ >= nq)
+        const int nsuper = (nq + WAVE - 1) / WAVE, nchunks = 4 * nsuper;
+        const int M = nsuper * WAVE;
+        int s_ = (int)(0.6180339887498949 * M) | 1;
+        if(s_ >= M)
           s_ = 1;
         for(;;)
           {
-            int a = s_, b = nq;
+            int a = nsuper, b = s_ % nsuper;
             while(b)
               {
                 int t = a % b;
@@ -1213,30 +1218,29 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
             if(a == 1)
               break;
             s_ += 2;
-            if(s_ >= nq)
+            if(s_ >= M)
               {
                 s_ = 1;
                 break;
               }
           }
-        const int step64 = (int)((64ll * s_) % nq);
-        int slot = (int)(((long long)lane * s_) % nq);
+        const int step64 = (int)((64ll * s_) % M);
+        int slot = (int)(((long long)lane * s_) % M);
         int npool = 0;
-        const int nsuper = (nq + WAVE - 1) / WAVE, nchunks = 4 * nsuper;
         // one extra pass (cc == nchunks) only drains what is left in the pool, so that the force loop exists once.
         // Software pipeline on the memory side: while chunk c is evaluated, the source records of chunk c+1 are in flight, and
         // the quad of item indices of the NEXT four chunks was requested four chunks ago.
         auto fetch_quad = [&](int sc, int4 &v, int &nvalid) {
           v.x = v.y = v.z = v.w = 0;
           nvalid = 0;
-          if(sc < nsuper && sc * WAVE + lane < nq)
+          if(sc < nsuper && slot < nq)
             {
               v = reinterpret_cast<const int4 *>(items)[slot];
               nvalid = n - 4 * slot;
               nvalid = nvalid > 4 ? 4 : nvalid;
             }
           slot += step64;
-          slot = slot >= nq ? slot - nq : slot;
+          slot = slot >= M ? slot - M : slot;
         };
         auto fetch_rec = [&](bool hv, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
           // (without a record q and hs keep their previous contents: the consumer tests `have` first)
