@@ -49,15 +49,20 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def _strict_worker(rank, world, port, out_dir, case):
+def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
     """the reference's walk (per-target decisions) on `world` tasks: top-leaf moments + imported top cells"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
     import importlib
+    import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     dd = importlib.import_module("ngravs_amd.distributed")
     pos, mass, typ, old, cfg = _strict_case(pkg, case)
@@ -119,6 +124,32 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
     err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1, axis=1)
     print("%s: 3 tasks vs 1, reference walk: max |da|/|a| = %.2e, interaction counts equal: %s (%.1f per particle)" %
           (case, err.max(), np.array_equal(cost, c1), c1.mean()))
+    assert np.array_equal(cost, c1)
+    assert err.max() < 1e-10
+
+
+def test_one_task_over_rccl(pkg, tmp_path):
+    """The production backend: torch.distributed "nccl" (= RCCL) on the library's DEVICE buffers -- all-reduce of doubles and
+    64-bit integers (sum / min / max), all-gather, all-to-all-v of byte blocks straight from and into library memory.  One GPU on
+    the box means one task; every collective of the decomposition, the import and the four PM exchanges still goes through RCCL
+    (`TorchComm`'s nccl branches).  TreePM, reference walk: the single-task engine's forces, identical interaction counts."""
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_strict_worker, args=(1, port, str(tmp_path), "c4", "nccl"), nprocs=1, join=True)
+    pos, mass, typ, old, cfg = _strict_case(pkg, "c4")
+    n = len(pos)
+    d = np.load(os.path.join(str(tmp_path), "s0.npz"))
+    assert np.array_equal(np.sort(d["ids"]), np.arange(n))
+    acc, cost = np.zeros((n, 3)), np.zeros(n)
+    acc[d["ids"]] = d["acc"]
+    cost[d["ids"]] = d["cost"]
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=old)
+    eng.compute_accelerations(pm_step=True)
+    a1, _, c1 = eng.get_accel()
+    eng.close()
+    err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1, axis=1)
+    print("one task over RCCL vs the single-task engine: max |da|/|a| = %.2e" % err.max())
     assert np.array_equal(cost, c1)
     assert err.max() < 1e-10
 
