@@ -433,36 +433,74 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v)
     v |= __shfl_xor(v, off);
   return v;
 }
-__global__ void k_dd_count(const unsigned long long *__restrict__ mask, long long n, int nranks, unsigned long long *__restrict__ counts)
+// Counters that every particle bumps are bumped once per BLOCK: atomics on one address are served one after the other (≈ 12 ns
+// each on the MI355X -- one per wave of 8.4 M particles was 1.6 ms), so the waves of a block first add up in LDS.
+#define DD_CNT_BLOCKS 1024
+__global__ __launch_bounds__(256) void k_dd_count(const unsigned long long *__restrict__ mask, long long n, int nranks,
+                                                  unsigned long long *__restrict__ counts)
 {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  __shared__ unsigned int cnt[65];
+  for(int t = threadIdx.x; t < 65; t += blockDim.x)
+    cnt[t] = 0;
+  __syncthreads();
   const int lane = threadIdx.x & 63;
+  unsigned int nstay = 0;
+  for(long long base = blockIdx.x * (long long)blockDim.x; base < n; base += gridDim.x * (long long)blockDim.x)
+    {
+      const long long i = base + threadIdx.x;
+      const unsigned long long m = i < n ? mask[i] : 0ull;
+      unsigned long long any = wave_or64(m);
+      while(any)
+        {
+          const int r = __builtin_ctzll(any);
+          any &= any - 1;
+          const unsigned long long b = __builtin_amdgcn_ballot_w64(((m >> r) & 1ull) != 0);
+          if(lane == 0)
+            atomicAdd(&cnt[r], (unsigned int)__popcll(b));
+        }
+      nstay += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(i < n && m == 0));   // stays / not exported
+    }
+  if(lane == 0 && nstay)
+    atomicAdd(&cnt[nranks], nstay);
+  __syncthreads();
+  for(int t = threadIdx.x; t <= nranks; t += blockDim.x)
+    if(cnt[t])
+      atomicAdd(&counts[t], (unsigned long long)cnt[t]);
+}
+
+// records of the exported particles, grouped by destination: a block reserves its share of every destination's range with one
+// atomic (waves take their places inside it through LDS)
+#define DD_FILL_THREADS 1024
+__global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long long *__restrict__ mask, long long n,
+                                                              const double *__restrict__ pos, const double *__restrict__ mass,
+                                                              const int *__restrict__ type, const double *__restrict__ oldacc,
+                                                              const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                                                              const double *__restrict__ cost, const unsigned long long *__restrict__ offs,
+                                                              unsigned long long *__restrict__ cursor, DDRecord *__restrict__ out)
+{
+  __shared__ unsigned int lcnt[64];                                 // per destination: records of this block
+  __shared__ unsigned long long lbase[64];                          // ... and where they start
+  __shared__ unsigned int woff[DD_FILL_THREADS / 64][64];           // ... and where each wave's start inside
+  if(threadIdx.x < 64)
+    lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long m = i < n ? mask[i] : 0ull;
-  unsigned long long any = wave_or64(m);
-  while(any)
+  const unsigned long long all = wave_or64(m);
+  for(unsigned long long any = all; any;)
     {
       const int r = __builtin_ctzll(any);
       any &= any - 1;
       const unsigned long long b = __builtin_amdgcn_ballot_w64(((m >> r) & 1ull) != 0);
       if(lane == 0)
-        atomicAdd(&counts[r], (unsigned long long)__popcll(b));
+        woff[wave][r] = atomicAdd(&lcnt[r], (unsigned int)__popcll(b));
     }
-  const unsigned long long stay = __builtin_amdgcn_ballot_w64(i < n && m == 0);
-  if(lane == 0 && stay)
-    atomicAdd(&counts[nranks], (unsigned long long)__popcll(stay));   // stays / not exported
-}
-
-__global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
-                          const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
-                          const unsigned char *__restrict__ active, const long long *__restrict__ id, const double *__restrict__ cost,
-                          const unsigned long long *__restrict__ offs, unsigned long long *__restrict__ cursor,
-                          DDRecord *__restrict__ out)
-{
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long m = i < n ? mask[i] : 0ull;
-  unsigned long long any = wave_or64(m);
-  if(!any)
+  __syncthreads();
+  if(threadIdx.x < 64 && lcnt[threadIdx.x])
+    lbase[threadIdx.x] = offs[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], (unsigned long long)lcnt[threadIdx.x]);
+  __syncthreads();
+  if(!all)
     return;
   DDRecord rec;
   rec.x = rec.y = rec.z = rec.m = rec.oldacc = rec.cost = 0;
@@ -477,39 +515,47 @@ __global__ void k_dd_fill(const unsigned long long *__restrict__ mask, long long
       rec.cost = cost[i];
       rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
     }
-  while(any)
+  for(unsigned long long any = all; any;)
     {
       const int r = __builtin_ctzll(any);
       any &= any - 1;
       const bool mine = ((m >> r) & 1ull) != 0;
       const unsigned long long b = __builtin_amdgcn_ballot_w64(mine);
-      unsigned long long base = 0;
-      if(lane == 0)
-        base = atomicAdd(&cursor[r], (unsigned long long)__popcll(b));
-      base = __shfl(base, 0);
       if(mine)
-        out[offs[r] + base + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = rec;
+        out[lbase[r] + woff[wave][r] + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = rec;
     }
 }
 
 // keep the particles that stay (mask == 0), compacted to the front of fresh columns
-__global__ void k_dd_keep(const unsigned long long *__restrict__ mask, long long n, const double *__restrict__ pos,
-                          const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
-                          const unsigned char *__restrict__ active, const long long *__restrict__ id, const double *__restrict__ cost,
-                          unsigned long long *__restrict__ cursor, double *__restrict__ pos2, double *__restrict__ mass2,
-                          int *__restrict__ type2, double *__restrict__ oldacc2, unsigned char *__restrict__ active2,
-                          long long *__restrict__ id2, double *__restrict__ cost2)
+__global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_keep(const unsigned long long *__restrict__ mask, long long n,
+                                                              const double *__restrict__ pos, const double *__restrict__ mass,
+                                                              const int *__restrict__ type, const double *__restrict__ oldacc,
+                                                              const unsigned char *__restrict__ active, const long long *__restrict__ id,
+                                                              const double *__restrict__ cost, unsigned long long *__restrict__ cursor,
+                                                              double *__restrict__ pos2, double *__restrict__ mass2,
+                                                              int *__restrict__ type2, double *__restrict__ oldacc2,
+                                                              unsigned char *__restrict__ active2, long long *__restrict__ id2,
+                                                              double *__restrict__ cost2)
 {
+  __shared__ unsigned int lcnt;
+  __shared__ unsigned long long lbase;
+  if(threadIdx.x == 0)
+    lcnt = 0;
+  __syncthreads();
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const bool keep = i < n && mask[i] == 0;
-  const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);   // one atomic per wave (see k_dd_count)
-  unsigned long long kbase = 0;
+  const unsigned long long kb = __builtin_amdgcn_ballot_w64(keep);   // one LDS atomic per wave, one global atomic per block
+  unsigned int wo = 0;
   if((threadIdx.x & 63) == 0 && kb)
-    kbase = atomicAdd(cursor, (unsigned long long)__popcll(kb));
-  kbase = __shfl(kbase, 0);
+    wo = atomicAdd(&lcnt, (unsigned int)__popcll(kb));
+  wo = __shfl(wo, 0);
+  __syncthreads();
+  if(threadIdx.x == 0 && lcnt)
+    lbase = atomicAdd(cursor, (unsigned long long)lcnt);
+  __syncthreads();
   if(!keep)
     return;
-  unsigned long long k = kbase + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0));
+  unsigned long long k = lbase + wo + __builtin_amdgcn_mbcnt_hi((unsigned)(kb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)kb, 0));
   pos2[3 * k + 0] = pos[3 * i + 0];
   pos2[3 * k + 1] = pos[3 * i + 1];
   pos2[3 * k + 2] = pos[3 * i + 2];
@@ -649,7 +695,7 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
     {
       hipLaunchKernelGGL(k_dd_dest, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
                          cell_len, c->cfg.periodic, c->dd_owner_ph.p, c->dd_owner_xyz.p, me, what, reach, c->dd_mask.p);
-      hipLaunchKernelGGL(k_dd_count, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
+      hipLaunchKernelGGL(k_dd_count, dim3(nb < DD_CNT_BLOCKS ? nb : DD_CNT_BLOCKS), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
       HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -665,7 +711,7 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
   if(tot > 0)
     {
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(k_dd_fill, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
+      hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
                          c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
                          (DDRecord *)c->dd_send.p);
     }
@@ -698,8 +744,7 @@ __global__ void k_dd_cellsums(const double *__restrict__ pos, const double *__re
   const int ty = type[i], g = (int)((t2g_packed >> (2 * ty)) & 3u);
   double *c = cells + (size_t)cell * TOP_CW(ng);
   const double m = mass[i];
-  atomicAdd(&c[0], 1.0);
-  atomicAdd(&c[1 + ty], 1.0);
+  atomicAdd(&c[1 + ty], 1.0);   // c[0], the particle count, is the sum of these: added on the host (one atomic less per particle)
   atomicAdd(&c[7 + 4 * g + 0], m);
   atomicAdd(&c[7 + 4 * g + 1], m * pos[3 * i + 0]);
   atomicAdd(&c[7 + 4 * g + 2], m * pos[3 * i + 1]);
@@ -725,6 +770,11 @@ int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
   HIP_TRY(c, hipMemcpyAsync(cells, d.p, sizeof(double) * ncell * cw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
+  for(long long i = 0; i < ncell; i++)
+    {
+      double *q = cells + (size_t)i * cw;
+      q[0] = q[1] + q[2] + q[3] + q[4] + q[5] + q[6];
+    }
   return NGRAVS_OK;
 }
 
@@ -825,7 +875,7 @@ int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, i
     {
       hipLaunchKernelGGL(k_dd_dest_cells, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
                          c->top.reqmask.p, me, c->dd_mask.p);
-      hipLaunchKernelGGL(k_dd_count, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
+      hipLaunchKernelGGL(k_dd_count, dim3(nb < DD_CNT_BLOCKS ? nb : DD_CNT_BLOCKS), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
       HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -841,7 +891,7 @@ int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, i
   if(tot > 0)
     {
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(k_dd_fill, dim3(nb), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
+      hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
                          c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
                          (DDRecord *)c->dd_send.p);
     }
@@ -948,7 +998,7 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p + 195, 0, sizeof(unsigned long long), c->stream));
   if(n > 0)
-    hipLaunchKernelGGL(k_dd_keep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->dd_mask.p, n, c->in_pos.p,
+    hipLaunchKernelGGL(k_dd_keep, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p,
                        c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 195, pos2.p,
                        mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p);
   unsigned long long kept = 0;

@@ -402,6 +402,7 @@ typedef struct
   int nbox;
   double (*bc)[3], (*bh)[3];
   uint8_t *need;         /* per level-L cell */
+  const uint8_t *mine;   /* all levels: nothing below this cell could be requested (every top leaf below is this task's own, or empty) */
 } need_t;
 
 static double near_abs(double x, double box) { return x - box * rint(x / box); }
@@ -500,7 +501,7 @@ static void need_visit(const need_t *T, int d, int64_t prefix)
 {
   const double cnt = T->sums[(size_t)(T->off[d] + prefix) * NGRAVS_TOP_CW(T->ng)];
   int k;
-  if(cnt < 0.5)
+  if(cnt < 0.5 || T->mine[T->off[d] + prefix])
     return;
   if(cnt < 1.5)   /* a single particle: it hangs directly below the opened parent */
     {
@@ -529,7 +530,7 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
   double *sums = NULL, dom[8], bounds[2], (*bc)[3] = NULL, (*bh)[3] = NULL, blo[64][3], bhi[64][3];
   int64_t *off = NULL, ncell, tot, i, *counts = NULL, *mat, *sb, *rb, nrec = 0, nrecv = 0;
   int32_t *xyz = NULL;
-  uint8_t *need = NULL, *allneed = NULL, *present = NULL;
+  uint8_t *need = NULL, *allneed = NULL, *present = NULL, *mine = NULL;
   uint64_t *reqmask = NULL;
   void *rec = NULL, *recvbuf = NULL;
   int L, nc, d, x, y, z, r, j, k, cw, used[64], rc = 0, W, me;
@@ -556,11 +557,12 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
   sums = calloc((size_t)tot * cw, sizeof(double));
   xyz = malloc(sizeof(int32_t) * (size_t)tot);
   need = calloc((size_t)ncell, 1);
+  mine = malloc((size_t)tot);
   allneed = malloc((size_t)ncell * (size_t)W);
   present = malloc((size_t)ncell);
   reqmask = calloc((size_t)ncell, sizeof(uint64_t));
   counts = malloc(sizeof(int64_t) * (size_t)(3 * 65 + W * W));
-  if(!sums || !xyz || !need || !allneed || !present || !reqmask || !counts)
+  if(!sums || !xyz || !need || !mine || !allneed || !present || !reqmask || !counts)
     rc = NGRAVS_ERR_NOMEM;
   /* top-leaf sums of all tasks (DomainMoment[], forcetree.c:766-850), then every coarser level */
   if(!rc)
@@ -659,6 +661,18 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
       T.bc = bc;
       T.bh = bh;
       T.need = need;
+      /* below a cell whose top leaves are all this task's own (or empty) there is nothing to request */
+      for(i = 0; i < ncell; i++)
+        mine[off[L] + i] = plan->owner_ph[i] == me || sums[(size_t)(off[L] + i) * cw] < 0.5;
+      for(d = L - 1; d >= 0; d--)
+        for(i = 0; i < (1ll << (3 * d)); i++)
+          {
+            uint8_t a = 1;
+            for(k = 0; k < 8; k++)
+              a &= mine[off[d + 1] + i * 8 + k];
+            mine[off[d] + i] = a;
+          }
+      T.mine = mine;
       if(T.nbox > 0)   /* the root is opened by every target inside it */
         for(k = 0; k < 8; k++)
           need_visit(&T, 1, k);
@@ -722,6 +736,7 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
   free(sums);
   free(xyz);
   free(need);
+  free(mine);
   free(allneed);
   free(present);
   free(reqmask);

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Stage times of the multi-task step on ONE task that has the GPU to itself (the rehearsals with several tasks on one GPU time
+kernels that compete for it): 2^23 particles and PMGRID 256 -- the particle count and the number of mesh cells ONE of 8 tasks
+holds at C4 (2^26 particles, PMGRID 512) -- through the production backend (torch.distributed "nccl" = RCCL, world size 1).
+Imports and exchange payloads are absent (no other task), everything else of the choreography runs.
+  python tools/probe_one_task.py [log2n] [pmgrid]"""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import torch.distributed as dist
+import __graft_entry__ as ge
+import bench
+
+
+def main():
+    log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 23
+    pmgrid = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    n, L = 1 << log2n, 1.0
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, err_tol_force_acc=0.005,
+                          softening=[eps] * 6, type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_GROUP)
+    pos, mass, ptype = bench.make_box(pkg, n, L, 2, 12345)
+    eng = dd.DistributedEngine(cfg)
+    eng.set_particles(pos, mass, ptype, ids=np.arange(n))
+    eng.compute_accelerations(pm_step=True)
+    nl = eng.num_local()
+    tmp = torch.zeros(nl, dtype=torch.float64, device="cuda")
+    eng.get_old_acc_device(tmp.data_ptr())
+    eng._check(pkg.lib().ngravs_set_old_acc(eng._h, tmp.data_ptr(), 8, 1), "ngravs_set_old_acc")
+    eng.set_opening(0.0, 0.005)
+    eng.compute_accelerations(pm_step=True)
+    eng.reset_wall()
+    steps = 3
+    dd_s, pm_s = np.zeros(8), np.zeros(13)
+    for _ in range(steps):
+        eng.compute_accelerations(pm_step=True)
+        dd_s += np.array(list(eng.info.seconds))
+        pm_s += np.array(eng.pm_seconds())
+    st = eng.stats()
+    w = eng.wall
+    names = ["extent+histogram+split", "migration", "top_cell_sums", "need_test_host", "requests+pack", "import_exchange+unpack",
+             "global_top", "local_decomposition"]
+    out = {"particles": n, "pmgrid": pmgrid, "backend": "nccl, world size 1",
+           "wall_ms_per_step": {k[:-2]: 1e3 * v / steps for k, v in w.items() if k.endswith("_s")},
+           "collective_calls_per_step": w["collective_calls"] / steps,
+           "decomposition_stage_ms": {k: 1e3 * v / steps for k, v in zip(names, dd_s)},
+           "pm_stage_ms": {"deposit+boxes": 1e3 * pm_s[0] / steps, "pack": list(1e3 * pm_s[1::3] / steps),
+                           "alltoallv": list(1e3 * pm_s[2::3] / steps), "unpack": list(1e3 * pm_s[3::3] / steps)},
+           "device_phases_ms_last_step": {"domain+peano": st.t_domain + st.t_peano, "pm": st.t_pm, "treebuild": st.t_treebuild,
+                                          "treewalk": st.t_treewalk}}
+    print(json.dumps(out))
+    eng.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
