@@ -514,6 +514,8 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
     }
   c->n = n;
   c->n_local = n;
+  if(!keep_tree)
+    c->own_order_nlocal = -1;   // new rows: the last Peano order says nothing about them
   int rc;
   if(!keep_tree && (rc = dd_fill_ids(c)))
     return rc;
@@ -695,9 +697,12 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   c->stats.t_domain = ev_ms(c) * 1e-3;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+  c->own_order_nlocal = -1;
   rc = dom_keys_and_sort(c);
   if(rc)
     return rc;
+  c->own_order_nlocal = c->n_local;   // the per-cell sums of the next multi-task decomposition visit the own rows in this order
+  c->own_order_len = c->n;
   HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
   c->stats.t_peano = ev_ms(c) * 1e-3;
   // target shard of this rank: a contiguous segment of the Peano order (domain.c:347-456 cuts the

@@ -331,21 +331,65 @@ __device__ __forceinline__ void dd_cell(const unsigned short (*step)[8], const d
   *iz = z >> (TREE_BITS - level);
 }
 
-__global__ void k_dd_hist(const double *__restrict__ pos, const double *__restrict__ cost, long long n, double cx, double cy, double cz,
-                          double fac21, int level, unsigned long long *__restrict__ hist, double *__restrict__ work)
+// Per-cell sums without one atomic per particle and value: visited in the Peano order of the last local decomposition
+// (`order`: rows of the working set then, own rows are the ones below n; any permutation is correct, this one puts the
+// particles of a cell next to each other), a wave whose particles all lie in ONE cell adds up across its lanes and issues one
+// atomic per value.  Waves that straddle cells, and runs without an order, fall back to one atomic per particle.
+// (A third level -- the waves of a 1024-thread block adding up in LDS -- measured slower: 1.88 against 1.55 ms for the stage.)
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+  for(int off = 32; off > 0; off >>= 1)
+    v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ bool dd_row(const unsigned int *__restrict__ order, long long norder, long long n, long long j, long long *i)
+{
+  if(order)
+    {
+      *i = j < norder ? (long long)order[j] : n;
+      return *i < n;
+    }
+  *i = j;
+  return j < n;
+}
+
+__global__ void k_dd_hist(const double *__restrict__ pos, const double *__restrict__ cost, long long n,
+                          const unsigned int *__restrict__ order, long long norder, double cx, double cy, double cz, double fac21,
+                          int level, unsigned long long *__restrict__ hist, double *__restrict__ work)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
     step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
   __syncthreads();
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
+  long long i;
+  const bool valid = dd_row(order, norder, n, blockIdx.x * (long long)blockDim.x + threadIdx.x, &i);
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  if(vm == 0ull)
     return;
   int ix, iy, iz;
-  long long cell;
-  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-  atomicAdd(&hist[cell], 1ull);
-  atomicAdd(&work[cell], 1.0 + cost[i]);   // domain.c:859-862: work of a cell = sum of (1 + GravCost)
+  long long cell = -1;
+  double w = 0;
+  if(valid)
+    {
+      dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+      w = 1.0 + cost[i];   // domain.c:859-862: work of a cell = sum of (1 + GravCost)
+    }
+  const int first = __builtin_ctzll(vm);
+  const long long cell0 = __shfl(cell, first);
+  if(__builtin_amdgcn_ballot_w64(valid && cell == cell0) == vm)
+    {
+      const double ws = wave_sum_f64(w);
+      if((threadIdx.x & 63) == first)
+        {
+          atomicAdd(&hist[cell0], (unsigned long long)__popcll(vm));
+          atomicAdd(&work[cell0], ws);
+        }
+    }
+  else if(valid)
+    {
+      atomicAdd(&hist[cell], 1ull);
+      atomicAdd(&work[cell], w);
+    }
 }
 
 // which other tasks receive particle i?  what = 0: its new owner (migration); what = 1: every task owning a cell within
@@ -660,9 +704,11 @@ int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
   double fac21;
   dd_fac(c, &fac21);
   const long long n = c->n_local;
+  const bool ordered = c->own_order_nlocal == n && c->own_order_len >= n && c->s_idx.p;
+  const long long nthr = ordered ? c->own_order_len : n;
   if(n > 0)
-    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_cost.p, n, c->dom[0],
-                       c->dom[1], c->dom[2], fac21, level, d.p, w.p);
+    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_cost.p, n,
+                       ordered ? c->s_idx.p : (const unsigned int *)nullptr, nthr, c->dom[0], c->dom[1], c->dom[2], fac21, level, d.p, w.p);
   HIP_TRY(c, hipMemcpyAsync(hist, d.p, sizeof(unsigned long long) * ncell, hipMemcpyDeviceToHost, c->stream));
   if(work)
     HIP_TRY(c, hipMemcpyAsync(work, w.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, c->stream));
@@ -728,27 +774,70 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
 // per-cell sums of the own particles: count, particles per type, per species mass and first moments (the local part of
 // DomainMoment[], forcetree.c:766-850, for every Peano cell of `level`)
 __global__ void k_dd_cellsums(const double *__restrict__ pos, const double *__restrict__ mass, const int *__restrict__ type, long long n,
-                              double cx, double cy, double cz, double fac21, int level, int ng, unsigned t2g_packed,
-                              double *__restrict__ cells)
+                              const unsigned int *__restrict__ order, long long norder, double cx, double cy, double cz, double fac21,
+                              int level, int ng, unsigned t2g_packed, double *__restrict__ cells)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
     step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
   __syncthreads();
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
+  long long i;
+  const bool valid = dd_row(order, norder, n, blockIdx.x * (long long)blockDim.x + threadIdx.x, &i);
+  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+  if(vm == 0ull)
     return;
-  int ix, iy, iz;
-  long long cell;
-  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-  const int ty = type[i], g = (int)((t2g_packed >> (2 * ty)) & 3u);
-  double *c = cells + (size_t)cell * TOP_CW(ng);
-  const double m = mass[i];
-  atomicAdd(&c[1 + ty], 1.0);   // c[0], the particle count, is the sum of these: added on the host (one atomic less per particle)
-  atomicAdd(&c[7 + 4 * g + 0], m);
-  atomicAdd(&c[7 + 4 * g + 1], m * pos[3 * i + 0]);
-  atomicAdd(&c[7 + 4 * g + 2], m * pos[3 * i + 1]);
-  atomicAdd(&c[7 + 4 * g + 3], m * pos[3 * i + 2]);
+  int ix, iy, iz, ty = -1, g = -1;
+  long long cell = -1;
+  double m = 0, mx = 0, my = 0, mz = 0;
+  if(valid)
+    {
+      dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
+      ty = type[i];
+      g = (int)((t2g_packed >> (2 * ty)) & 3u);
+      m = mass[i];
+      mx = m * pos[3 * i + 0];
+      my = m * pos[3 * i + 1];
+      mz = m * pos[3 * i + 2];
+    }
+  // (c[0], the particle count, is the sum of the per-type counts: added on the host -- one atomic less per particle)
+  const int first = __builtin_ctzll(vm);
+  const long long cell0 = __shfl(cell, first);
+  if(__builtin_amdgcn_ballot_w64(valid && cell == cell0) == vm)
+    {
+      double *c = cells + (size_t)cell0 * TOP_CW(ng);
+      const bool lead = (threadIdx.x & 63) == first;
+      for(int t = 0; t < NGRAVS_NTYPES; t++)
+        {
+          const unsigned long long tm = __builtin_amdgcn_ballot_w64(ty == t);
+          if(tm && lead)
+            atomicAdd(&c[1 + t], (double)__popcll(tm));
+        }
+      for(int s = 0; s < ng; s++)
+        {
+          const unsigned long long sm = __builtin_amdgcn_ballot_w64(g == s);
+          if(sm == 0ull)
+            continue;
+          const bool in = g == s;
+          const double a0 = wave_sum_f64(in ? m : 0.0), a1 = wave_sum_f64(in ? mx : 0.0), a2 = wave_sum_f64(in ? my : 0.0),
+                       a3 = wave_sum_f64(in ? mz : 0.0);
+          if(lead)
+            {
+              atomicAdd(&c[7 + 4 * s + 0], a0);
+              atomicAdd(&c[7 + 4 * s + 1], a1);
+              atomicAdd(&c[7 + 4 * s + 2], a2);
+              atomicAdd(&c[7 + 4 * s + 3], a3);
+            }
+        }
+    }
+  else if(valid)
+    {
+      double *c = cells + (size_t)cell * TOP_CW(ng);
+      atomicAdd(&c[1 + ty], 1.0);
+      atomicAdd(&c[7 + 4 * g + 0], m);
+      atomicAdd(&c[7 + 4 * g + 1], mx);
+      atomicAdd(&c[7 + 4 * g + 2], my);
+      atomicAdd(&c[7 + 4 * g + 3], mz);
+    }
 }
 
 int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
@@ -764,9 +853,12 @@ int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
   unsigned t2g_packed = 0;
   for(int t = 0; t < NGRAVS_NTYPES; t++)
     t2g_packed |= ((unsigned)(c->cfg.type_to_grav[t] & 3)) << (2 * t);
+  const bool ordered = c->own_order_nlocal == n && c->own_order_len >= n && c->s_idx.p;
+  const long long nthr = ordered ? c->own_order_len : n;
   if(n > 0)
-    hipLaunchKernelGGL(k_dd_cellsums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p, n,
-                       c->dom[0], c->dom[1], c->dom[2], fac21, level, c->cfg.n_gravs, t2g_packed, d.p);
+    hipLaunchKernelGGL(k_dd_cellsums, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p, n,
+                       ordered ? c->s_idx.p : (const unsigned int *)nullptr, nthr, c->dom[0], c->dom[1], c->dom[2], fac21, level,
+                       c->cfg.n_gravs, t2g_packed, d.p);
   HIP_TRY(c, hipMemcpyAsync(cells, d.p, sizeof(double) * ncell * cw, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -1025,6 +1117,7 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
   c->in_id = id2;
   c->n_local = (int64_t)kept + nrec;
   c->n = c->n_local;
+  c->own_order_nlocal = -1;   // rows moved: the old order no longer names them
   c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
   return NGRAVS_OK;
 }
