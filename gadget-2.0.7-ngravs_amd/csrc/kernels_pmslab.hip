@@ -147,33 +147,61 @@ __global__ void k_tr_pack_fwd(const double2 *__restrict__ C, const long long *__
   const long long ysd = T_R(tab, d, 0), nyd = T_R(tab, d, 1), off = T_R(tab, d, 4);
   send[off + (((long long)g * nx + ix) * nyd + (y - ysd)) * NH + z] = C[idx];
 }
+// The two strided halves of the transposes go through a 32 x 32 tile of LDS: both the (x slow, z fast) blocks of the exchange
+// and the (z slow, x fast) layout of the 1-D transforms are then read and written in runs of 32 consecutive elements (512
+// bytes).  Block = 32 x 8 threads, one tile of one (species, y) plane; grid (N / 32, ceil(NH / 32), ng * ny).
+#define TR_TILE 32
 // received blocks [g][ix_s][yl][z] of every source s -> T[g][yl][z][x] (x fastest: contiguous 1-D transforms along x)
-__global__ void k_tr_unpack_fwd(const double2 *__restrict__ recv, const long long *__restrict__ tab, int N, int NH, int ny, int ng,
-                                double2 *__restrict__ T)
+__global__ __launch_bounds__(TR_TILE * 8) void k_tr_unpack_fwd(const double2 *__restrict__ recv, const long long *__restrict__ tab, int N,
+                                                               int NH, int ny, int ng, double2 *__restrict__ T)
 {
-  const long long tot = (long long)ng * ny * NH * N;
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(idx >= tot)
-    return;
-  const int x = (int)(idx % N), z = (int)((idx / N) % NH), yl = (int)((idx / ((long long)N * NH)) % ny);
-  const int g = (int)(idx / ((long long)N * NH * ny));
-  const int s = T_XOWN(tab, x);
-  const long long xss = T_R(tab, s, 2), nxs = T_R(tab, s, 3), off = T_R(tab, s, 5);
-  T[idx] = recv[off + (((long long)g * nxs + (x - xss)) * ny + yl) * NH + z];
+  __shared__ double2 tile[TR_TILE][TR_TILE + 1];
+  const int tx = threadIdx.x & (TR_TILE - 1), ty = threadIdx.x / TR_TILE;
+  const int x0 = blockIdx.x * TR_TILE, z0 = blockIdx.y * TR_TILE;
+  const int yl = blockIdx.z % ny, g = blockIdx.z / ny;
+  for(int xx = ty; xx < TR_TILE; xx += 8)
+    {
+      const int x = x0 + xx, z = z0 + tx;
+      if(x < N && z < NH)
+        {
+          const int s = T_XOWN(tab, x);
+          const long long xss = T_R(tab, s, 2), nxs = T_R(tab, s, 3), off = T_R(tab, s, 5);
+          tile[xx][tx] = recv[off + (((long long)g * nxs + (x - xss)) * ny + yl) * NH + z];
+        }
+    }
+  __syncthreads();
+  for(int zz = ty; zz < TR_TILE; zz += 8)
+    {
+      const int x = x0 + tx, z = z0 + zz;
+      if(x < N && z < NH)
+        T[(((long long)g * ny + yl) * NH + z) * N + x] = tile[tx][zz];
+    }
 }
 // T[g][yl][z][x] -> blocks [g][x - xs_d][yl][z] per destination d = owner of x
-__global__ void k_tr_pack_bwd(const double2 *__restrict__ T, const long long *__restrict__ tab, int N, int NH, int ny, int ng,
-                              double2 *__restrict__ send)
+__global__ __launch_bounds__(TR_TILE * 8) void k_tr_pack_bwd(const double2 *__restrict__ T, const long long *__restrict__ tab, int N, int NH,
+                                                             int ny, int ng, double2 *__restrict__ send)
 {
-  const long long tot = (long long)ng * ny * NH * N;
-  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(idx >= tot)
-    return;
-  const int x = (int)(idx % N), z = (int)((idx / N) % NH), yl = (int)((idx / ((long long)N * NH)) % ny);
-  const int g = (int)(idx / ((long long)N * NH * ny));
-  const int d = T_XOWN(tab, x);
-  const long long xsd = T_R(tab, d, 2), nxd = T_R(tab, d, 3), off = T_R(tab, d, 4);
-  send[off + (((long long)g * nxd + (x - xsd)) * ny + yl) * NH + z] = T[idx];
+  __shared__ double2 tile[TR_TILE][TR_TILE + 1];
+  const int tx = threadIdx.x & (TR_TILE - 1), ty = threadIdx.x / TR_TILE;
+  const int x0 = blockIdx.x * TR_TILE, z0 = blockIdx.y * TR_TILE;
+  const int yl = blockIdx.z % ny, g = blockIdx.z / ny;
+  for(int zz = ty; zz < TR_TILE; zz += 8)
+    {
+      const int x = x0 + tx, z = z0 + zz;
+      if(x < N && z < NH)
+        tile[zz][tx] = T[(((long long)g * ny + yl) * NH + z) * N + x];
+    }
+  __syncthreads();
+  for(int xx = ty; xx < TR_TILE; xx += 8)
+    {
+      const int x = x0 + xx, z = z0 + tx;
+      if(x < N && z < NH)
+        {
+          const int d = T_XOWN(tab, x);
+          const long long xsd = T_R(tab, d, 2), nxd = T_R(tab, d, 3), off = T_R(tab, d, 4);
+          send[off + (((long long)g * nxd + (x - xsd)) * ny + yl) * NH + z] = tile[tx][xx];
+        }
+    }
 }
 // received blocks [g][ix][y - ys_s][z] of every source s -> C[g][ix][y][z]
 __global__ void k_tr_unpack_bwd(const double2 *__restrict__ recv, const long long *__restrict__ tab, int N, int NH, int nx, int ng,
@@ -695,7 +723,8 @@ int pmslab_pack(ngravs_ctx *c, int stage, const int *all_bbox, int64_t *send_cou
           const long long tot = (long long)ng * tcells;
           const double2 *phi_t = (const double2 *)s.tbuf.p + (size_t)ng * tcells;   // second half of tbuf: the potentials
           if(tot > 0)
-            hipLaunchKernelGGL(k_tr_pack_bwd, GRIDN(tot), 0, c->stream, phi_t, s.desc.p, N, NH, s.ny, ng, (double2 *)s.send.p);
+            hipLaunchKernelGGL(k_tr_pack_bwd, dim3((N + TR_TILE - 1) / TR_TILE, (NH + TR_TILE - 1) / TR_TILE, (unsigned)(ng * s.ny)), dim3(TR_TILE * 8), 0, c->stream,
+                               phi_t, s.desc.p, N, NH, s.ny, ng, (double2 *)s.send.p);
         }
     }
   else
@@ -808,7 +837,8 @@ int pmslab_unpack(ngravs_ctx *c, int stage)
       const long long tot = (long long)ng * tcells;
       if(tot > 0)
         {
-          hipLaunchKernelGGL(k_tr_unpack_fwd, GRIDN(tot), 0, c->stream, (const double2 *)s.recv.p, s.desc.p, N, NH, s.ny, ng, rho_t);
+          hipLaunchKernelGGL(k_tr_unpack_fwd, dim3((N + TR_TILE - 1) / TR_TILE, (NH + TR_TILE - 1) / TR_TILE, (unsigned)(ng * s.ny)), dim3(TR_TILE * 8), 0,
+                             c->stream, (const double2 *)s.recv.p, s.desc.p, N, NH, s.ny, ng, rho_t);
           for(int a = 0; a < ng; a++)
             FFT_TRY(c, hipfftExecZ2Z(*(hipfftHandle *)s.plan1, (hipfftDoubleComplex *)(rho_t + tcells * a),
                                      (hipfftDoubleComplex *)(rho_t + tcells * a), HIPFFT_FORWARD));
