@@ -275,8 +275,16 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
   info->seconds[0] = -wall_now();
   CHECK(ngravs_get_config(ctx, &cfg));
   CHECK(ngravs_dd_local_extent(ctx, lo, hi));
-  CHECK(cm->allreduce(cm->user, lo, 3, NGRAVS_T_F64, NGRAVS_OP_MIN));
-  CHECK(cm->allreduce(cm->user, hi, 3, NGRAVS_T_F64, NGRAVS_OP_MAX));
+  {
+    /* one collective for both ends: max(hi) = -min(-hi) */
+    double e[6] = {lo[0], lo[1], lo[2], -hi[0], -hi[1], -hi[2]};
+    CHECK(cm->allreduce(cm->user, e, 6, NGRAVS_T_F64, NGRAVS_OP_MIN));
+    for(r = 0; r < 3; r++)
+      {
+        lo[r] = e[r];
+        hi[r] = -e[3 + r];
+      }
+  }
   CHECK(ngravs_dd_set_extent(ctx, lo, hi));
   if(level <= 0)
     level = choose_level(&cfg);
@@ -295,9 +303,27 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level,
   if(!rc)
     rc = ngravs_dd_histogram(ctx, level, hist, work);
   if(!rc)
-    rc = cm->allreduce(cm->user, hist, ncell, NGRAVS_T_I64, NGRAVS_OP_SUM);
-  if(!rc)
-    rc = cm->allreduce(cm->user, work, ncell, NGRAVS_T_F64, NGRAVS_OP_SUM);
+    {
+      /* counts and work in ONE collective: whole numbers below 2^53 add up exactly as doubles */
+      double *both = malloc(sizeof(double) * 2 * (size_t)ncell);
+      if(!both)
+        rc = NGRAVS_ERR_NOMEM;
+      else
+        {
+          for(i = 0; i < ncell; i++)
+            {
+              both[i] = (double)hist[i];
+              both[ncell + i] = work[i];
+            }
+          rc = cm->allreduce(cm->user, both, 2 * ncell, NGRAVS_T_F64, NGRAVS_OP_SUM);
+          for(i = 0; i < ncell && !rc; i++)
+            {
+              hist[i] = (int64_t)(both[i] + 0.5);
+              work[i] = both[ncell + i];
+            }
+          free(both);
+        }
+    }
   if(!rc)
     {
       for(i = 0; i < ncell; i++)
