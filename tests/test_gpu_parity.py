@@ -569,6 +569,49 @@ def test_slab_pm_one_task_equals_the_3d_transform(pkg, O):
         assert np.abs(full - pm_o).max() / scale < TOL
 
 
+def test_cell_sums_in_the_last_peano_order(pkg, O):
+    """The top-cell sums of a multi-task decomposition (histogram + work, per-type counts, per-species mass and first moments:
+    the global top of the tree is built from them) are taken in plain row order on the first step and, from the second step on,
+    in the Peano order of the last local decomposition with one atomic per wave and value.  Same particles, Barnes-Hut criterion
+    (no OldAcc dependence): the second step must return the first step's forces (summation order of the sums only) and equal
+    interaction counts, and both the single-task engine's -- two species, a clump so that waves straddle cells."""
+    import importlib
+    import torch.distributed as dist
+    dd = importlib.import_module("ngravs_amd.distributed")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29400 + os.getpid() % 500), rank=0, world_size=1)
+    n = 50000
+    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=91)
+    typ = (1 + (np.arange(n) % 2)).astype(np.int32)
+    mass = mass * np.where(typ == 2, 3.0, 1.0)
+    kw = dict(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.02, 0.01, 0.01, 0.01],
+              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton", walk_mode=pkg.WALK_STRICT)
+    eng = pkg.Engine(pkg.make_config(**kw))
+    eng.set_particles(pos, mass, typ)
+    eng.compute_accelerations(pm_step=False)
+    a1, _, c1 = eng.get_accel()
+    eng.close()
+    deng = dd.DistributedEngine(pkg.make_config(**kw))
+    deng.set_particles(pos, mass, typ, ids=np.arange(n))
+    res = []
+    for step in range(3):
+        deng.compute_accelerations(pm_step=False)
+        acc, _, cost = deng.get_accel()[:3]
+        ids = deng.local_ids()
+        a = np.zeros((n, 3))
+        c = np.zeros(n)
+        a[ids] = acc
+        c[ids] = cost
+        res.append((a, c))
+    deng.close()
+    for step, (a, c) in enumerate(res):
+        err = np.linalg.norm(a - a1, axis=1) / np.linalg.norm(a1, axis=1)
+        print("step %d vs the single-task engine: max |da|/|a| = %.2e" % (step, err.max()))
+        assert np.array_equal(c, c1)
+        assert err.max() < 1e-10
+    assert np.abs(res[1][0] - res[0][0]).max() / np.abs(res[0][0]).max() < 1e-12
+
+
 def test_bam_laws_strict_walk_and_direct_sum(pkg, O):
     """the BAM / NGRAVS_ACCUMULATOR family (ngravs.c:495-668; wiring NGRAVS_ACCUMULATOR_TESTING :163-210): laws of
     the TARGET mass and of the number of particles of the source species a node holds (allvars.h:645-648).  Baryons (species
