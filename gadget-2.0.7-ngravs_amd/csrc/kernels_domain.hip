@@ -182,14 +182,16 @@ __global__ void k_gather(const unsigned int *__restrict__ idx, long long n, cons
   s_active[i] = (unsigned char)((meta >> 8) & 255);
 }
 
-// Two-stage sort: a stable radix sort on the TOP bits of the key only (SORT_TOP_BITS of the 63: 6 passes instead of 9), then every run of
-// equal top bits -- rare and short: 2^42 cells for the particles to share -- is put in order of its low bits by the thread that
+// Two-stage sort: a stable radix sort on the TOP bits of the key only (35 or 42 of the 63: 5 or 6 passes instead of 9), then every run of
+// equal top bits -- rare and short: 2^35 or 2^42 cells for the particles to share -- is put in order of its low bits by the thread that
 // finds its head (stable insertion sort of the (key, index) pairs in place).  The result is exactly that of a stable sort on all
 // 63 bits.  A run longer than SORT_RUN_MAX (a pathological clump below 1/16384 of the domain) raises a flag and the caller
 // sorts again on all bits.
-#define SORT_LOW_BITS 21
+// How many low bits are left to the fix-up adapts to the particle set: 28 (5 passes) to begin with; a run that is too long
+// makes this step sort on all bits and the next steps leave 21 (6 passes), then none (ctx sort_low; new particles start over).
 #define SORT_RUN_MAX 64
-__global__ void k_sort_fixup(unsigned long long *__restrict__ key, unsigned int *__restrict__ idx, long long n, int *__restrict__ flag)
+__global__ void k_sort_fixup(unsigned long long *__restrict__ key, unsigned int *__restrict__ idx, long long n, int *__restrict__ flag,
+                             const int SORT_LOW_BITS)
 {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
@@ -241,17 +243,20 @@ int dom_keys_and_sort(ngravs_ctx *c)
                                      3 * TREE_BITS, c->stream);
   if(c->sort_tmp.ensure(tmp_bytes) || c->d_counters.ensure(16))
     return NGRAVS_ERR_NOMEM;
-  bool full = c->tune.sort_full != 0 || n < 4096;
+  bool full = c->tune.sort_full != 0 || n < 4096 || c->sort_low <= 0;
   if(!full)
     {
       int h_flag = 0;
+      const int low = c->sort_low;
       HIP_TRY(c, hipMemsetAsync(c->d_counters.p + 15, 0, sizeof(int), c->stream));
       HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
-                                                    c->s_idx.p, (int)n, SORT_LOW_BITS, 3 * TREE_BITS, c->stream));
-      hipLaunchKernelGGL(k_sort_fixup, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->s_idx.p, n, c->d_counters.p + 15);
+                                                    c->s_idx.p, (int)n, low, 3 * TREE_BITS, c->stream));
+      hipLaunchKernelGGL(k_sort_fixup, dim3(nb), dim3(bs), 0, c->stream, c->s_key.p, c->s_idx.p, n, c->d_counters.p + 15, low);
       HIP_TRY(c, hipMemcpyAsync(&h_flag, c->d_counters.p + 15, sizeof(int), hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      full = h_flag != 0;   // a clump too dense for the fix-up: sort on all bits
+      full = h_flag != 0;   // a clump too dense for the fix-up: sort on all bits, and leave it fewer bits from now on
+      if(full)
+        c->sort_low = low > 21 ? 21 : 0;
     }
   if(full)
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
