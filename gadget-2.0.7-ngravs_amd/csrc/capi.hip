@@ -517,7 +517,7 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   if(!keep_tree)
     {
       c->own_order_nlocal = -1;   // new rows: the last Peano order says nothing about them
-      c->sort_low = 28;
+      c->sort_low = 35;
     }
   int rc;
   if(!keep_tree && (rc = dd_fill_ids(c)))

@@ -192,7 +192,7 @@ struct ngravs_ctx
   // multi-task decomposition scratch
   DevBuf<unsigned long long> dd_mask, dd_counts, dd_hist;
   DevBuf<double> dd_work, dd_cells;
-  int sort_low = 28;   // key bits the two-stage sort leaves to its fix-up (28 -> 21 -> 0 = plain sort, as runs of ties get too long)
+  int sort_low = 35;   // key bits the two-stage sort leaves to its fix-up (35 -> 28 -> 21 -> 0 = plain sort, as runs of ties get too long)
   long long own_order_nlocal = -1, own_order_len = 0;   // s_idx still is the Peano order of the last local decomposition (of own_order_len rows, own_order_nlocal of them own)
   DevBuf<int> dd_owner_ph, dd_owner_xyz;
   DevBuf<unsigned char> dd_send, dd_recv;

@@ -182,13 +182,13 @@ __global__ void k_gather(const unsigned int *__restrict__ idx, long long n, cons
   s_active[i] = (unsigned char)((meta >> 8) & 255);
 }
 
-// Two-stage sort: a stable radix sort on the TOP bits of the key only (35 or 42 of the 63: 5 or 6 passes instead of 9), then every run of
-// equal top bits -- rare and short: 2^35 or 2^42 cells for the particles to share -- is put in order of its low bits by the thread that
+// Two-stage sort: a stable radix sort on the TOP bits of the key only (28 of the 63 to begin with: 4 passes instead of 9), then every run of
+// equal top bits -- short: 2^28 cells for the particles to share -- is put in order of its low bits by the thread that
 // finds its head (stable insertion sort of the (key, index) pairs in place).  The result is exactly that of a stable sort on all
 // 63 bits.  A run longer than SORT_RUN_MAX (a pathological clump below 1/16384 of the domain) raises a flag and the caller
 // sorts again on all bits.
-// How many low bits are left to the fix-up adapts to the particle set: 28 (5 passes) to begin with; a run that is too long
-// makes this step sort on all bits and the next steps leave 21 (6 passes), then none (ctx sort_low; new particles start over).
+// How many low bits are left to the fix-up adapts to the particle set: 35 (4 passes) to begin with; a run that is too long
+// makes this step sort on all bits and the next steps leave 28, then 21, then none (ctx sort_low; new particles start over).
 #define SORT_RUN_MAX 64
 __global__ void k_sort_fixup(unsigned long long *__restrict__ key, unsigned int *__restrict__ idx, long long n, int *__restrict__ flag,
                              const int SORT_LOW_BITS)
@@ -256,7 +256,7 @@ int dom_keys_and_sort(ngravs_ctx *c)
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       full = h_flag != 0;   // a clump too dense for the fix-up: sort on all bits, and leave it fewer bits from now on
       if(full)
-        c->sort_low = low > 21 ? 21 : 0;
+        c->sort_low = low > 28 ? 28 : (low > 21 ? 21 : 0);
     }
   if(full)
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
