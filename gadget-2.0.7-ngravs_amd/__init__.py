@@ -25,7 +25,7 @@ _LIB = None
 # every symbol include/ngravs_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 EXPORTS = [
     "ngravs_abi_version", "ngravs_build_info", "ngravs_config_default", "ngravs_create", "ngravs_destroy",
-    "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_get_config", "ngravs_set_tuning",
+    "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_softening", "ngravs_dd_record_bytes", "ngravs_get_config", "ngravs_set_tuning",
     "ngravs_memcpy",
     "ngravs_set_particles",
     "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition",
@@ -77,6 +77,9 @@ def lib():
         L.ngravs_compute_accelerations.argtypes = [C.c_void_p, C.c_int]
         L.ngravs_set_opening.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.ngravs_set_walk_mode.argtypes = [C.c_void_p, C.c_int]
+        L.ngravs_set_softening.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_dd_record_bytes.restype = C.c_int64
+        L.ngravs_dd_record_bytes.argtypes = [C.c_void_p, C.c_int]
         L.ngravs_set_particles.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_set_old_acc.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.ngravs_get_accel.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -252,6 +255,14 @@ class Engine:
         self._check(lib().ngravs_set_opening(self._h, theta, err_tol_force_acc), "ngravs_set_opening")
         self.cfg.err_tol_theta = theta
         self.cfg.err_tol_force_acc = err_tol_force_acc
+
+    def set_softening(self, force_softening):
+        """All.ForceSoftening[6] after set_softenings() (gravtree.c:468-518): comoving runs change it every step"""
+        fs = np.ascontiguousarray(force_softening, dtype=np.float64)
+        assert fs.shape == (6,)
+        self._check(lib().ngravs_set_softening(self._h, fs.ctypes.data), "ngravs_set_softening")
+        for t in range(6):
+            self.cfg.force_softening[t] = fs[t]
 
     def set_walk_mode(self, mode):
         self._check(lib().ngravs_set_walk_mode(self._h, mode), "ngravs_set_walk_mode")

@@ -5,7 +5,7 @@ compiled library (ngravs_build_info) so that a drift is caught on CPU.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_GRAVS = 3
 NTYPES = 6
 NTAB = 2048

@@ -121,6 +121,27 @@ __global__ void k_permute_f64(const unsigned int *idx, long long n, int ncomp, c
   for(int k = 0; k < ncomp; k++)
     dst[i * ncomp + k] = src[j * ncomp + k];
 }
+// Peano order <- caller order for a column that only exists for the first `lim` (own) rows: imported copies read 0
+__global__ void k_permute_f64_lim(const unsigned int *idx, long long n, long long lim, int ncomp, const double *src, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  long long j = idx[i];
+  for(int k = 0; k < ncomp; k++)
+    dst[i * ncomp + k] = j < lim ? src[j * ncomp + k] : 0.0;
+}
+// Peano order -> caller order, own rows only
+__global__ void k_unpermute_f64_lim(const unsigned int *idx, long long n, long long lim, int ncomp, const double *src, double *dst)
+{
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(i >= n)
+    return;
+  long long j = idx[i];
+  if(j < lim)
+    for(int k = 0; k < ncomp; k++)
+      dst[j * ncomp + k] = src[i * ncomp + k];
+}
 __global__ void k_key18(const unsigned long long *k21, long long n, long long *out)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -375,6 +396,25 @@ extern "C" int ngravs_set_opening(ngravs_ctx *c, double theta, double errtol)
     return NGRAVS_ERR_ARG;
   c->cfg.err_tol_theta = theta;
   c->cfg.err_tol_force_acc = errtol;
+  return NGRAVS_OK;
+}
+
+// set_softenings() (gravtree.c:468-518) recomputes All.ForceSoftening[] from the scale factor at the top of every gravity_tree()
+// of a comoving run (gravtree.c:50-51).  The walk, the direct sum and the import decision read the new lengths from the next
+// call on; the max-softening-type flags of the nodes are those of the last tree build or refit, as in the reference
+// (force_update_node_recursive, forcetree.c:704-713, runs at build time only).
+extern "C" int ngravs_set_softening(ngravs_ctx *c, const double force_softening[NGRAVS_NTYPES])
+{
+  if(!c || !force_softening)
+    return NGRAVS_ERR_ARG;
+  for(int t = 0; t < NGRAVS_NTYPES; t++)
+    if(!(force_softening[t] >= 0.0))
+      {
+        ngravs_report(c, NGRAVS_ERR_ARG, "ngravs_set_softening: negative or NaN softening length");
+        return NGRAVS_ERR_ARG;
+      }
+  for(int t = 0; t < NGRAVS_NTYPES; t++)
+    c->cfg.force_softening[t] = force_softening[t];
   return NGRAVS_OK;
 }
 
@@ -675,23 +715,38 @@ static double ev_ms(ngravs_ctx *c)
   return ms;
 }
 
+// P[].GravPM survives between PM steps (it is only rewritten by pmforce_periodic): park the OWN rows of r_pm (Peano order of the
+// last decomposition) in caller order before the rows are re-sorted, migrated or joined by new imports.  pm_orig then is a
+// caller-order column like in_mass: the migration moves it with the particles (kernels_domain.hip).
+static int park_grav_pm(ngravs_ctx *c)
+{
+  if(!c->have_pm || !c->have_order)
+    return NGRAVS_OK;
+  if(c->pm_orig.ensure(3 * (c->n_local > 0 ? c->n_local : 1)))
+    return NGRAVS_ERR_NOMEM;
+  hipLaunchKernelGGL(k_unpermute_f64_lim, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, (long long)c->n_local, 3, c->r_pm.p,
+                     c->pm_orig.p);
+  c->pm_parked = true;
+  c->have_pm = false;
+  return NGRAVS_OK;
+}
+
 static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
 {
   if(!c || !c->have_particles)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  // P[].GravPM survives between PM steps (it is only rewritten by pmforce_periodic): park it in caller order
-  // under the OLD Peano order before re-sorting, unless this step recomputes it anyway
-  if(c->have_pm && keep_pm)
+  if(keep_pm)
     {
-      if(c->pm_orig.ensure(3 * c->n))
-        return NGRAVS_ERR_NOMEM;
-      hipLaunchKernelGGL(k_unpermute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->r_pm.p, c->pm_orig.p);
+      if(int rc = park_grav_pm(c))   // unless this step recomputes GravPM anyway
+        return rc;
     }
-  else if(c->pm_parked && keep_pm && c->n == c->n_local)
-    c->have_pm = true;   // GravPM handed over with the particles (ngravs_particles_t.grav_pm)
   else
-    c->have_pm = false;
+    c->pm_parked = false;
+  // parked GravPM (own rows; handed over with the particles, ngravs_particles_t.grav_pm, or parked above / by
+  // ngravs_dd_local_extent): permuted into the new order below; imported copies carry none and are never read (k_finish
+  // visits active own rows only)
+  c->have_pm = c->pm_parked;
   c->pm_parked = false;
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   int rc = dom_find_extent(c);
@@ -723,7 +778,8 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
     {
       if(c->r_pm.ensure(3 * c->n))
         return NGRAVS_ERR_NOMEM;
-      hipLaunchKernelGGL(k_permute_f64, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, 3, c->pm_orig.p, c->r_pm.p);
+      hipLaunchKernelGGL(k_permute_f64_lim, GRID1(c->n), 0, c->stream, c->s_idx.p, (long long)c->n, (long long)c->n_local, 3, c->pm_orig.p,
+                         c->r_pm.p);
       HIP_TRY(c, hipGetLastError());
     }
   return NGRAVS_OK;
@@ -916,11 +972,13 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
   if(!c || !c->have_order)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  const int64_t n = c->n;
+  // the working set is own rows [0, n_local) followed by imported copies; ONLY the own rows are the caller's (its arrays hold
+  // NumPart = ngravs_dd_num_local() rows -- the imports of a multi-task step never reach them)
+  const int64_t n = c->n, nl = c->n_local;
   if(c->out_tmp.ensure(3 * n) || c->out_tmpf.ensure(n))
     return NGRAVS_ERR_NOMEM;
-  // in_active is the caller-order flag column of the last hand-over (bit 1: halo copies, never written)
-  const unsigned char *mask = (only_active && !(c->all_active && c->n_local == c->n)) ? c->in_active.p : nullptr;
+  // in_active is the caller-order flag column of the last hand-over
+  const unsigned char *mask = only_active ? c->in_active.p : nullptr;
   int rc;
   if(grav_accel)
     {
@@ -928,7 +986,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
         return NGRAVS_ERR_STATE;
       HIP_TRY(c, hipMemsetAsync(c->out_tmp.p, 0, sizeof(double) * 3 * n, c->stream));
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_acc.p, c->out_tmp.p);
-      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, n, grav_accel, accel_stride, on_device, mask)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, nl, grav_accel, accel_stride, on_device, mask)))
         return rc;
     }
   if(grav_pm)
@@ -936,7 +994,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
       if(!c->have_pm)
         return NGRAVS_ERR_STATE;
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 3, c->r_pm.p, c->out_tmp.p);
-      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, n, grav_pm, pm_stride, on_device, nullptr)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 3, nl, grav_pm, pm_stride, on_device, nullptr)))
         return rc;
     }
   if(old_acc)
@@ -944,7 +1002,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
       if(!c->have_acc)
         return NGRAVS_ERR_STATE;
       hipLaunchKernelGGL(k_unpermute_f64, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, 1, c->r_oldacc.p, c->out_tmp.p);
-      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 1, n, old_acc, old_acc_stride, on_device, mask)))
+      if((rc = deliver(c, c->out_tmp.p, sizeof(double), 1, nl, old_acc, old_acc_stride, on_device, mask)))
         return rc;
     }
   if(grav_cost)
@@ -952,7 +1010,7 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
       if(!c->have_acc)
         return NGRAVS_ERR_STATE;
       hipLaunchKernelGGL(k_unpermute_i2f, GRID1(n), 0, c->stream, c->s_idx.p, (long long)n, c->r_nint.p, c->out_tmpf.p);
-      if((rc = deliver(c, c->out_tmpf.p, sizeof(float), 1, n, grav_cost, cost_stride, on_device, mask)))
+      if((rc = deliver(c, c->out_tmpf.p, sizeof(float), 1, nl, grav_cost, cost_stride, on_device, mask)))
         return rc;
     }
   return NGRAVS_OK;
@@ -984,7 +1042,7 @@ extern "C" int ngravs_get_keys(ngravs_ctx *c, int64_t *keys, int on_device)
     return NGRAVS_ERR_NOMEM;
   long long *tmp = reinterpret_cast<long long *>(c->out_tmp.p);
   hipLaunchKernelGGL(k_key18, GRID1(n), 0, c->stream, c->in_key.p, (long long)n, tmp);
-  return download_strided(c, tmp, sizeof(long long), 1, n, keys, sizeof(long long), on_device);
+  return download_strided(c, tmp, sizeof(long long), 1, c->n_local, keys, sizeof(long long), on_device);   // own rows
 }
 
 extern "C" int ngravs_get_order(ngravs_ctx *c, int32_t *order, int on_device)
@@ -1076,6 +1134,8 @@ extern "C" int ngravs_dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3])
   if(!c || !c->have_particles)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  if(int rc = park_grav_pm(c))   // GravPM of the own rows outlives the order that is about to go (non-PM steps: gravtree.c:318-330)
+    return rc;
   c->n = c->n_local;   // a new step: forget the previous halo
   c->have_order = c->have_tree = false;
   return dd_local_extent(c, lo, hi);
@@ -1188,10 +1248,15 @@ extern "C" int ngravs_dd_recv_buffer(ngravs_ctx *c, int64_t nrec, void **dev_rec
   if(!c || nrec < 0 || !dev_records)
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  if(c->dd_recv.ensure((size_t)(nrec > 0 ? nrec : 1) * NGRAVS_DD_RECORD_BYTES))
+  if(c->dd_recv.ensure((size_t)(nrec > 0 ? nrec : 1) * NGRAVS_DD_MAX_RECORD_BYTES))
     return NGRAVS_ERR_NOMEM;
   *dev_records = c->dd_recv.p;
   return NGRAVS_OK;
+}
+
+extern "C" int64_t ngravs_dd_record_bytes(ngravs_ctx *c, int what)
+{
+  return c ? (int64_t)sizeof(double) * dd_record_doubles(c, what) : NGRAVS_ERR_ARG;
 }
 
 extern "C" int ngravs_dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)

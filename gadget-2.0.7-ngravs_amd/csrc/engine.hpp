@@ -276,6 +276,7 @@ int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, i
 int dd_set_top(ngravs_ctx *c, int level, const double *gcells, const unsigned char *present);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
+int dd_record_doubles(const ngravs_ctx *c, int what);
 // ---- kernels_tree.hip
 int tree_build(ngravs_ctx *c);
 int tree_moments(ngravs_ctx *c, bool refit, bool counts = false);

@@ -525,7 +525,8 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
                                                               const int *__restrict__ type, const double *__restrict__ oldacc,
                                                               const unsigned char *__restrict__ active, const long long *__restrict__ id,
                                                               const double *__restrict__ cost, const unsigned long long *__restrict__ offs,
-                                                              unsigned long long *__restrict__ cursor, DDRecord *__restrict__ out)
+                                                              unsigned long long *__restrict__ cursor, double *__restrict__ out,
+                                                              const double *__restrict__ pm, int rdbl)
 {
   __shared__ unsigned int lcnt[64];                                 // per destination: records of this block
   __shared__ unsigned long long lbase[64];                          // ... and where they start
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
   DDRecord rec;
   rec.x = rec.y = rec.z = rec.m = rec.oldacc = rec.cost = 0;
   rec.meta = 0;
+  double g0 = 0, g1 = 0, g2 = 0;   // migration records of TreePM runs carry P[].GravPM behind the 7 base words (rdbl = 10)
   if(m)
     {
       rec.x = pos[3 * i + 0];
@@ -563,6 +565,12 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
       rec.oldacc = oldacc[i];
       rec.cost = cost[i];
       rec.meta = (long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16);
+      if(pm)
+        {
+          g0 = pm[3 * i + 0];
+          g1 = pm[3 * i + 1];
+          g2 = pm[3 * i + 2];
+        }
     }
   for(unsigned long long any = all; any;)
     {
@@ -571,7 +579,22 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
       const bool mine = ((m >> r) & 1ull) != 0;
       const unsigned long long b = __builtin_amdgcn_ballot_w64(mine);
       if(mine)
-        out[lbase[r] + woff[wave][r] + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = rec;
+        {
+          double *o = out + (size_t)(lbase[r] + woff[wave][r] + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))) * rdbl;
+          o[0] = rec.x;
+          o[1] = rec.y;
+          o[2] = rec.z;
+          o[3] = rec.m;
+          o[4] = rec.oldacc;
+          o[5] = rec.cost;
+          o[6] = __longlong_as_double(rec.meta);
+          if(rdbl > 7)
+            {
+              o[7] = g0;
+              o[8] = g1;
+              o[9] = g2;
+            }
+        }
     }
 }
 
@@ -584,7 +607,7 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_keep(const unsigned long
                                                               double *__restrict__ pos2, double *__restrict__ mass2,
                                                               int *__restrict__ type2, double *__restrict__ oldacc2,
                                                               unsigned char *__restrict__ active2, long long *__restrict__ id2,
-                                                              double *__restrict__ cost2)
+                                                              double *__restrict__ cost2, const double *__restrict__ pm, double *__restrict__ pm2)
 {
   __shared__ unsigned int lcnt;
   __shared__ unsigned long long lbase;
@@ -614,17 +637,32 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_keep(const unsigned long
   active2[k] = active[i];
   id2[k] = id[i];
   cost2[k] = cost[i];
+  if(pm2)
+    for(int j = 0; j < 3; j++)
+      pm2[3 * k + j] = pm ? pm[3 * i + j] : 0.0;
 }
 
-__global__ void k_dd_unpack(const DDRecord *__restrict__ rec, long long nrec, long long at, int halo, double *__restrict__ pos,
+__global__ void k_dd_unpack(const double *__restrict__ rec, int rdbl, long long nrec, long long at, int halo, double *__restrict__ pos,
                             double *__restrict__ mass, int *__restrict__ type, double *__restrict__ oldacc,
-                            unsigned char *__restrict__ active, long long *__restrict__ id, double *__restrict__ cost)
+                            unsigned char *__restrict__ active, long long *__restrict__ id, double *__restrict__ cost,
+                            double *__restrict__ pm)
 {
   long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(k >= nrec)
     return;
-  DDRecord r = rec[k];
+  const double *q = rec + (size_t)k * rdbl;
+  DDRecord r;
+  r.x = q[0];
+  r.y = q[1];
+  r.z = q[2];
+  r.m = q[3];
+  r.oldacc = q[4];
+  r.cost = q[5];
+  r.meta = __double_as_longlong(q[6]);
   long long i = at + k;
+  if(pm)
+    for(int j = 0; j < 3; j++)
+      pm[3 * i + j] = rdbl > 7 ? q[7 + j] : 0.0;
   pos[3 * i + 0] = r.x;
   pos[3 * i + 1] = r.y;
   pos[3 * i + 2] = r.z;
@@ -651,6 +689,9 @@ template <typename T> static int grow_keep(ngravs_ctx *c, DevBuf<T> &b, size_t k
   b = nb;
   return 0;
 }
+
+// doubles per exchanged record: 7 (DDRecord), + P[].GravPM for the migration of a TreePM run (ngravs_dd_record_bytes)
+int dd_record_doubles(const ngravs_ctx *c, int what) { return (what == 0 && c->cfg.pmgrid) ? 10 : 7; }
 
 static void dd_fac(const ngravs_ctx *c, double *fac21) { *fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION)); }
 
@@ -757,14 +798,15 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
       counts[r] = (int64_t)h[r];
       tot += h[r];
     }
-  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(DDRecord)))
+  const int rdbl = dd_record_doubles(c, what);
+  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(double) * rdbl))
     return NGRAVS_ERR_NOMEM;
   if(tot > 0)
     {
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
                          c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
-                         (DDRecord *)c->dd_send.p);
+                         (double *)c->dd_send.p, (what == 0 && c->pm_parked) ? c->pm_orig.p : (const double *)nullptr, rdbl);
     }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -990,7 +1032,7 @@ int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, i
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
                          c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
-                         (DDRecord *)c->dd_send.p);
+                         (double *)c->dd_send.p, (const double *)nullptr, 7);
     }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -1085,25 +1127,29 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
       c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
       return NGRAVS_OK;
     }
-  DevBuf<double> pos2, mass2, old2, cost2;
+  DevBuf<double> pos2, mass2, old2, cost2, pm2;
   DevBuf<int> type2;
   DevBuf<unsigned char> act2;
   DevBuf<long long> id2;
   const size_t cap = (size_t)(n + nrec + 64);
+  const int rdbl = dd_record_doubles(c, 0);
+  const bool with_pm = rdbl > 7;   // TreePM: P[].GravPM moves with the particle (zeros while no PM force exists)
   if(pos2.ensure(3 * cap) || mass2.ensure(cap) || old2.ensure(cap) || type2.ensure(cap) || act2.ensure(cap) || id2.ensure(cap) ||
-     cost2.ensure(cap))
+     cost2.ensure(cap) || (with_pm && pm2.ensure(3 * cap)))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p + 195, 0, sizeof(unsigned long long), c->stream));
   if(n > 0)
     hipLaunchKernelGGL(k_dd_keep, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p,
                        c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 195, pos2.p,
-                       mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p);
+                       mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p, c->pm_parked ? c->pm_orig.p : (const double *)nullptr,
+                       with_pm ? pm2.p : (double *)nullptr);
   unsigned long long kept = 0;
   HIP_TRY(c, hipMemcpyAsync(&kept, c->dd_counts.p + 195, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if(nrec > 0)
-    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
-                       (long long)nrec, (long long)kept, 0, pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p);
+    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const double *)dev_records, rdbl,
+                       (long long)nrec, (long long)kept, 0, pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p,
+                       with_pm ? pm2.p : (double *)nullptr);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   c->in_pos.release();
@@ -1114,6 +1160,11 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
   c->in_id.release();
   c->in_cost.release();
   c->in_cost = cost2;
+  if(with_pm)
+    {
+      c->pm_orig.release();
+      c->pm_orig = pm2;   // pm_parked stays as it was: zeros are not a PM force
+    }
   c->in_pos = pos2;
   c->in_mass = mass2;
   c->in_oldacc = old2;
@@ -1135,9 +1186,9 @@ int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
      grow_keep(c, c->in_cost, nl, tot))
     return NGRAVS_ERR_NOMEM;
   if(nrec > 0)
-    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const DDRecord *)dev_records,
+    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const double *)dev_records, 7,
                        (long long)nrec, nl, 1, c->in_pos.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p,
-                       c->in_cost.p);
+                       c->in_cost.p, (double *)nullptr);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   c->n = tot;

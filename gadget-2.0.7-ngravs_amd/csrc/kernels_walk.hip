@@ -2067,7 +2067,9 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
         wp->inv_asmthfac = 1.0 / wp->asmthfac;
         wp->exp_tab = (wp->ym * wp->inv_asmthfac < 1.0e-3) ? 1 : 0;   // u^5/120 < 1e-17
       }
-    wp->src_in_box = 1;
+    // (a refit tree holds drifted positions the extent below never saw -- the reference does not wrap between decompositions,
+    // predict.c:79-91 --, so the shortcut is off until the next decomposition has checked them)
+    wp->src_in_box = (c->tree_refit || c->tree_stale) ? 0 : 1;
     for(int j = 0; j < 3; j++)
       if(!(c->pos_lo[j] >= 0.0 && c->pos_hi[j] <= cfg.box_size))
         wp->src_in_box = 0;

@@ -226,11 +226,16 @@ class DistributedEngine(Engine):
         self.wall = {"steps": 0, "decomposition_s": 0.0, "decomposition_collectives_s": 0.0, "pm_s": 0.0, "pm_collectives_s": 0.0,
                      "gravity_tree_s": 0.0, "collective_calls": 0}
 
-    def get_accel(self, want_pm=False):
-        """rows of this task's OWN particles (ids from local_ids()); halo rows are dropped"""
+    def get_accel(self, want_pm=False, into=None):
+        """rows of this task's OWN particles (ids from local_ids()); the library never delivers the imported copies"""
+        self.n = self.num_local()
+        return super().get_accel(want_pm=want_pm, into=into)
+
+    def order(self):
+        """Peano order of the working set: own rows [0, num_local()) and the imported copies behind them"""
         nl = self.num_local()
-        total = nl + int(self.timings.get("halo", 0))
-        self.n = total
-        res = super().get_accel(want_pm=want_pm)
-        self.n = nl
-        return tuple(r[:nl] if r is not None else None for r in res)
+        self.n = nl + int(self.info.n_halo)
+        try:
+            return super().order()
+        finally:
+            self.n = nl

@@ -208,14 +208,14 @@ static void ensure_ctx(void)
   memset(&Comm, 0, sizeof(Comm));
   Comm.rank = ThisTask;
   Comm.size = NTask;
-  Comm.device_buffers = 0;	/* set to 1 with a GPU-aware MPI: the exchanges then never touch host memory */
+  Comm.device_buffers = 0;	/* set to 1 with a GPU-aware MPI: the exchanges then never touch host memory (RCCL: ngravs_comm_rccl.h) */
   Comm.allreduce = mpi_allreduce;
   Comm.allgather = mpi_allgather;
   Comm.alltoallv = mpi_alltoallv;
-#ifndef PMGRID
+#if defined(PERIODIC) && !defined(PMGRID)
   if(NTask > 1)
     {
-      printf("ngravs-hip: several tasks need the finite TreePM cut (PMGRID) for the halo decomposition\n");
+      printf("ngravs-hip: periodic tree-only runs (lattice-correction walk, forcetree.c:2077-2455) run on one task only\n");
       endrun(1054);
     }
 #endif
@@ -420,12 +420,84 @@ void force_treefree(void)
   Father = NULL;
 }
 
+/* proto.h:184 -- gravtree.c:468-518: the softening table of the six particle types, comoving lengths capped at their
+ * physical maxima; All.ForceSoftening = 2.8 x the Plummer-equivalent length.  Called by init() (init.c:60), by
+ * compute_potential() (potential.c:40) and at the top of every gravity_tree() of a comoving run (gravtree.c:50-51): the
+ * device library is told every time (ngravs_set_softening), it keeps no copy of its own beyond the last one handed over. */
+void set_softenings(void)
+{
+  const double comoving[6] = { All.SofteningGas, All.SofteningHalo, All.SofteningDisk, All.SofteningBulge, All.SofteningStars,
+    All.SofteningBndry
+  };
+  const double maxphys[6] = { All.SofteningGasMaxPhys, All.SofteningHaloMaxPhys, All.SofteningDiskMaxPhys,
+    All.SofteningBulgeMaxPhys, All.SofteningStarsMaxPhys, All.SofteningBndryMaxPhys
+  };
+  int t;
+  for(t = 0; t < 6; t++)
+    {
+      double eps = comoving[t];
+      if(All.ComovingIntegrationOn && eps * All.Time > maxphys[t])
+	eps = maxphys[t] / All.Time;
+      All.SofteningTable[t] = eps;
+      All.ForceSoftening[t] = 2.8 * eps;
+    }
+  All.MinGasHsml = All.MinGasHsmlFractional * All.ForceSoftening[0];
+  if(Ctx)
+    must(ngravs_set_softening(Ctx, All.ForceSoftening), 1069);
+}
+
+/* proto.h:88 -- forcetree.c:1134: hmax of tree nodes that hold SPH particles, for the hydro neighbour search (accel.c:74).  The
+ * device tree holds no gas (ensure_ctx refuses SphP[] with several tasks; density()/hydro_force() walk the host-side ngb tree,
+ * which this glue does not provide): nothing to update. */
+void force_update_hmax(void)
+{
+}
+
+#ifdef PERIODIC
+/* proto.h:61 -- forcetree.c:3611: the Ewald / lattice-sum correction tables (begrun.c:48, under PERIODIC && (!PMGRID ||
+ * FORCETEST)).  The library tabulates them on the device on first use (k_lattice_table) and needs no file cache. */
+void lattice_init(void)
+{
+}
+#endif
+
+/* proto.h:83-84, :163 -- potentials are outside this path (the reference's own potential walk does not
+ * compile, forcetree.c:2748-2756): compute_potential() (potential.c:94-96, 177-179, 271) ends the run with a clear message
+ * instead of a link error. */
+static void no_potentials(void)
+{
+  printf("ngravs-hip: gravitational potentials are not provided by libngravs_hip (compute_potential(): set the energy statistics off)\n");
+  endrun(1070);
+}
+void force_treeevaluate_potential(int target, int mode)
+{
+  (void)target;
+  (void)mode;
+  no_potentials();
+}
+#ifdef PMGRID
+void force_treeevaluate_potential_shortrange(int target, int mode)
+{
+  (void)target;
+  (void)mode;
+  no_potentials();
+}
+#ifdef PERIODIC
+void pmpotential_periodic(void)
+{
+  no_potentials();
+}
+#endif
+#endif
+
 /* proto.h:114 */
 void gravity_tree(void)
 {
   ngravs_stats_t st;
   double t0 = second(), nf = 0, ia = 0, tw = 0, sum[3];
   ensure_ctx();
+  if(All.ComovingIntegrationOn)	/* gravtree.c:50-51: new softening lengths for the new scale factor */
+    set_softenings();
   must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
   must(ngravs_gravity_tree(Ctx), 1063);
   /* only particles with Ti_endstep == Ti_Current are written (gravtree.c:318-341); inactive rows of P[] keep their values */
@@ -468,6 +540,8 @@ void pmforce_periodic(void)
     must(ngravs_pmforce_periodic(Ctx), 1065);
   else
     must(ngravs_host_pmforce_periodic(Ctx, &Comm), 1066);	/* x-slab decomposed mesh, four exchanges */
+  /* GravPM of all NumPart own particles (pm_periodic.c:716-763); the library delivers own rows only -- the imported copies of a
+   * multi-task working set never reach P[] (ABI 3) */
   must(ngravs_get_accel(Ctx, NULL, 0, &P[0].GravPM[0], sizeof(struct particle_data), NULL, 0, NULL, 0, 0, 0), 1067);
   ngravs_get_stats(Ctx, &st);
   All.CPU_PM += st.t_pm;

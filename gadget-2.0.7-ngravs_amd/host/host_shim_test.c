@@ -149,7 +149,7 @@ static void box_config(ngravs_config_t *cfg)
   cfg->walk_mode = NGRAVS_WALK_STRICT;   /* the reference's per-target walk: its forces must not depend on the number of tasks */
 }
 
-static void hand_over(ngravs_ctx *ctx, struct particle_data *P, int n, ngravs_particles_t *pp)
+static void hand_over(ngravs_ctx *ctx, struct particle_data *P, int n, ngravs_particles_t *pp, int with_pm)
 {
   memset(pp, 0, sizeof(*pp));
   pp->n = n;
@@ -159,54 +159,40 @@ static void hand_over(ngravs_ctx *ctx, struct particle_data *P, int n, ngravs_pa
   pp->old_acc = &P[0].OldAcc;
   pp->grav_cost = &P[0].GravCost;
   pp->pos_stride = pp->mass_stride = pp->type_stride = pp->old_acc_stride = pp->grav_cost_stride = sizeof(struct particle_data);
+  if(with_pm)   /* non-PM step: P[].GravPM of the last PM step enters OldAcc (gravtree.c:318-330), as push_particles() in the glue */
+    {
+      pp->grav_pm = &P[0].GravPM[0];
+      pp->grav_pm_stride = sizeof(struct particle_data);
+    }
   (void)ctx;
 }
 
-static void *task_main(void *arg)
+/* domain_Decomposition() as in gadget_glue.c for NTask > 1: owners, destinations, host-side exchange of whole particle_data
+ * records through the same communicator, the migrated P[] handed over, top-leaf moments + import */
+static int glue_decomposition(ngravs_ctx *ctx, ngravs_comm *cm, shm_rank *u, struct particle_data *P, int *np, int with_pm,
+                              ngravs_dd_info *info)
 {
-  shm_rank *u = arg;
   const int me = u->rank;
-  int i, r, n = 0, nkeep = 0, cap = N2, err = 0;
-  struct particle_data *P = malloc(sizeof(*P) * cap), *out[NT];
-  int nout[NT] = {0, 0};
-  ngravs_config_t cfg;
-  ngravs_ctx *ctx = NULL;
-  ngravs_comm cm;
+  int i, r, n = *np, nkeep = 0, err = 0, nout[NT] = {0, 0};
+  struct particle_data *out[NT];
   ngravs_particles_t pp;
   ngravs_dd_plan plan;
-  ngravs_dd_info info;
   int32_t *dest;
-  intptr_t rc = 0;
-  for(i = me; i < N2; i += NT)   /* an arbitrary initial distribution: every task has particles everywhere */
-    P[n++] = Pall[i];
-  box_config(&cfg);
-  if(ngravs_create(&cfg, &ctx))
-    return (void *)(intptr_t)20;
-  memset(&cm, 0, sizeof(cm));
-  cm.rank = me;
-  cm.size = NT;
-  cm.device_buffers = 0;   /* like a plain MPI: exchange buffers are staged through host memory */
-  cm.user = u;
-  cm.allreduce = shm_allreduce;
-  cm.allgather = shm_allgather;
-  cm.alltoallv = shm_alltoallv;
-  /* ---- domain_Decomposition() as in gadget_glue.c ---- */
-  hand_over(ctx, P, n, &pp);
+  hand_over(ctx, P, n, &pp, with_pm);
   err |= ngravs_set_particles(ctx, &pp);
-  err |= ngravs_host_domain_owners(ctx, &cm, 0, 1.5, &plan, &info);
-  dest = malloc(sizeof(int32_t) * n);
+  err |= ngravs_host_domain_owners(ctx, cm, 0, 1.5, &plan, info);
+  dest = malloc(sizeof(int32_t) * (n > 0 ? n : 1));
   err |= ngravs_dd_get_dest(ctx, plan.level, plan.owner_ph, dest);
   if(err)
-    return (void *)(intptr_t)21;
+    return 21;
   for(r = 0; r < NT; r++)
-    out[r] = malloc(sizeof(*P) * n);
+    out[r] = malloc(sizeof(*P) * (n > 0 ? n : 1));
   for(i = 0; i < n; i++)
     if(dest[i] == me)
       P[nkeep++] = P[i];
     else
       out[dest[i]][nout[dest[i]]++] = P[i];
   {
-    /* exchange_particles(): whole particle_data records, through the same communicator */
     int64_t sb[NT], sd[NT], rb[NT], rd[NT], cnt[NT], mat[NT * NT], tot = 0;
     struct particle_data *sendbuf = malloc(sizeof(*P) * (n > 0 ? n : 1));
     for(r = 0; r < NT; r++)
@@ -226,44 +212,88 @@ static void *task_main(void *arg)
         tot += mat[r * NT + me];
       }
     if(shm_alltoallv(u, sendbuf, sb, sd, P + nkeep, rb, rd))
-      return (void *)(intptr_t)22;
+      return 22;
     n = nkeep + (int)tot;
     free(sendbuf);
   }
-  hand_over(ctx, P, n, &pp);
+  hand_over(ctx, P, n, &pp, with_pm);
   err |= ngravs_set_particles(ctx, &pp);            /* the migrated P[]: its order is the order of the results */
-  err |= ngravs_host_domain_halo(ctx, &cm, &plan, &info);
+  err |= ngravs_host_domain_halo(ctx, cm, &plan, info);
   ngravs_host_plan_free(&plan);
-  /* ---- long_range_force() + gravity_tree() ---- */
+  for(r = 0; r < NT; r++)
+    free(out[r]);
+  free(dest);
+  *np = n;
+  return err ? 23 : 0;
+}
+
+static double Old1b[N2], Old2b[N2];         /* OldAcc of the following non-PM step, single task / two tasks, by ID */
+
+static void *task_main(void *arg)
+{
+  shm_rank *u = arg;
+  const int me = u->rank;
+  int i, r, n = 0, cap = N2, err = 0;
+  struct particle_data *P = malloc(sizeof(*P) * (cap + 1));   /* + one canary row */
+  ngravs_config_t cfg;
+  ngravs_ctx *ctx = NULL;
+  ngravs_comm cm;
+  ngravs_dd_info info;
+  intptr_t rc = 0;
+  for(i = me; i < N2; i += NT)   /* an arbitrary initial distribution: every task has particles everywhere */
+    P[n++] = Pall[i];
+  box_config(&cfg);
+  if(ngravs_create(&cfg, &ctx))
+    return (void *)(intptr_t)20;
+  memset(&cm, 0, sizeof(cm));
+  cm.rank = me;
+  cm.size = NT;
+  cm.device_buffers = 0;   /* like a plain MPI: exchange buffers are staged through host memory */
+  cm.user = u;
+  cm.allreduce = shm_allreduce;
+  cm.allgather = shm_allgather;
+  cm.alltoallv = shm_alltoallv;
+  /* ---- step 1 (a PM step): domain_Decomposition(), long_range_force(), gravity_tree() ---- */
+  if((err = glue_decomposition(ctx, &cm, u, P, &n, 0, &info)))
+    return (void *)(intptr_t)err;
   err |= ngravs_host_pmforce_periodic(ctx, &cm);
   err |= ngravs_gravity_tree(ctx);
   if(err)
     return (void *)(intptr_t)23;
   {
-    /* own rows come first; the library's working set is own + halo */
-    const int64_t tot = info.n_local + info.n_halo;
-    double *a = malloc(sizeof(double) * 3 * tot), *pm = malloc(sizeof(double) * 3 * tot);
-    if(info.n_local != n || ngravs_get_accel(ctx, a, 24, pm, 24, NULL, 0, NULL, 0, 0, 0))
+    /* results straight into P[], which holds exactly NumPart = n rows (the library's working set is own + imported rows; it
+     * must deliver the own rows only): the row behind the last one is a canary */
+    struct particle_data canary;
+    memset(&P[n], 0x5a, sizeof(P[n]));
+    canary = P[n];
+    if(info.n_local != n || info.n_halo <= 0 ||
+       ngravs_get_accel(ctx, &P[0].GravAccel[0], sizeof(*P), &P[0].GravPM[0], sizeof(*P), &P[0].OldAcc, sizeof(*P), &P[0].GravCost,
+                        sizeof(*P), 0, 0))
       return (void *)(intptr_t)24;
+    if(memcmp(&canary, &P[n], sizeof(canary)))
+      return (void *)(intptr_t)25;   /* wrote past NumPart rows */
     for(i = 0; i < n; i++)
       {
         const unsigned id = P[i].ID;
         for(r = 0; r < 3; r++)
           {
-            Acc2[id][r] = a[3 * i + r];
-            Pm2[id][r] = pm[3 * i + r];
+            Acc2[id][r] = P[i].GravAccel[r];
+            Pm2[id][r] = P[i].GravPM[r];
           }
         __sync_fetch_and_add(&Seen2[id], 1);
       }
-    free(a);
-    free(pm);
   }
   if(me == 0)
     printf("two tasks: level %d, work balance %.3f, memory balance %.3f; task 0 holds %ld own + %ld halo particles\n", info.level,
            info.work_balance, info.memory_balance, (long)info.n_local, (long)info.n_halo);
-  for(r = 0; r < NT; r++)
-    free(out[r]);
-  free(dest);
+  /* ---- step 2 (no PM): P[].GravPM of step 1 is handed over with the particles and must enter OldAcc although the task's
+   * working set holds imported rows (gravtree.c:318-330) ---- */
+  if((err = glue_decomposition(ctx, &cm, u, P, &n, 1, &info)))
+    return (void *)(intptr_t)(30 + err);
+  if(ngravs_gravity_tree(ctx) || ngravs_get_accel(ctx, NULL, 0, NULL, 0, &P[0].OldAcc, sizeof(*P), NULL, 0, 0, 0))
+    return (void *)(intptr_t)26;
+  for(i = 0; i < n; i++)
+    Old2b[P[i].ID] = P[i].OldAcc;
   free(P);
   ngravs_destroy(ctx);
   return (void *)rc;
@@ -292,13 +322,17 @@ static int two_tasks(void)
   box_config(&cfg);
   if(ngravs_create(&cfg, &ctx))
     return 10;
-  hand_over(ctx, Pall, N2, &pp);
+  hand_over(ctx, Pall, N2, &pp, 0);
   a = malloc(sizeof(double) * 3 * N2);
   pm = malloc(sizeof(double) * 3 * N2);
   if(ngravs_set_particles(ctx, &pp) || ngravs_compute_accelerations(ctx, 1) || ngravs_get_accel(ctx, a, 24, pm, 24, NULL, 0, NULL, 0, 0, 0))
     return 11;
   memcpy(Acc1, a, sizeof(Acc1));
   memcpy(Pm1, pm, sizeof(Pm1));
+  /* the following non-PM step: OldAcc = |GravAccel + GravPM/G| (gravtree.c:318-330) */
+  if(ngravs_get_accel(ctx, NULL, 0, NULL, 0, Old1b, 8, NULL, 0, 0, 0) || ngravs_set_old_acc(ctx, Old1b, 8, 0) ||
+     ngravs_compute_accelerations(ctx, 0) || ngravs_get_accel(ctx, NULL, 0, NULL, 0, Old1b, 8, NULL, 0, 0, 0))
+    return 14;
   ngravs_destroy(ctx);
   /* two tasks */
   pthread_barrier_init(&World.bar, NULL, NT);
@@ -348,6 +382,13 @@ static int two_tasks(void)
            dpm / pmax, sum / N2, worst, nbig, N2, bad);
     if(bad || dpm / pmax > 1e-10 || nbig > 0)
       return 13;
+    /* the non-PM step after it: same OldAcc as the single task's, i.e. the imported rows did not cost the own rows their GravPM */
+    worst = 0;
+    for(i = 0; i < N2; i++)
+      worst = fmax(worst, fabs(Old2b[i] - Old1b[i]) / Old1b[i]);
+    printf("non-PM step after it: OldAcc two tasks vs one, worst relative difference %.2e\n", worst);
+    if(!(worst < 1e-10))
+      return 15;
   }
   free(a);
   free(pm);
@@ -474,6 +515,48 @@ int main(void)
         if(keep[i][k] != P[i].GravAccel[k])
           bad++;
     free(keep);
+  }
+  /* a comoving run changes All.ForceSoftening[] every step (set_softenings(), gravtree.c:50-51, 468-518): the glue forwards it
+   * with ngravs_set_softening(); pairs closer than the new length must now feel the spline, nothing else may change */
+  {
+    double fs[6], worst2 = 0, changed = 0;
+    const double h2 = 2.8 * 0.05;
+    for(k = 0; k < 6; k++)
+      fs[k] = h2;
+    if(ngravs_set_softening(ctx, fs) || ngravs_compute_accelerations(ctx, 0) ||
+       ngravs_get_accel(ctx, &P[0].Vel[0], sizeof(*P), NULL, 0, NULL, 0, NULL, 0, 0, 0))   /* second force into the Vel slot */
+      return 8;
+    for(i = 0; i < N; i += 7)
+      {
+        double a[3] = {0, 0, 0}, e2 = 0, n2 = 0, c2 = 0;
+        if(!active[i])
+          continue;
+        for(j = 0; j < N; j++)
+          {
+            double d[3], r2 = 0, r, fac;
+            for(k = 0; k < 3; k++)
+              {
+                d[k] = P[j].Pos[k] - P[i].Pos[k];
+                r2 += d[k] * d[k];
+              }
+            r = sqrt(r2);
+            fac = r >= h2 ? P[j].Mass / r2 / r : plummer(P[j].Mass, h2, r);
+            for(k = 0; k < 3; k++)
+              a[k] += d[k] * fac * cfg.G;
+          }
+        for(k = 0; k < 3; k++)
+          {
+            e2 += (a[k] - P[i].Vel[k]) * (a[k] - P[i].Vel[k]);
+            c2 += (P[i].GravAccel[k] - P[i].Vel[k]) * (P[i].GravAccel[k] - P[i].Vel[k]);
+            n2 += a[k] * a[k];
+          }
+        worst2 = fmax(worst2, sqrt(e2 / n2));
+        changed = fmax(changed, sqrt(c2 / n2));
+      }
+    printf("after ngravs_set_softening(5 x): worst error against the direct sum with the NEW length %.3e; forces moved by up to %.2e\n",
+           worst2, changed);
+    if(!(worst2 < 0.1 && changed > 0.05))
+      bad++;
   }
   ngravs_stats_t st;
   ngravs_get_stats(ctx, &st);

@@ -172,8 +172,9 @@ int ngravs_host_split(const int64_t *count, const double *work, int64_t ncell, i
   rc = find_split(&S, 0, ntask, 0, (int)ncell - 1);
   if(rc == 0 && work)
     {
-      /* domain_shiftSplit (domain.c:468-544): move boundary cells between neighbours while that lowers the larger of the
-       * two work sums and keeps the particle load within bounds */
+      /* domain_shiftSplit (domain.c:468-544): move boundary cells between neighbours while that LOWERS the larger of the
+       * two work sums (strictly: a move that leaves it unchanged would be undone by the next sweep, for ever) and keeps the
+       * particle load within bounds */
       for(t = 0; t < ntask; t++)
         wk[t] = 0;
       for(i = 0; i < ncell; i++)
@@ -189,7 +190,7 @@ int ngravs_host_split(const int64_t *count, const double *work, int64_t ncell, i
                   const int cell = S.start[t + 1];
                   if(S.end[t + 1] <= cell)   /* the neighbour keeps at least one cell */
                     continue;
-                  if(fmax(wk[t] + work[cell], wk[t + 1] - work[cell]) <= maxw && S.load[t] + (double)count[cell] <= S.maxload)
+                  if(fmax(wk[t] + work[cell], wk[t + 1] - work[cell]) < maxw && S.load[t] + (double)count[cell] <= S.maxload)
                     {
                       wk[t] += work[cell];
                       wk[t + 1] -= work[cell];
@@ -206,7 +207,7 @@ int ngravs_host_split(const int64_t *count, const double *work, int64_t ncell, i
                   const int cell = S.end[t];
                   if(S.start[t] >= cell)
                     continue;
-                  if(fmax(wk[t] - work[cell], wk[t + 1] + work[cell]) <= maxw && S.load[t + 1] + (double)count[cell] <= S.maxload)
+                  if(fmax(wk[t] - work[cell], wk[t + 1] + work[cell]) < maxw && S.load[t + 1] + (double)count[cell] <= S.maxload)
                     {
                       wk[t] -= work[cell];
                       wk[t + 1] += work[cell];
@@ -391,10 +392,11 @@ static int record_exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_
     rc = cm->allgather(cm->user, counts, mat, (int64_t)sizeof(int64_t) * W);
   if(!rc)
     {
+      const int64_t rbytes = ngravs_dd_record_bytes(ctx, what);   /* migration records of TreePM runs carry GravPM */
       for(r = 0; r < W; r++)
         {
-          sb[r] = counts[r] * NGRAVS_DD_RECORD_BYTES;
-          rb[r] = mat[(size_t)r * W + me] * NGRAVS_DD_RECORD_BYTES;
+          sb[r] = counts[r] * rbytes;
+          rb[r] = mat[(size_t)r * W + me] * rbytes;
           nrecv += mat[(size_t)r * W + me];
           if(r != me)
             *(what == 0 ? &info->bytes_migration : &info->bytes_halo) += (double)sb[r];
@@ -790,7 +792,7 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int
 }
 
 /* ---- pmforce_periodic on the slab-decomposed mesh -------------------------------------------------------------------------- */
-static double pm_seconds[13];   /* last call: [0] deposit + bounding boxes, then per stage s: [1+3s] pack, [2+3s] exchange, [3+3s] unpack */
+static __thread double pm_seconds[13];   /* per host thread (host_shim_test runs two tasks as two threads); last call: [0] deposit + bounding boxes, then per stage s: [1+3s] pack, [2+3s] exchange, [3+3s] unpack */
 
 void ngravs_host_pm_seconds(double out[13])
 {

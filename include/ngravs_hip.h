@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define NGRAVS_ABI_VERSION 2
+#define NGRAVS_ABI_VERSION 3
 #define NGRAVS_MAX_GRAVS 3      /* N_GRAVS upper bound compiled in (allvars.h:130-152)            */
 #define NGRAVS_NTYPES 6         /* Gadget particle types                                           */
 #define NGRAVS_NTAB 2048        /* NTAB: short-range table length (Makefile.reference, forcetree.c:33) */
@@ -176,6 +176,10 @@ void ngravs_set_fatal_handler(ngravs_ctx *ctx, ngravs_fatal_fn fn);
 /* Change the walk parameters between calls (All.ErrTolTheta latch, gravtree.c:334-335). */
 int ngravs_set_opening(ngravs_ctx *ctx, double err_tol_theta, double err_tol_force_acc);
 int ngravs_set_walk_mode(ngravs_ctx *ctx, int walk_mode);
+/* New All.ForceSoftening[6] (= 2.8 * All.SofteningTable[]): set_softenings() (gravtree.c:468-518) recomputes it from the scale
+ * factor at the top of every gravity_tree() of a comoving run (gravtree.c:50-51); the glue's set_softenings() forwards it here.
+ * Takes effect from the next walk / direct sum / import decision on. */
+int ngravs_set_softening(ngravs_ctx *ctx, const double force_softening[NGRAVS_NTYPES]);
 /* the configuration the context was created with (opening parameters as last set) */
 int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
 /* Performance / test parameters of the engine, by name (none changes WHAT is computed beyond rounding; there is no
@@ -227,6 +231,9 @@ int ngravs_compute_accelerations(ngravs_ctx *ctx, int pm_step);
 
 /* ---- results, in the caller's ORIGINAL particle order -------------------------------------- */
 /* Any pointer may be NULL.  stride in bytes as above.  grav_cost = ninteractions (gravtree.c).
+ * Rows: exactly the caller's own particles, i.e. the n rows of the last ngravs_set_particles() (ngravs_dd_num_local() rows after
+ * a library-side migration) -- the copies of other tasks' particles a multi-task step imports are never delivered, so an array
+ * of NumPart rows is enough (ABI 3; ABI 2 wrote NumPart + imported rows).
  * only_active != 0: GravAccel / OldAcc / GravCost are written ONLY for the rows the last hand-over marked active, as the
  * reference does (gravtree.c:318-341 touch only Ti_endstep == Ti_Current) -- inactive rows of the caller's arrays keep
  * their values.  only_active == 0: every row is written; rows that were not walked read GravAccel = 0, GravCost = 0 and
@@ -277,6 +284,11 @@ int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *a
  * Records are 56 bytes (NGRAVS_DD_RECORD_BYTES): x,y,z,mass,old_acc,grav_cost (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64.
  * ngravs_host.h holds this sequence as plain C over a communicator vtable (MPI in the reference glue, RCCL in bench.py). */
 #define NGRAVS_DD_RECORD_BYTES 56
+#define NGRAVS_DD_MAX_RECORD_BYTES 80
+/* bytes per record of ngravs_dd_pack(what, ...): what = 0 (migration) of a TreePM run appends P[].GravPM[3] (the particle's
+ * long-range force of the last PM step travels with it, as the whole particle_data does in domain_exchangeParticles,
+ * domain.c:695-795; OldAcc on non-PM steps needs it, gravtree.c:318-330): 80 bytes; everything else NGRAVS_DD_RECORD_BYTES */
+int64_t ngravs_dd_record_bytes(ngravs_ctx *ctx, int what);
 int64_t ngravs_dd_num_local(ngravs_ctx *ctx);
 int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);             /* domain.c:894-905 */
 int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */

@@ -43,7 +43,11 @@ extern struct global_data_all_processes
   double G, BoxSize, Time;
   int NumCurrentTiStep, Ti_Current, PM_Ti_endstep;
   double Asmth[2], Rcut[2];
-  double ForceSoftening[6];
+  double ForceSoftening[6], SofteningTable[6];
+  double SofteningGas, SofteningHalo, SofteningDisk, SofteningBulge, SofteningStars, SofteningBndry;
+  double SofteningGasMaxPhys, SofteningHaloMaxPhys, SofteningDiskMaxPhys, SofteningBulgeMaxPhys, SofteningStarsMaxPhys, SofteningBndryMaxPhys;
+  double MinGasHsml, MinGasHsmlFractional;
+  int ComovingIntegrationOn;
   double TreeDomainUpdateFrequency;
   double CPU_TreeConstruction, CPU_TreeWalk, CPU_Imbalance, CPU_PM, CPU_Domain, CPU_Peano;
   char OutputDir[MAXLEN_FILENAME];

@@ -72,8 +72,17 @@ def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
     eng.set_particles(pos[mine], mass[mine], typ[mine], old_acc=old[mine], ids=mine)
     eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
     acc, oa, cost = eng.get_accel()[:3]
-    np.savez(os.path.join(out_dir, "s%d.npz" % rank), ids=eng.local_ids(), acc=acc, cost=cost, old=oa,
-             halo=np.array([eng.timings["halo"], eng.num_local()]))
+    ids1, halo1, nloc1 = eng.local_ids(), eng.timings["halo"], eng.num_local()
+    extra = {}
+    if cfg.pmgrid:
+        # a step WITHOUT the PM force: GravPM of the PM step must still enter OldAcc (gravtree.c:318-330) although the cut moves
+        # (now weighted by the first step's GravCost: particles migrate, and their GravPM with them) and although the working
+        # set holds imported rows
+        eng.compute_accelerations(pm_step=False)
+        a2, o2, c2, p2 = eng.get_accel(want_pm=True)
+        extra = dict(ids2=eng.local_ids(), acc2=a2, old2=o2, cost2=c2, pm2=p2, mig2=np.array([eng.timings["migrated"], eng.timings["halo"]]))
+    np.savez(os.path.join(out_dir, "s%d.npz" % rank), ids=ids1, acc=acc, cost=cost, old=oa,
+             halo=np.array([halo1, nloc1]), **extra)
     eng.close()
     dist.destroy_process_group()
 
@@ -126,6 +135,25 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
           (case, err.max(), np.array_equal(cost, c1), c1.mean()))
     assert np.array_equal(cost, c1)
     assert err.max() < 1e-10
+    if cfg.pmgrid:
+        # the following non-PM step: OldAcc = |GravAccel + GravPM/G| with the GravPM of the PM step
+        eng = pkg.Engine(cfg)
+        eng.set_particles(pos, mass, typ, old_acc=old)
+        eng.compute_accelerations(pm_step=True)
+        eng.compute_accelerations(pm_step=False)
+        a1, o1, c1, p1 = eng.get_accel(want_pm=True)
+        eng.close()
+        o2, c2, p2, moved = np.zeros(n), np.zeros(n), np.zeros((n, 3)), 0
+        for r in range(world):
+            d = np.load(os.path.join(str(tmp_path), "s%d.npz" % r))
+            o2[d["ids2"]], c2[d["ids2"]], p2[d["ids2"]] = d["old2"], d["cost2"], d["pm2"]
+            moved += int(d["mig2"][0])
+            assert d["mig2"][1] > 0           # imported rows were present
+        eo = np.abs(o2 - o1).max() / o1.max()
+        print("non-PM step: %d particles migrated with their GravPM; OldAcc 3 tasks vs 1: %.2e; GravPM carried: %.2e" %
+              (moved, eo, np.abs(p2 - p1).max() / np.abs(p1).max()))
+        assert moved > 0
+        assert np.array_equal(c2, c1) and eo < 1e-10 and np.abs(p2 - p1).max() / np.abs(p1).max() < 1e-10
 
 
 def test_one_task_over_rccl(pkg, tmp_path):

@@ -22,7 +22,7 @@ def test_c_host_links_against_the_abi(pkg, have_lib):
 
 
 @pytest.mark.parametrize("flags", [[], ["-DPERIODIC", "-DPMGRID=64"], ["-DPERIODIC", "-DPMGRID=64", "-DFORCETEST=0.1"],
-                                   ["-DFORCETEST=0.1", "-DN_GRAVS=3"]])
+                                   ["-DFORCETEST=0.1", "-DN_GRAVS=3"], ["-DPERIODIC"]])
 def test_glue_compiles_against_the_reference_interface(pkg, flags):
     """gadget_glue.c is what a maintainer drops into the reference tree.  The reference cannot be built here (GSL, FFTW-2),
     so the glue is compiled -fsyntax-only -Wall -Wextra -Werror against tests/glue_stub/: declarations of exactly the
@@ -38,6 +38,49 @@ def test_glue_compiles_against_the_reference_interface(pkg, flags):
     cmd.remove("-DDOUBLEPRECISION")
     out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode != 0 and "DOUBLEPRECISION" in out.stderr
+
+
+OPTION_SETS = [[], ["-DPERIODIC", "-DPMGRID=64"], ["-DPERIODIC", "-DPMGRID=64", "-DFORCETEST=0.1"], ["-DFORCETEST=0.1", "-DN_GRAVS=3"],
+               ["-DPERIODIC"]]
+
+
+@pytest.mark.parametrize("flags", OPTION_SETS)
+def test_glue_defines_every_symbol_the_link_recipe_needs(pkg, flags, tmp_path):
+    """INTEGRATION.md's recipe drops gravtree.o forcetree.o pm_periodic.o domain.o peano.o gravtree_forcetest.o from the
+    reference's OBJS and adds gadget_glue.o.  tests/golden/glue_required_symbols.json (written by tools/glue_required_symbols.py
+    in the build container: NAMES of the non-static functions those six units define and a kept unit calls, with the #if guards
+    of their definitions) says what the kept objects will look for; the glue, compiled to an object against the interface
+    stubs, must define every one of them under the same options -- checked with nm, so a forgotten symbol is a test failure
+    here instead of a link error in the maintainer's tree."""
+    import json
+    root = os.path.join(os.path.dirname(pkg.__file__), "..")
+    glue = os.path.join(os.path.dirname(pkg.__file__), "host", "gadget_glue.c")
+    obj = str(tmp_path / "gadget_glue.o")
+    cmd = ["gcc", "-c", "-O0", "-Wall", "-Wextra", "-Werror", "-DNGRAVS_BUILD_INSIDE_REFERENCE", "-DDOUBLEPRECISION",
+           "-DUNEQUALSOFTENINGS", "-I" + os.path.join(root, "tests", "glue_stub"), "-I" + os.path.join(root, "include")] + flags + \
+          [glue, "-o", obj]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    nm = subprocess.run(["nm", "--defined-only", obj], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in nm.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TtDdBb"}
+    macros = {f[2:].split("=")[0] for f in flags}
+    req = json.load(open(os.path.join(root, "tests", "golden", "glue_required_symbols.json")))["required"]
+    assert len(req) >= 16
+    missing = []
+    for name, rec in req.items():
+        on = True
+        for g in rec["guards"]:
+            m = g.replace("#ifdef", "").strip()
+            assert g.startswith("#ifdef"), g      # the only guard form on these definitions
+            on = on and m in macros
+        if on and name not in defined:
+            missing.append("%s (%s, called from %s)" % (name, rec["defined"], rec["used_by"][0]))
+    assert not missing, "gadget_glue.o does not define: " + ", ".join(missing)
+    # and it must not define what a KEPT unit defines (duplicate symbols at link time)
+    undefined = {ln.split()[-1] for ln in subprocess.run(["nm", "-u", obj], capture_output=True, text=True).stdout.splitlines()}
+    for kept_symbol in ("endrun", "second", "timediff", "do_box_wrapping", "get_random_number"):
+        assert kept_symbol not in defined
+    assert {"endrun", "ngravs_create", "ngravs_gravity_tree"} <= undefined
 
 
 def test_glue_source_mentions_every_entry_point(pkg):
