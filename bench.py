@@ -11,10 +11,14 @@ A "step" is one compute_accelerations(): domain extent + Peano keys + sort (doma
 pmforce_periodic, force_treebuild, gravity_tree (walk + OldAcc/G post-processing) for ALL particles,
 inputs already resident in HBM.  value = particles * steps / wall time (max over ranks).
 
-  --gpus N : one process per GPU (torch.distributed / RCCL only for the barrier and the max-reduce).
-             Every rank holds the full particle set; the tree walk -- >= 90 % of the step -- is sharded
-             into N contiguous Peano segments (strong scaling, no data-path collective);
-             decomposition, tree build and PM are still replicated this round (DESIGN.md "Multi-GPU").
+  --gpus N : one process per GPU, N tasks over RCCL (torch.distributed backend "nccl").  Started by the driver's
+             `python -m torch.distributed.run ... bench.py --gpus N`, or by itself: without WORLD_SIZE in the environment
+             `python bench.py --gpus N` starts its own N children through torch.distributed.run (the parent never touches
+             a GPU) and relays rank 0's JSON line and exit code.
+             Default decomposition (TreePM configs): the reference's own -- work-weighted Peano-Hilbert domains cut at
+             top-tree leaves, particle migration, all-reduced top-leaf moments + import of the top-tree cells a task may
+             open, x-slab decomposed PM with four plane exchanges; total work is fixed: "scaling": "strong".
+             --decomp replicated (tree-only configs): every rank holds all particles, only the walk is sharded.
 """
 import argparse
 import json
@@ -43,6 +47,10 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
         b += 88 + 64 * g * cells_per_particle
     return b
 
+
+# ngravs_dd_info.seconds[] (include/ngravs_host.h)
+DD_STAGES = ["extent+leaf_sums+top_tree+cut", "migration", "of_the_first:leaf_sum_passes+allreduce", "import_decision_host",
+             "count/request_allgather+pack", "import_exchange+unpack", "global_top", "local_decomposition"]
 
 TRAFFIC_PROFILE = os.path.join("profiles", "r02_walk_traffic.json")
 
@@ -181,6 +189,26 @@ def cpu_baseline(pkg, n_gravs, wiring, cells_per_particle):
     }
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) as CHILD processes and relay what they print.  The parent initialises no GPU and no
+    process group; it only waits.  Returns the children's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on these hosts (RCCL across processes)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:                             # rank 0 prints the one JSON line; anything else is passed through too
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,9 +224,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
                     help="ngravs_set_tuning() parameters, e.g. --tune walk_sg=2 (experiments; the default run sets none)")
     ap.add_argument("--decomp", default=None, choices=["replicated", "domain"],
-                    help="N>1: 'domain' (default) = work-weighted Peano-Hilbert domain decomposition: migration + short-range halo "
-                         "all-to-all-v, x-slab decomposed PM with four plane exchanges (DESIGN.md Multi-GPU); 'replicated' = every "
-                         "rank holds all particles and only the walk is sharded (no data-path collective; tree-only configs)")
+                    help="N>1: 'domain' (default) = work-weighted Peano-Hilbert domain decomposition: migration, all-reduced top-leaf "
+                         "moments + import of the top-tree cells a task may open, x-slab decomposed PM with four plane exchanges "
+                         "(DESIGN.md 7); 'replicated' = every rank holds all particles and only the walk is sharded (no data-path "
+                         "collective; default for the tree-only configs)")
     ap.add_argument("--config", default="c4", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 (default, the metric's) | c5: 256M N_GRAVS=3 PMGRID=1024 | c3: 16M N_GRAVS=1 PMGRID=256 | "
                          "c2: 4M Plummer tree-only | c1: the reference's own GalaxyCollision.IC (60k particles, N_GRAVS=2, tree-only)")
@@ -210,6 +239,9 @@ def main():
     if args.config == "c2":
         args.log2n, args.ngravs, args.wiring = (22 if args.log2n == 26 else args.log2n), 1, "newton"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))     # before anything in this process could touch a GPU
+
     import torch
     import torch.distributed as dist
 
@@ -217,8 +249,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # rehearsal knobs (one-GPU box): NGRAVS_BENCH_BACKEND=gloo NGRAVS_BENCH_DEVICE=0 puts every rank on GPU 0
@@ -305,8 +336,8 @@ def main():
         # OldAcc of the own particles (first num_local rows of the working set) feeds the next pass
         nl = eng.num_local()
         tot = nl + int(eng.timings.get("halo", 0))
-        tmp = torch.zeros(tot, dtype=torch.float64, device=dev)
-        eng.get_old_acc_device(tmp.data_ptr())
+        tmp = torch.zeros(tot, dtype=torch.float64, device=dev)    # ngravs_set_old_acc reads the working set's rows; own rows first
+        eng.get_old_acc_device(tmp.data_ptr())                     # ... the library delivers exactly those
         eng._check(pkg.lib().ngravs_set_old_acc(eng._h, tmp.data_ptr(), 8, 1), "ngravs_set_old_acc")
     else:
         eng.get_old_acc_device(d_old.data_ptr())
@@ -368,6 +399,9 @@ def main():
                                    (args.config.upper(), n, "GalaxyCollision.IC" if args.config == "c1" else ("Plummer sphere" if treeonly else "uniform periodic box"), args.ngravs,
                                     args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
+                       "mesh_cells_per_particle": cells_per_particle,   # the short-range sphere holds ~ 1/this: ia_per_particle scales with it
+                       "backend": (eng.backend if domain else (dist.get_backend() if world > 1 else None)),
+                       "world_size_reported_by_backend": (eng.comm.world_reported if domain else (dist.get_world_size() if world > 1 else 1)),
                        "parallelism": ("work-weighted Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, x-slab decomposed PM (4 plane exchanges)" % world)
                        if domain else ("walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world),
                        "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
@@ -399,9 +433,9 @@ def main():
                 "pm_exchange_bytes": eng.pm_bytes() if not treeonly else None,
                 "pm_stage_ms": (lambda v: {"deposit+boxes": v[0], "pack": [v[1], v[4], v[7], v[10]], "alltoallv": [v[2], v[5], v[8], v[11]],
                                            "unpack": [v[3], v[6], v[9], v[12]]})([1e3 * x for x in eng.pm_seconds()]) if not treeonly else None,
-                "decomposition_stage_ms": dict(zip(["extent+histogram+split", "migration", "top_cell_sums", "need_test_host", "requests+pack",
-                                                    "import_exchange+unpack", "global_top", "local_decomposition"],
-                                                   [1e3 * float(v) for v in eng.info.seconds]))}
+                "top_tree": {"nodes": int(eng.info.n_topnodes), "leaves": int(eng.info.n_topleaves), "counting_rounds": int(eng.info.toptree_rounds)},
+                "decomposition_collectives": int(eng.info.collectives),
+                "decomposition_stage_ms": dict(zip(DD_STAGES, [1e3 * float(v) for v in eng.info.seconds]))}
         if world == 1 and not treeonly and not args.no_accuracy:
             out["accuracy"] = accuracy_block(pkg, eng, n, dev)
         else:

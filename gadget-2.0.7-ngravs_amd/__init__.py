@@ -33,16 +33,21 @@ EXPORTS = [
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
-    "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_dd_histogram", "ngravs_dd_pack",
-    "ngravs_dd_apply_migration", "ngravs_dd_set_halo", "ngravs_dd_set_ids", "ngravs_dd_get_ids",
-    "ngravs_dd_recv_buffer", "ngravs_dd_get_dest", "ngravs_dd_cell_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack_cells",
-    "ngravs_dd_set_top", "ngravs_get_domain_extent", "ngravs_pm_deposit", "ngravs_pm_density", "ngravs_pm_finish",
+    "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
+    "ngravs_dd_get_toptree", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
+    "ngravs_dd_pack_leaves", "ngravs_dd_set_top", "ngravs_dd_recv_buffer", "ngravs_dd_apply_migration", "ngravs_dd_set_halo",
+    "ngravs_dd_set_ids", "ngravs_dd_get_ids",
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
 HOST_EXPORTS = ["ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
                 "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
-                "ngravs_host_pm_seconds"]
+                "ngravs_host_pm_seconds", "ngravs_host_toptree_init", "ngravs_host_toptree_from_children", "ngravs_host_toptree_adapt",
+                "ngravs_host_toptree_free", "ngravs_host_import_request"]
+# include/ngravs_comm_rccl.h (libngravs_rccl.so: the communicator vtable over RCCL, plain C)
+RCCL_LIB_PATH = os.path.join(_HERE, "libngravs_rccl.so")
+RCCL_EXPORTS = ["ngravs_rccl_unique_id", "ngravs_rccl_create", "ngravs_rccl_fill", "ngravs_rccl_destroy", "ngravs_rccl_stats",
+                "ngravs_rccl_last_error", "ngravs_rccl_world", "ngravs_rccl_barrier"]
 
 
 class NgravsError(RuntimeError):
@@ -96,18 +101,19 @@ def lib():
         L.ngravs_direct_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ngravs_dd_local_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_dd_set_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.ngravs_dd_histogram.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ngravs_get_config.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_host_split.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_void_p]
-        L.ngravs_dd_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]
+        L.ngravs_dd_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ngravs_host_toptree_init.argtypes = [C.c_void_p, C.c_int]
+        L.ngravs_host_toptree_from_children.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.ngravs_host_toptree_adapt.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+        L.ngravs_host_toptree_free.argtypes = [C.c_void_p]
+        L.ngravs_host_toptree_free.restype = None
+        L.ngravs_host_import_request.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.ngravs_dd_apply_migration.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ngravs_dd_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.ngravs_dd_set_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ngravs_dd_get_ids.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        L.ngravs_pm_deposit.argtypes = [C.c_void_p]
-        L.ngravs_pm_finish.argtypes = [C.c_void_p]
-        L.ngravs_pm_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB
 

@@ -321,19 +321,18 @@ extern "C" void ngravs_destroy(ngravs_ctx *c)
   c->in_id.release();
   c->dd_mask.release();
   c->dd_counts.release();
-  c->dd_owner_ph.release();
-  c->dd_owner_xyz.release();
   c->dd_send.release();
   c->dd_recv.release();
-  c->dd_hist.release();
-  c->dd_work.release();
-  c->dd_cells.release();
+  c->top.child.release();
+  c->top.leaf.release();
   c->top.gcnt.release();
-  c->top.cellxyz.release();
+  c->top.info.release();
   c->top.gsum.release();
-  c->top.partial.release();
+  c->top.leaf_owner.release();
   c->top.reqmask.release();
-  c->n_prefix.release();
+  c->top.leaf_sums.release();
+  ngravs_host_toptree_free(&c->top.h);
+  c->n_top.release();
   c->s_pm.release();
   c->s_type.release();
   c->s_active.release();
@@ -651,7 +650,7 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   else
     {
       c->have_order = c->have_tree = c->have_pm = c->have_acc = false;   // new P[]: nothing carries over ...
-      c->top.level = 0;
+      c->top.on = false;   // (the top tree itself is kept: it is the first guess of the next decomposition)
       c->pm_parked = false;
       if(p->grav_pm && c->cfg.pmgrid)
         {
@@ -1158,35 +1157,38 @@ extern "C" int ngravs_dd_set_extent(ngravs_ctx *c, const double lo[3], const dou
   return NGRAVS_OK;
 }
 
-extern "C" int ngravs_dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
+extern "C" int ngravs_dd_set_toptree(ngravs_ctx *c, int32_t nnode, const int32_t *child)
 {
-  if(!c || !c->have_particles || !c->extent_override || !hist || level < 1 || level > 7)
-    return NGRAVS_ERR_STATE;
+  if(!c || !child || nnode < 1)
+    return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  return dd_histogram(c, level, hist, work);
+  return dd_set_toptree(c, nnode, child);
 }
 
-extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
-                              int my_rank, int64_t *counts, void **dev_records, int64_t *nrec)
+extern "C" int ngravs_dd_get_toptree(ngravs_ctx *c, int32_t *nnode, const int32_t **child)
 {
-  if(!c || !c->have_particles || !c->extent_override || !owner_ph || !owner_xyz || !counts || !dev_records || !nrec)
+  if(!c || !nnode || !child)
+    return NGRAVS_ERR_ARG;
+  *nnode = c->top.h.nnode;
+  *child = c->top.h.child;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_dd_leaf_sums(ngravs_ctx *c, void **dev_sums, int64_t *count)
+{
+  if(!c || !c->have_particles || !c->extent_override || !dev_sums || !count)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  double reach = 0;
-  if(what == 1)
-    {
-      if(!c->cfg.pmgrid)
-        {
-          ngravs_report(c, NGRAVS_ERR_ARG, "halo decomposition needs the finite TreePM cut (tree-only runs use replicated sources)");
-          return NGRAVS_ERR_ARG;
-        }
-      WalkParams wp;
-      make_walk_params(c, &wp);
-      reach = sqrt(wp.reach2);
-      if(c->cfg.periodic)
-        reach += c->dom[6] - c->cfg.box_size;   // the curve's cube is 1.001 x the box: seam slack, conservative
-    }
-  return dd_pack(c, what, level, owner_ph, owner_xyz, nranks, my_rank, reach, counts, dev_records, nrec);
+  return dd_leaf_sums(c, dev_sums, count);
+}
+
+extern "C" int ngravs_dd_pack(ngravs_ctx *c, int what, const int32_t *leaf_owner, int nranks, int my_rank, int64_t *counts,
+                              void **dev_records, int64_t *nrec)
+{
+  if(!c || !c->have_particles || !c->extent_override || !leaf_owner || !counts || !dev_records || !nrec)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_pack(c, what, leaf_owner, nranks, my_rank, counts, dev_records, nrec);
 }
 
 extern "C" int ngravs_get_domain_extent(ngravs_ctx *c, double out[8])
@@ -1197,14 +1199,6 @@ extern "C" int ngravs_get_domain_extent(ngravs_ctx *c, double out[8])
   return NGRAVS_OK;
 }
 
-extern "C" int ngravs_dd_cell_sums(ngravs_ctx *c, int level, double *cells)
-{
-  if(!c || !c->have_particles || !c->extent_override || !cells || level < 1 || level > 7)
-    return NGRAVS_ERR_STATE;
-  (void)hipSetDevice(c->cfg.device);
-  return dd_cell_sums(c, level, cells);
-}
-
 extern "C" int ngravs_dd_target_bounds(ngravs_ctx *c, double out[2])
 {
   if(!c || !c->have_particles || !out)
@@ -1213,34 +1207,34 @@ extern "C" int ngravs_dd_target_bounds(ngravs_ctx *c, double out[2])
   return dd_target_bounds(c, out);
 }
 
-extern "C" int ngravs_dd_pack_cells(ngravs_ctx *c, int level, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts,
-                                    void **dev_records, int64_t *nrec)
+extern "C" int ngravs_dd_pack_leaves(ngravs_ctx *c, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts, void **dev_records,
+                                     int64_t *nrec)
 {
   if(!c || !c->have_particles || !c->extent_override || !reqmask || !counts || !dev_records || !nrec)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  return dd_pack_cells(c, level, (const unsigned long long *)reqmask, nranks, my_rank, counts, dev_records, nrec);
+  return dd_pack_leaves(c, (const unsigned long long *)reqmask, nranks, my_rank, counts, dev_records, nrec);
 }
 
-extern "C" int ngravs_dd_set_top(ngravs_ctx *c, int level, const double *gcells, const uint8_t *present)
+extern "C" int ngravs_dd_set_top(ngravs_ctx *c, const double *node_sums, const uint8_t *present)
 {
   if(!c)
     return NGRAVS_ERR_ARG;
-  if(level > 0 && c->cfg.periodic && !c->cfg.pmgrid)
+  if(node_sums && c->cfg.periodic && !c->cfg.pmgrid)
     {
       ngravs_report(c, NGRAVS_ERR_ARG, "multi-task periodic tree-only runs (lattice correction walk) are not supported");
       return NGRAVS_ERR_ARG;
     }
   (void)hipSetDevice(c->cfg.device);
-  return dd_set_top(c, level, gcells, present);
+  return dd_set_top(c, node_sums, present);
 }
 
-extern "C" int ngravs_dd_get_dest(ngravs_ctx *c, int level, const int32_t *owner_ph, int32_t *dest)
+extern "C" int ngravs_dd_get_dest(ngravs_ctx *c, const int32_t *leaf_owner, int32_t *dest)
 {
-  if(!c || !c->have_particles || !c->extent_override || !owner_ph || !dest || level < 1 || level > 7)
+  if(!c || !c->have_particles || !c->extent_override || !leaf_owner || !dest)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
-  return dd_get_dest(c, level, owner_ph, dest);
+  return dd_get_dest(c, leaf_owner, dest);
 }
 
 extern "C" int ngravs_dd_recv_buffer(ngravs_ctx *c, int64_t nrec, void **dev_records)
@@ -1292,47 +1286,6 @@ extern "C" int ngravs_dd_get_ids(ngravs_ctx *c, int64_t *ids, int on_device)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
   return download_strided(c, c->in_id.p, sizeof(long long), 1, c->n_local, ids, sizeof(long long), on_device);
-}
-
-// pmforce_periodic in two halves, so that a multi-task host can all-reduce the density mesh in between
-extern "C" int ngravs_pm_deposit(ngravs_ctx *c)
-{
-  if(!c || !c->have_order)
-    return NGRAVS_ERR_STATE;
-  (void)hipSetDevice(c->cfg.device);
-  if(!c->have_tree)
-    {
-      int64_t nn = ngravs_force_treebuild(c);
-      if(nn < 0)
-        return (int)nn;
-    }
-  HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-  int rc = pm_deposit(c);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  return rc;
-}
-
-extern "C" int ngravs_pm_density(ngravs_ctx *c, void **dev, int64_t *count)
-{
-  if(!c || !dev || !count || !c->pm_rho.p)
-    return NGRAVS_ERR_STATE;
-  const int64_t N = c->cfg.pmgrid;
-  *dev = c->pm_rho.p;
-  *count = (int64_t)c->cfg.n_gravs * N * N * (N + 2);
-  return NGRAVS_OK;
-}
-
-extern "C" int ngravs_pm_finish(ngravs_ctx *c)
-{
-  if(!c || !c->have_order || !c->pm_rho.p)
-    return NGRAVS_ERR_STATE;
-  (void)hipSetDevice(c->cfg.device);
-  int rc = pm_finish(c);
-  if(rc)
-    return rc;
-  HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-  c->stats.t_pm = ev_ms(c) * 1e-3;
-  return NGRAVS_OK;
 }
 
 // ---- slab-decomposed pmforce_periodic (kernels_pmslab.hip) ------------------------------------------------------------------

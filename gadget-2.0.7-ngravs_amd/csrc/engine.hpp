@@ -16,7 +16,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "../../include/ngravs_hip.h"
+#include "../../include/ngravs_host.h"
 
 #define NG_MAX NGRAVS_MAX_GRAVS
 #define NTAB NGRAVS_NTAB
@@ -123,23 +123,23 @@ struct Tuning
   int tree_levelwise = 0;   // build the tree level by level (the multi-task path) also for single-task trees
 };
 
-// The global top of the tree for multi-task runs (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996,
-// with the reference's adaptive TopNodes replaced by the complete Peano cells of one level): every task knows, for every
-// cell of levels 0..level, the GLOBAL particle count and per-species mass / first moments.  The tree build forces the
-// topology of those levels from the global counts, so that it is the single-task tree's; a level-`level` cell whose
-// particles are not on this task becomes a pseudo node (global monopoles, no children).
-#define TOP_CW(ng) (7 + 4 * (ng))   // doubles per cell: count, particles per type [6], per species m, m x, m y, m z
+// The global top of the tree for multi-task runs (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996):
+// the reference's adaptive TopNodes[] (domain.c:933-1138), the same on every task.  Every task knows, for every top node, the
+// GLOBAL particle count and per-species mass / first moments.  The tree build forces the topology of the top tree from the
+// global counts, so that it is the single-task tree's; a top LEAF whose particles are not on this task becomes a pseudo node
+// (global monopoles, no children).
+#define TOP_CW(ng) (7 + 4 * (ng))   // doubles per node: count (leaf sums: work), particles per type [6], per species m, m x, m y, m z
 struct TopTree
 {
-  int level = 0;                       // 0: off (single task)
-  int tab_level = 0;                   // level the geometry table (cellxyz) was built for
-  std::vector<long long> off;          // off[d] = index of the first cell of level d in the per-level tables
-  DevBuf<int> gcnt;                    // global count per cell
-  DevBuf<int> cellxyz;                 // ix | iy << 10 | iz << 20 of the cell with that Peano prefix
-  DevBuf<double> gsum;                 // TOP_CW doubles per cell
-  DevBuf<unsigned char> partial;       // cell contains particles that are not on this task
-  DevBuf<unsigned long long> reqmask;  // per level-`level` cell: tasks that asked for its particles
-  std::vector<int> h_cellxyz;
+  bool on = false;                     // sums + presence are set: the next tree build forces the global top (ngravs_dd_set_top)
+  ngravs_toptree h = {0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // host copy: child, level, xyz, leaf numbers
+  DevBuf<int> child, leaf;             // per node: first child or -1; leaf number (curve order) or -1
+  DevBuf<int> gcnt;                    // per node: global particle count
+  DevBuf<unsigned char> info;          // per node: bits 0-2 octant in its parent (x << 2 | y << 1 | z), bit 3 PARTIAL
+  DevBuf<double> gsum;                 // per node: TOP_CW doubles
+  DevBuf<int> leaf_owner;              // per leaf
+  DevBuf<unsigned long long> reqmask;  // per leaf: tasks that asked for its particles
+  DevBuf<double> leaf_sums;            // per leaf: TOP_CW doubles of the own particles (+ 1 spare word)
 };
 
 // slab-decomposed particle mesh of the multi-task path (kernels_pmslab.hip)
@@ -165,7 +165,7 @@ struct ngravs_ctx
   Tuning tune;
   PmSlab pms;
   TopTree top;
-  DevBuf<int> n_prefix;       // Peano prefix of a node's cell (top levels of a multi-task tree)
+  DevBuf<int> n_top;          // top-tree node a tree node is (multi-task trees; -1: none)
   ngravs_fatal_fn on_fatal = nullptr;
   hipStream_t stream = nullptr;
   double asmth = 0, rcut = 0;
@@ -190,11 +190,9 @@ struct ngravs_ctx
   DevBuf<unsigned long long> in_key;
   DevBuf<long long> in_id;
   // multi-task decomposition scratch
-  DevBuf<unsigned long long> dd_mask, dd_counts, dd_hist;
-  DevBuf<double> dd_work, dd_cells;
+  DevBuf<unsigned long long> dd_mask, dd_counts;
   int sort_low = 35;   // key bits the two-stage sort leaves to its fix-up (35 -> 28 -> 21 -> 0 = plain sort, as runs of ties get too long)
   long long own_order_nlocal = -1, own_order_len = 0;   // s_idx still is the Peano order of the last local decomposition (of own_order_len rows, own_order_nlocal of them own)
-  DevBuf<int> dd_owner_ph, dd_owner_xyz;
   DevBuf<unsigned char> dd_send, dd_recv;
   // sorted
   DevBuf<double4> s_pm;
@@ -264,16 +262,14 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
                   long long *d_keys);
 int dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3]);
 void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3]);
-int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work);
-int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *owner_xyz, int nranks, int me, double reach,
-            int64_t *counts, void **dev_records, int64_t *nrec);
+int dd_set_toptree(ngravs_ctx *c, int nnode, const int *child);
+int dd_leaf_sums(ngravs_ctx *c, void **dev_sums, int64_t *count);
+int dd_pack(ngravs_ctx *c, int what, const int *leaf_owner, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec);
 int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec);
-int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest);
-int dd_cell_sums(ngravs_ctx *c, int level, double *cells);
+int dd_get_dest(ngravs_ctx *c, const int *leaf_owner, int *dest);
 int dd_target_bounds(ngravs_ctx *c, double out[2]);
-int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records,
-                  int64_t *nrec);
-int dd_set_top(ngravs_ctx *c, int level, const double *gcells, const unsigned char *present);
+int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec);
+int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *present);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
 int dd_fill_ids(ngravs_ctx *c);
 int dd_record_doubles(const ngravs_ctx *c, int what);

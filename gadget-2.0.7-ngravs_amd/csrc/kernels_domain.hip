@@ -300,15 +300,14 @@ int dom_keys_only(ngravs_ctx *c, const double *d_pos, int64_t n, const double co
 //  Multi-task domain decomposition (the role of domain_decompose / domain_exchangeParticles,
 //  domain.c:164-330, 554-760, and of the pseudo-particle export of gravtree.c:112-285).
 //
-//  MI355X design: the global Peano curve is cut at the boundaries of level-`level` Peano cells (cubes of the
-//  domain cube, the analogue of the reference's top-level tree leaves); a task owns a contiguous run of
-//  cells.  Two all-to-all-v exchanges per step, both built here as packed 48-byte records grouped by
-//  destination: (0) migration of particles whose cell changed owner, (1) the *halo*: copies of particles
-//  lying within the short-range cut of a cell owned by another task.  With TreePM the cut is finite
-//  (group_reach * Asmth), so a task that holds its own particles + halo can build a tree over them and
-//  walk its own targets with no further communication -- instead of exporting targets and importing
-//  partial forces (gravtree.c:170-280).  The host drives the collectives (RCCL through torch.distributed
-//  in bench.py, MPI in the reference glue); this file only packs and unpacks.
+//  MI355X design: the global Peano curve is cut at the leaves of an adaptive top tree in key space (the reference's
+//  TopNodes[], domain.c:933-1138); a task owns a contiguous run of leaves.  A particle finds its leaf by walking the top
+//  tree's child table with the digits of its own 63-bit key (a handful of dependent loads from a table that lives in L2).
+//  Two all-to-all-v exchanges per step, both built here as packed records grouped by destination: (0) migration of
+//  particles whose leaf changed owner, (2) import: ALL particles of the leaves another task asked for (its targets may
+//  open them), so that the task can build the tree it needs and walk its own targets with no further communication --
+//  instead of exporting targets and importing partial forces (gravtree.c:170-280).  The host drives the collectives
+//  (host/ngravs_host.c over RCCL / MPI); this file only packs and unpacks.
 // =====================================================================================================
 struct DDRecord
 {
@@ -323,23 +322,27 @@ __global__ void k_dd_iota(long long *p, long long n)
     p[i] = i;
 }
 
-__device__ __forceinline__ void dd_cell(const unsigned short (*step)[8], const double *pos, long long i, double cx, double cy,
-                                        double cz, double fac21, int level, int *ix, int *iy, int *iz, long long *phcell)
+// the top leaf a particle lies in: its key's digits select the child, level by level, until a leaf is reached
+__device__ __forceinline__ int dd_leaf(const unsigned short (*step)[8], const double *pos, long long i, double cx, double cy,
+                                       double cz, double fac21, const int *__restrict__ t_child, const int *__restrict__ t_leaf)
 {
   int x = (int)__dmul_rn(__dsub_rn(pos[3 * i + 0], cx), fac21);
   int y = (int)__dmul_rn(__dsub_rn(pos[3 * i + 1], cy), fac21);
   int z = (int)__dmul_rn(__dsub_rn(pos[3 * i + 2], cz), fac21);
-  long long key = ngravs_ph_key_tab(step, x, y, z, TREE_BITS);
-  *phcell = key >> (3 * (TREE_BITS - level));
-  *ix = x >> (TREE_BITS - level);
-  *iy = y >> (TREE_BITS - level);
-  *iz = z >> (TREE_BITS - level);
+  const unsigned long long key = (unsigned long long)ngravs_ph_key_tab(step, x, y, z, TREE_BITS);
+  int node = 0, c, sh = 3 * (TREE_BITS - 1);
+  while((c = t_child[node]) >= 0 && sh >= 0)
+    {
+      node = c + (int)((key >> sh) & 7ull);
+      sh -= 3;
+    }
+  return t_leaf[node];
 }
 
-// Per-cell sums without one atomic per particle and value: visited in the Peano order of the last local decomposition
+// Per-leaf sums without one atomic per particle and value: visited in the Peano order of the last local decomposition
 // (`order`: rows of the working set then, own rows are the ones below n; any permutation is correct, this one puts the
-// particles of a cell next to each other), a wave whose particles all lie in ONE cell adds up across its lanes and issues one
-// atomic per value.  Waves that straddle cells, and runs without an order, fall back to one atomic per particle.
+// particles of a leaf next to each other), a wave whose particles all lie in ONE leaf adds up across its lanes and issues one
+// atomic per value.  Waves that straddle leaves, and runs without an order, fall back to one atomic per particle.
 // (A third level -- the waves of a 1024-thread block adding up in LDS -- measured slower: 1.88 against 1.55 ms for the stage.)
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
@@ -358,9 +361,13 @@ __device__ __forceinline__ bool dd_row(const unsigned int *__restrict__ order, l
   return j < n;
 }
 
-__global__ void k_dd_hist(const double *__restrict__ pos, const double *__restrict__ cost, long long n,
-                          const unsigned int *__restrict__ order, long long norder, double cx, double cy, double cz, double fac21,
-                          int level, unsigned long long *__restrict__ hist, double *__restrict__ work)
+// per top leaf: [0] work sum(1 + GravCost) (domain_sumCost, domain.c:859-862), [1..6] particles per type, per species mass and
+// first moments (the local part of DomainMoment[], forcetree.c:766-850) -- ONE pass for the count/work histogram of the cut
+// and the moments of the global top
+__global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__restrict__ mass, const int *__restrict__ type,
+                              const double *__restrict__ cost, long long n, const unsigned int *__restrict__ order, long long norder,
+                              double cx, double cy, double cz, double fac21, const int *__restrict__ t_child,
+                              const int *__restrict__ t_leaf, int ng, unsigned t2g_packed, double *__restrict__ sums)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
@@ -371,37 +378,68 @@ __global__ void k_dd_hist(const double *__restrict__ pos, const double *__restri
   const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
   if(vm == 0ull)
     return;
-  int ix, iy, iz;
-  long long cell = -1;
-  double w = 0;
+  int ty = -1, g = -1, leaf = -1;
+  double m = 0, mx = 0, my = 0, mz = 0, w = 0;
   if(valid)
     {
-      dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-      w = 1.0 + cost[i];   // domain.c:859-862: work of a cell = sum of (1 + GravCost)
+      leaf = dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
+      ty = type[i];
+      g = (int)((t2g_packed >> (2 * ty)) & 3u);
+      m = mass[i];
+      mx = m * pos[3 * i + 0];
+      my = m * pos[3 * i + 1];
+      mz = m * pos[3 * i + 2];
+      w = 1.0 + cost[i];
     }
   const int first = __builtin_ctzll(vm);
-  const long long cell0 = __shfl(cell, first);
-  if(__builtin_amdgcn_ballot_w64(valid && cell == cell0) == vm)
+  const int leaf0 = __shfl(leaf, first);
+  if(__builtin_amdgcn_ballot_w64(valid && leaf == leaf0) == vm)
     {
+      double *c = sums + (size_t)leaf0 * TOP_CW(ng);
+      const bool lead = (threadIdx.x & 63) == first;
       const double ws = wave_sum_f64(w);
-      if((threadIdx.x & 63) == first)
+      if(lead)
+        atomicAdd(&c[0], ws);
+      for(int t = 0; t < NGRAVS_NTYPES; t++)
         {
-          atomicAdd(&hist[cell0], (unsigned long long)__popcll(vm));
-          atomicAdd(&work[cell0], ws);
+          const unsigned long long tm = __builtin_amdgcn_ballot_w64(ty == t);
+          if(tm && lead)
+            atomicAdd(&c[1 + t], (double)__popcll(tm));
+        }
+      for(int s = 0; s < ng; s++)
+        {
+          const unsigned long long sm = __builtin_amdgcn_ballot_w64(g == s);
+          if(sm == 0ull)
+            continue;
+          const bool in = g == s;
+          const double a0 = wave_sum_f64(in ? m : 0.0), a1 = wave_sum_f64(in ? mx : 0.0), a2 = wave_sum_f64(in ? my : 0.0),
+                       a3 = wave_sum_f64(in ? mz : 0.0);
+          if(lead)
+            {
+              atomicAdd(&c[7 + 4 * s + 0], a0);
+              atomicAdd(&c[7 + 4 * s + 1], a1);
+              atomicAdd(&c[7 + 4 * s + 2], a2);
+              atomicAdd(&c[7 + 4 * s + 3], a3);
+            }
         }
     }
   else if(valid)
     {
-      atomicAdd(&hist[cell], 1ull);
-      atomicAdd(&work[cell], w);
+      double *c = sums + (size_t)leaf * TOP_CW(ng);
+      atomicAdd(&c[0], w);
+      atomicAdd(&c[1 + ty], 1.0);
+      atomicAdd(&c[7 + 4 * g + 0], m);
+      atomicAdd(&c[7 + 4 * g + 1], mx);
+      atomicAdd(&c[7 + 4 * g + 2], my);
+      atomicAdd(&c[7 + 4 * g + 3], mz);
     }
 }
 
-// which other tasks receive particle i?  what = 0: its new owner (migration); what = 1: every task owning a cell within
-// `reach` of it (halo).  One bit per task (world_size <= 64).
-__global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
-                          double cell_len, int periodic, const int *__restrict__ owner_ph, const int *__restrict__ owner_xyz,
-                          int me, int what, double reach, unsigned long long *__restrict__ mask)
+// which other tasks receive particle i?  One bit per task (world_size <= 64).  leaf_owner: its new owner (migration);
+// reqmask: every task that asked for its leaf (import)
+__global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21,
+                          const int *__restrict__ t_child, const int *__restrict__ t_leaf, const int *__restrict__ leaf_owner,
+                          const unsigned long long *__restrict__ reqmask, int me, unsigned long long *__restrict__ mask, int *__restrict__ dest)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
@@ -410,67 +448,16 @@ __global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  int ix, iy, iz;
-  long long cell;
-  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-  unsigned long long m = 0;
-  if(what == 0)
+  const int leaf = dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
+  if(dest)
+    dest[i] = leaf_owner[leaf];
+  else if(leaf_owner)
     {
-      int o = owner_ph[cell];
-      if(o != me)
-        m = 1ull << o;
+      const int o = leaf_owner[leaf];
+      mask[i] = o != me ? 1ull << o : 0ull;
     }
   else
-    {
-      const int nc = 1 << level;
-      // offsets of the particle inside its cell
-      const double lx = pos[3 * i + 0] - (cx + ix * cell_len), ly = pos[3 * i + 1] - (cy + iy * cell_len),
-                   lz = pos[3 * i + 2] - (cz + iz * cell_len);
-      const double r2 = reach * reach;
-      for(int dx = -1; dx <= 1; dx++)
-        for(int dy = -1; dy <= 1; dy++)
-          for(int dz = -1; dz <= 1; dz++)
-            {
-              if(!dx && !dy && !dz)
-                continue;
-              int jx = ix + dx, jy = iy + dy, jz = iz + dz;
-              if(periodic)
-                {
-                  // the domain cube is 1.001 x the box: the outermost cell layers wrap onto each other; treat the
-                  // curve's cube as periodic -- conservative (a few extra halo particles at the seam)
-                  jx = (jx + nc) % nc;
-                  jy = (jy + nc) % nc;
-                  jz = (jz + nc) % nc;
-                }
-              else if(jx < 0 || jy < 0 || jz < 0 || jx >= nc || jy >= nc || jz >= nc)
-                continue;
-              int o = owner_xyz[(jx * nc + jy) * nc + jz];
-              if(o == me || o < 0)
-                continue;
-              double ax = dx < 0 ? lx : (dx > 0 ? cell_len - lx : 0.0);
-              double ay = dy < 0 ? ly : (dy > 0 ? cell_len - ly : 0.0);
-              double az = dz < 0 ? lz : (dz > 0 ? cell_len - lz : 0.0);
-              if(ax * ax + ay * ay + az * az < r2)
-                m |= 1ull << o;
-            }
-    }
-  mask[i] = m;
-}
-
-__global__ void k_dd_owner(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
-                           const int *__restrict__ owner_ph, int *__restrict__ dest)
-{
-  __shared__ unsigned short step[48][8];
-  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
-    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
-  __syncthreads();
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  int ix, iy, iz;
-  long long cell;
-  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-  dest[i] = owner_ph[cell];
+    mask[i] = reqmask[leaf] & ~(1ull << me);
 }
 
 // One atomic per wave and destination, not per particle: 8 M particles adding to the same counter serialise in the memory
@@ -738,55 +725,72 @@ void dd_apply_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
   c->dom[7] = 1.0 / len * (double)(((long long)1) << NGRAVS_BITS_PER_DIMENSION);
 }
 
-int dd_histogram(ngravs_ctx *c, int level, int64_t *hist, double *work)
+// The top tree as the host hands it over: child table -> host copy with levels / coordinates / leaf numbers
+// (ngravs_host_toptree_from_children, host/ngravs_host.c) and the two device tables the kernels descend with.  Setting the tree
+// that is already set costs a comparison.
+int dd_set_toptree(ngravs_ctx *c, int nnode, const int *child)
 {
-  const long long ncell = 1ll << (3 * level);
-  DevBuf<unsigned long long> &d = c->dd_hist;   // persistent scratch: no hipMalloc / hipFree per step
-  DevBuf<double> &w = c->dd_work;
-  if(d.ensure(ncell) || w.ensure(ncell))
+  TopTree &t = c->top;
+  if(nnode < 1 || !child)
+    return NGRAVS_ERR_ARG;
+  if(t.h.nnode == nnode && t.h.child && memcmp(t.h.child, child, sizeof(int) * (size_t)nnode) == 0)
+    return NGRAVS_OK;
+  ngravs_toptree fresh;
+  int rc = ngravs_host_toptree_from_children(&fresh, child, nnode);
+  if(rc)
+    {
+      ngravs_report(c, rc, "ngravs_dd_set_toptree: not a tree (child[t] = first of 8 consecutive children, or -1)");
+      return rc;
+    }
+  ngravs_host_toptree_free(&t.h);
+  t.h = fresh;
+  t.on = false;   /* sums and presence of the old tree say nothing about this one */
+  c->have_tree = false;
+  if(t.child.ensure((size_t)nnode) || t.leaf.ensure((size_t)nnode))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(unsigned long long) * ncell, c->stream));
-  HIP_TRY(c, hipMemsetAsync(w.p, 0, sizeof(double) * ncell, c->stream));
-  double fac21;
-  dd_fac(c, &fac21);
-  const long long n = c->n_local;
-  const bool ordered = c->own_order_nlocal == n && c->own_order_len >= n && c->s_idx.p;
-  const long long nthr = ordered ? c->own_order_len : n;
-  if(n > 0)
-    hipLaunchKernelGGL(k_dd_hist, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_cost.p, n,
-                       ordered ? c->s_idx.p : (const unsigned int *)nullptr, nthr, c->dom[0], c->dom[1], c->dom[2], fac21, level, d.p, w.p);
-  HIP_TRY(c, hipMemcpyAsync(hist, d.p, sizeof(unsigned long long) * ncell, hipMemcpyDeviceToHost, c->stream));
-  if(work)
-    HIP_TRY(c, hipMemcpyAsync(work, w.p, sizeof(double) * ncell, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.child.p, t.h.child, sizeof(int) * (size_t)nnode, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.leaf.p, t.h.leaf, sizeof(int) * (size_t)nnode, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NGRAVS_OK;
 }
 
-int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *owner_xyz, int nranks, int me, double reach,
-            int64_t *counts, void **dev_records, int64_t *nrec)
+// per-leaf sums of the own particles on the device (+ one spare word, zero: the host's status slot in the all-reduce)
+int dd_leaf_sums(ngravs_ctx *c, void **dev_sums, int64_t *count)
 {
-  if(nranks > 64 || level < 1 || level > 7)
-    return NGRAVS_ERR_ARG;
-  const long long n = c->n_local, ncell = 1ll << (3 * level);
-  const double cell_len = c->dom[6] / (double)(1 << level);
-  if(what == 1 && !(reach <= cell_len))
-    {
-      ngravs_report(c, NGRAVS_ERR_ARG, "halo: the decomposition cells must be at least as wide as the short-range cut");
-      return NGRAVS_ERR_ARG;
-    }
-  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->dd_owner_ph.ensure(ncell) || c->dd_owner_xyz.ensure(ncell) || c->dd_counts.ensure(3 * 65 + 2))
+  TopTree &t = c->top;
+  if(t.h.nnode < 1)
+    return NGRAVS_ERR_STATE;
+  const int cw = TOP_CW(c->cfg.n_gravs);
+  const long long n = c->n_local, words = (long long)t.h.nleaf * cw + 1;
+  if(t.leaf_sums.ensure((size_t)words))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_ph.p, owner_ph, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_xyz.p, owner_xyz, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
+  HIP_TRY(c, hipMemsetAsync(t.leaf_sums.p, 0, sizeof(double) * words, c->stream));
   double fac21;
   dd_fac(c, &fac21);
+  unsigned t2g_packed = 0;
+  for(int ty = 0; ty < NGRAVS_NTYPES; ty++)
+    t2g_packed |= ((unsigned)(c->cfg.type_to_grav[ty] & 3)) << (2 * ty);
+  const bool ordered = c->own_order_nlocal == n && c->own_order_len >= n && c->s_idx.p;
+  const long long nthr = ordered ? c->own_order_len : n;
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_leafsums, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p,
+                       c->in_cost.p, n, ordered ? c->s_idx.p : (const unsigned int *)nullptr, nthr, c->dom[0], c->dom[1], c->dom[2], fac21,
+                       t.child.p, t.leaf.p, c->cfg.n_gravs, t2g_packed, t.leaf_sums.p);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  *dev_sums = t.leaf_sums.p;
+  *count = words;
+  return NGRAVS_OK;
+}
+
+// records of the own particles grouped by destination; mask[i] = bit per receiving task (set by the caller's kernel)
+static int dd_pack_masked(ngravs_ctx *c, int what, int nranks, int64_t *counts, void **dev_records, int64_t *nrec)
+{
+  const long long n = c->n_local;
   unsigned nb = (unsigned)((n + 255) / 256);
   std::vector<unsigned long long> h(65, 0), offs(65, 0);
   if(n > 0)
     {
-      hipLaunchKernelGGL(k_dd_dest, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
-                         cell_len, c->cfg.periodic, c->dd_owner_ph.p, c->dd_owner_xyz.p, me, what, reach, c->dd_mask.p);
       hipLaunchKernelGGL(k_dd_count, dim3(nb < DD_CNT_BLOCKS ? nb : DD_CNT_BLOCKS), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
       HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -817,106 +821,26 @@ int dd_pack(ngravs_ctx *c, int what, int level, const int *owner_ph, const int *
   return NGRAVS_OK;
 }
 
-// ---- the global top of the tree (multi-task) ---------------------------------------------------------------------------
-// per-cell sums of the own particles: count, particles per type, per species mass and first moments (the local part of
-// DomainMoment[], forcetree.c:766-850, for every Peano cell of `level`)
-__global__ void k_dd_cellsums(const double *__restrict__ pos, const double *__restrict__ mass, const int *__restrict__ type, long long n,
-                              const unsigned int *__restrict__ order, long long norder, double cx, double cy, double cz, double fac21,
-                              int level, int ng, unsigned t2g_packed, double *__restrict__ cells)
+// migration (what = 0): every own particle whose leaf belongs to another task goes there
+int dd_pack(ngravs_ctx *c, int what, const int *leaf_owner, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec)
 {
-  __shared__ unsigned short step[48][8];
-  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
-    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
-  __syncthreads();
-  long long i;
-  const bool valid = dd_row(order, norder, n, blockIdx.x * (long long)blockDim.x + threadIdx.x, &i);
-  const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
-  if(vm == 0ull)
-    return;
-  int ix, iy, iz, ty = -1, g = -1;
-  long long cell = -1;
-  double m = 0, mx = 0, my = 0, mz = 0;
-  if(valid)
-    {
-      dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-      ty = type[i];
-      g = (int)((t2g_packed >> (2 * ty)) & 3u);
-      m = mass[i];
-      mx = m * pos[3 * i + 0];
-      my = m * pos[3 * i + 1];
-      mz = m * pos[3 * i + 2];
-    }
-  // (c[0], the particle count, is the sum of the per-type counts: added on the host -- one atomic less per particle)
-  const int first = __builtin_ctzll(vm);
-  const long long cell0 = __shfl(cell, first);
-  if(__builtin_amdgcn_ballot_w64(valid && cell == cell0) == vm)
-    {
-      double *c = cells + (size_t)cell0 * TOP_CW(ng);
-      const bool lead = (threadIdx.x & 63) == first;
-      for(int t = 0; t < NGRAVS_NTYPES; t++)
-        {
-          const unsigned long long tm = __builtin_amdgcn_ballot_w64(ty == t);
-          if(tm && lead)
-            atomicAdd(&c[1 + t], (double)__popcll(tm));
-        }
-      for(int s = 0; s < ng; s++)
-        {
-          const unsigned long long sm = __builtin_amdgcn_ballot_w64(g == s);
-          if(sm == 0ull)
-            continue;
-          const bool in = g == s;
-          const double a0 = wave_sum_f64(in ? m : 0.0), a1 = wave_sum_f64(in ? mx : 0.0), a2 = wave_sum_f64(in ? my : 0.0),
-                       a3 = wave_sum_f64(in ? mz : 0.0);
-          if(lead)
-            {
-              atomicAdd(&c[7 + 4 * s + 0], a0);
-              atomicAdd(&c[7 + 4 * s + 1], a1);
-              atomicAdd(&c[7 + 4 * s + 2], a2);
-              atomicAdd(&c[7 + 4 * s + 3], a3);
-            }
-        }
-    }
-  else if(valid)
-    {
-      double *c = cells + (size_t)cell * TOP_CW(ng);
-      atomicAdd(&c[1 + ty], 1.0);
-      atomicAdd(&c[7 + 4 * g + 0], m);
-      atomicAdd(&c[7 + 4 * g + 1], mx);
-      atomicAdd(&c[7 + 4 * g + 2], my);
-      atomicAdd(&c[7 + 4 * g + 3], mz);
-    }
-}
-
-int dd_cell_sums(ngravs_ctx *c, int level, double *cells)
-{
-  const long long ncell = 1ll << (3 * level), n = c->n_local;
-  const int cw = TOP_CW(c->cfg.n_gravs);
-  DevBuf<double> &d = c->dd_cells;
-  if(d.ensure((size_t)ncell * cw))
+  TopTree &t = c->top;
+  if(nranks > 64 || what != 0 || t.h.nnode < 1)
+    return NGRAVS_ERR_ARG;
+  const long long n = c->n_local;
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || t.leaf_owner.ensure((size_t)t.h.nleaf) || c->dd_counts.ensure(3 * 65 + 2))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(d.p, 0, sizeof(double) * ncell * cw, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.leaf_owner.p, leaf_owner, sizeof(int) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
   double fac21;
   dd_fac(c, &fac21);
-  unsigned t2g_packed = 0;
-  for(int t = 0; t < NGRAVS_NTYPES; t++)
-    t2g_packed |= ((unsigned)(c->cfg.type_to_grav[t] & 3)) << (2 * t);
-  const bool ordered = c->own_order_nlocal == n && c->own_order_len >= n && c->s_idx.p;
-  const long long nthr = ordered ? c->own_order_len : n;
   if(n > 0)
-    hipLaunchKernelGGL(k_dd_cellsums, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p, n,
-                       ordered ? c->s_idx.p : (const unsigned int *)nullptr, nthr, c->dom[0], c->dom[1], c->dom[2], fac21, level,
-                       c->cfg.n_gravs, t2g_packed, d.p);
-  HIP_TRY(c, hipMemcpyAsync(cells, d.p, sizeof(double) * ncell * cw, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipGetLastError());
-  for(long long i = 0; i < ncell; i++)
-    {
-      double *q = cells + (size_t)i * cw;
-      q[0] = q[1] + q[2] + q[3] + q[4] + q[5] + q[6];
-    }
-  return NGRAVS_OK;
+    hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21,
+                       t.child.p, t.leaf.p, t.leaf_owner.p, (const unsigned long long *)nullptr, me, c->dd_mask.p, (int *)nullptr);
+  return dd_pack_masked(c, 0, nranks, counts, dev_records, nrec);
 }
 
+// ---- the global top of the tree (multi-task) ---------------------------------------------------------------------------
 // smallest ErrTolForceAcc * OldAcc and smallest softening length over the own ACTIVE particles: what the conservative
 // opening tests of a whole domain need (the group walk uses the same two minima per group)
 __global__ void k_dd_bounds(const double *__restrict__ oldacc, const int *__restrict__ type, const unsigned char *__restrict__ active,
@@ -958,159 +882,83 @@ int dd_target_bounds(ngravs_ctx *c, double out[2])
   return NGRAVS_OK;
 }
 
-// every own particle goes to the tasks that asked for its cell
-__global__ void k_dd_dest_cells(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21, int level,
-                                const unsigned long long *__restrict__ reqmask, int me, unsigned long long *__restrict__ mask)
-{
-  __shared__ unsigned short step[48][8];
-  for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
-    step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
-  __syncthreads();
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if(i >= n)
-    return;
-  int ix, iy, iz;
-  long long cell;
-  dd_cell(step, pos, i, cx, cy, cz, fac21, level, &ix, &iy, &iz, &cell);
-  mask[i] = reqmask[cell] & ~(1ull << me);
-}
-
 // destination task of every local particle (host array): what the migration pack would do, without packing
-int dd_get_dest(ngravs_ctx *c, int level, const int *owner_ph, int *dest)
+int dd_get_dest(ngravs_ctx *c, const int *leaf_owner, int *dest)
 {
-  const long long n = c->n_local, ncell = 1ll << (3 * level);
+  TopTree &t = c->top;
+  const long long n = c->n_local;
+  if(t.h.nnode < 1)
+    return NGRAVS_ERR_STATE;
   if(n <= 0)
     return NGRAVS_OK;
   DevBuf<int> d;
-  if(c->dd_owner_ph.ensure(ncell) || d.ensure(n))
+  if(t.leaf_owner.ensure((size_t)t.h.nleaf) || d.ensure(n))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemcpyAsync(c->dd_owner_ph.p, owner_ph, sizeof(int) * ncell, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.leaf_owner.p, leaf_owner, sizeof(int) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
   double fac21;
   dd_fac(c, &fac21);
-  hipLaunchKernelGGL(k_dd_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2],
-                     fac21, level, c->dd_owner_ph.p, d.p);
+  hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2],
+                     fac21, t.child.p, t.leaf.p, t.leaf_owner.p, (const unsigned long long *)nullptr, 0, (unsigned long long *)nullptr, d.p);
   HIP_TRY(c, hipMemcpyAsync(dest, d.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   d.release();
   return NGRAVS_OK;
 }
 
-// cell import: the records of the own particles of every cell another task asked for (what = 2 of the pack family)
-int dd_pack_cells(ngravs_ctx *c, int level, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records,
-                  int64_t *nrec)
+// leaf import: the records of the own particles of every leaf another task asked for (what = 2 of the pack family)
+int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec)
 {
-  if(nranks > 64 || level < 1 || level > 7)
+  TopTree &t = c->top;
+  if(nranks > 64 || t.h.nnode < 1)
     return NGRAVS_ERR_ARG;
-  const long long n = c->n_local, ncell = 1ll << (3 * level);
-  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->top.reqmask.ensure(ncell) || c->dd_counts.ensure(3 * 65 + 2))
+  const long long n = c->n_local;
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || t.reqmask.ensure((size_t)t.h.nleaf) || c->dd_counts.ensure(3 * 65 + 2))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemcpyAsync(c->top.reqmask.p, reqmask, sizeof(unsigned long long) * ncell, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.reqmask.p, reqmask, sizeof(unsigned long long) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
   double fac21;
   dd_fac(c, &fac21);
-  unsigned nb = (unsigned)((n + 255) / 256);
-  std::vector<unsigned long long> h(65, 0), offs(65, 0);
   if(n > 0)
-    {
-      hipLaunchKernelGGL(k_dd_dest_cells, dim3(nb), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21, level,
-                         c->top.reqmask.p, me, c->dd_mask.p);
-      hipLaunchKernelGGL(k_dd_count, dim3(nb < DD_CNT_BLOCKS ? nb : DD_CNT_BLOCKS), dim3(256), 0, c->stream, c->dd_mask.p, n, nranks, c->dd_counts.p);
-      HIP_TRY(c, hipMemcpyAsync(h.data(), c->dd_counts.p, sizeof(unsigned long long) * 65, hipMemcpyDeviceToHost, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-  long long tot = 0;
-  for(int r = 0; r < nranks; r++)
-    {
-      offs[r] = tot;
-      counts[r] = (int64_t)h[r];
-      tot += h[r];
-    }
-  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(DDRecord)))
-    return NGRAVS_ERR_NOMEM;
-  if(tot > 0)
-    {
-      HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
-      hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
-                         c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
-                         (double *)c->dd_send.p, (const double *)nullptr, 7);
-    }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipGetLastError());
-  *dev_records = c->dd_send.p;
-  *nrec = tot;
-  c->dd_last_what = 2;
-  return NGRAVS_OK;
+    hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21,
+                       t.child.p, t.leaf.p, (const int *)nullptr, t.reqmask.p, me, c->dd_mask.p, (int *)nullptr);
+  return dd_pack_masked(c, 2, nranks, counts, dev_records, nrec);
 }
 
-// The global cell table of level `level` (all-reduced dd_cell_sums) and which of those cells are present on this task
-// (own or imported): the tables of all coarser levels are aggregated here and uploaded for the tree build.
-int dd_set_top(ngravs_ctx *c, int level, const double *gcells, const unsigned char *present)
+// The global sums of every top node (all-reduced leaf sums, added up the tree by the host) and which leaves are present on
+// this task (own or imported): uploaded for the tree build.  A node is PARTIAL if a leaf below it holds particles that are
+// not here.
+int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *present)
 {
   TopTree &t = c->top;
-  if(level <= 0)
+  if(!node_sums || !present)
     {
-      t.level = 0;
+      t.on = false;
       return NGRAVS_OK;
     }
-  if(level > 7 || !gcells || !present)
-    return NGRAVS_ERR_ARG;
-  const int cw = TOP_CW(c->cfg.n_gravs);
-  t.off.assign(level + 2, 0);
-  for(int d = 0; d <= level; d++)
-    t.off[d + 1] = t.off[d] + (1ll << (3 * d));
-  const long long tot = t.off[level + 1];
-  // geometry: the cell (ix, iy, iz) behind every Peano prefix of every level (depends on the level only)
-  if(t.tab_level != level)
+  if(t.h.nnode < 1)
+    return NGRAVS_ERR_STATE;
+  const int cw = TOP_CW(c->cfg.n_gravs), nn = t.h.nnode;
+  std::vector<int> cnt((size_t)nn);
+  std::vector<unsigned char> info((size_t)nn);
+  for(int i = nn - 1; i >= 0; i--)   // children have larger indices than their parent
     {
-      t.h_cellxyz.assign((size_t)tot, 0);
-      for(int d = 0; d <= level; d++)
-        {
-          const int nc = 1 << d;
-          for(int x = 0; x < nc; x++)
-            for(int y = 0; y < nc; y++)
-              for(int z = 0; z < nc; z++)
-                t.h_cellxyz[(size_t)(t.off[d] + ngravs_ph_key(x, y, z, d))] = x | (y << 10) | (z << 20);
-        }
-      if(t.cellxyz.ensure((size_t)tot))
-        return NGRAVS_ERR_NOMEM;
-      HIP_TRY(c, hipMemcpyAsync(t.cellxyz.p, t.h_cellxyz.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      t.tab_level = level;
+      cnt[i] = (int)(node_sums[(size_t)i * cw] + 0.5);
+      unsigned char part = 0;
+      if(t.h.child[i] < 0)
+        part = (cnt[i] > 0 && !present[t.h.leaf[i]]) ? 1 : 0;
+      else
+        for(int k = 0; k < 8; k++)
+          part |= (info[t.h.child[i] + k] >> 3) & 1;
+      const int *xyz = t.h.xyz + 3 * (size_t)i;
+      info[i] = (unsigned char)(((xyz[0] & 1) << 2) | ((xyz[1] & 1) << 1) | (xyz[2] & 1) | (part << 3));
     }
-  std::vector<double> sum((size_t)tot * cw, 0.0);
-  std::vector<int> cnt((size_t)tot, 0);
-  std::vector<unsigned char> part((size_t)tot, 0);
-  const long long ncell = 1ll << (3 * level);
-  memcpy(&sum[(size_t)t.off[level] * cw], gcells, sizeof(double) * ncell * cw);
-  for(long long i = 0; i < ncell; i++)
-    {
-      cnt[(size_t)(t.off[level] + i)] = (int)(gcells[(size_t)i * cw] + 0.5);
-      part[(size_t)(t.off[level] + i)] = (cnt[(size_t)(t.off[level] + i)] > 0 && !present[i]) ? 1 : 0;
-    }
-  for(int d = level - 1; d >= 0; d--)
-    for(long long p = 0; p < (1ll << (3 * d)); p++)
-      {
-        double *dst = &sum[(size_t)(t.off[d] + p) * cw];
-        int cc = 0;
-        unsigned char pp = 0;
-        for(int k = 0; k < 8; k++)      // fixed order: the same sums on every task
-          {
-            const size_t ch = (size_t)(t.off[d + 1] + p * 8 + k);
-            for(int q = 0; q < cw; q++)
-              dst[q] += sum[ch * cw + q];
-            cc += cnt[ch];
-            pp |= part[ch];
-          }
-        cnt[(size_t)(t.off[d] + p)] = cc;
-        part[(size_t)(t.off[d] + p)] = pp;
-      }
-  if(t.gcnt.ensure((size_t)tot) || t.gsum.ensure((size_t)tot * cw) || t.partial.ensure((size_t)tot))
+  if(t.gcnt.ensure((size_t)nn) || t.gsum.ensure((size_t)nn * cw) || t.info.ensure((size_t)nn))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemcpyAsync(t.gcnt.p, cnt.data(), sizeof(int) * tot, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(t.gsum.p, sum.data(), sizeof(double) * tot * cw, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(t.partial.p, part.data(), (size_t)tot, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.gcnt.p, cnt.data(), sizeof(int) * (size_t)nn, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.gsum.p, node_sums, sizeof(double) * (size_t)nn * cw, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.info.p, info.data(), (size_t)nn, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  t.level = level;
+  t.on = true;
   c->have_tree = false;
   return NGRAVS_OK;
 }

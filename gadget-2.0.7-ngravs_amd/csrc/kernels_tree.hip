@@ -26,10 +26,10 @@ __device__ __forceinline__ int key_digit(unsigned long long k, int level)   // d
 }
 
 // child[] encoding after this kernel: -1 empty, -2-p particle p, >=0 : start particle of a sub-range (fixed up in k_link)
-// Multi-task trees: for a node of the global top (level < top level) the KIND of every child follows from the GLOBAL particle
-// count of the child cell (gcnt_next[prefix * 8 + k]) -- 0: empty, 1: particle leaf, >= 2: node -- whatever part of it is
-// present on this task; so the topology of the top levels is the single-task tree's (forcetree.c:292-431 builds the same
-// top-level nodes from the global TopNodes on every task).
+// Multi-task trees: for a node that is a SPLIT node of the global top tree (n_top[node] = t, t_child[t] >= 0) the KIND of every
+// child follows from the GLOBAL particle count of the child's top node (t_gcnt[t_child[t] + k]) -- 0: empty, 1: particle leaf,
+// >= 2: node -- whatever part of it is present on this task; so the topology of the top is the single-task tree's
+// (forcetree.c:292-431 builds the same top-level nodes from the global TopNodes on every task).
 #define TB 128   // nodes per (virtual) block of the build kernels
 
 // The build never returns to the host between levels: lv[2 l], lv[2 l + 1] = first node and node count of level l live on the
@@ -39,7 +39,8 @@ __device__ __forceinline__ int key_digit(unsigned long long k, int level)   // d
 __global__ __launch_bounds__(TB) void k_split(const unsigned long long *__restrict__ key, const int *__restrict__ n_first,
                                               const int *__restrict__ n_count, const int *__restrict__ lv, int level,
                                               int *__restrict__ n_child, int *__restrict__ n_nchild, int *__restrict__ blocksum,
-                                              const int *__restrict__ gcnt_next = nullptr, const int *__restrict__ n_prefix = nullptr)
+                                              const int *__restrict__ n_top = nullptr, const int *__restrict__ t_child = nullptr,
+                                              const int *__restrict__ t_gcnt = nullptr)
 {
   __shared__ int wsum[TB / 64];
   const int node0 = lv[2 * level], nnodes_level = lv[2 * level + 1];
@@ -83,13 +84,20 @@ __global__ __launch_bounds__(TB) void k_split(const unsigned long long *__restri
                   b[k] = lo;
                 }
             }
+          int tc = -1;                                               // first child top node if this node is a split node of the top tree
+          if(n_top)
+            {
+              const int t = n_top[node];
+              if(t >= 0)
+                tc = t_child[t];
+            }
           for(int k = 0; k < 8; k++)
             {
               int c = b[k + 1] - b[k], v;
               int kind = c;                                          // 0 empty, 1 particle, >= 2 node
-              if(gcnt_next)
+              if(tc >= 0)
                 {
-                  kind = gcnt_next[(long long)n_prefix[node] * 8 + k];
+                  kind = t_gcnt[tc + k];
                   if(kind == 1 && c != 1)
                     kind = 0;                                        // a single particle that lives elsewhere: its parent is never opened here
                 }
@@ -169,9 +177,8 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(int *__restrict__ blocksum
 __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, int *__restrict__ n_first, int *__restrict__ n_count,
                                              int *__restrict__ n_child, double4 *__restrict__ n_geo, int *__restrict__ n_flags,
                                              const int *__restrict__ n_nchild, const int *__restrict__ blocksum, const int *__restrict__ lv,
-                                             int level, double cx, double cy, double cz, double fac21, int *__restrict__ n_prefix = nullptr,
-                                             const int *__restrict__ xyz_next = nullptr,
-                                             const unsigned char *__restrict__ partial_next = nullptr, int top_level = 0)
+                                             int level, double cx, double cy, double cz, double fac21, int *__restrict__ n_top = nullptr,
+                                             const int *__restrict__ t_child = nullptr, const unsigned char *__restrict__ t_info = nullptr)
 {
   typedef hipcub::BlockScan<int, TB> BlockScan;
   __shared__ typename BlockScan::TempStorage tmp;
@@ -190,6 +197,13 @@ __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, i
       int end = n_first[node] + n_count[node];
       double4 g = n_geo[node];
       int nxt = next0 + blocksum[vb] + excl;
+      int tc = -1;   // first child top node if this node is a split node of the global top tree
+      if(n_top)
+        {
+          const int t = n_top[node];
+          if(t >= 0)
+            tc = t_child[t];
+        }
       int starts[8], vals[8];
       for(int k = 0; k < 8; k++)
         {
@@ -216,17 +230,18 @@ __global__ __launch_bounds__(TB) void k_link(const double4 *__restrict__ s_pm, i
           // tree, where a cell may hold no local particle, from the cell table); centre recurrence of forcetree.c:190-206
           // (centre +- 0.25*len of the parent)
           int ox, oy, oz, fl = (level + 1 >= TREE_BITS) ? FLAG_BUCKET : 0;
-          if(xyz_next)
+          if(n_top)
+            n_top[cn] = tc >= 0 ? tc + k : -1;
+          if(tc >= 0)
             {
-              const int pc = n_prefix[node] * 8 + k, xyz = xyz_next[pc];
-              ox = xyz & 1;
-              oy = (xyz >> 10) & 1;
-              oz = (xyz >> 20) & 1;
-              n_prefix[cn] = pc;
-              if(partial_next[pc])
+              const int ct = tc + k, inf = t_info[ct];
+              ox = (inf >> 2) & 1;
+              oy = (inf >> 1) & 1;
+              oz = inf & 1;
+              if(inf & 8)
                 fl |= FLAG_PARTIAL;
-              if(level + 1 == top_level && e - starts[k] == 0)
-                fl |= FLAG_PSEUDO;          // all of its particles live on other tasks (forcetree.c:345-431 pseudo particle)
+              if(t_child[ct] < 0 && e - starts[k] == 0)
+                fl |= FLAG_PSEUDO;          // a top leaf all of whose particles live on other tasks (forcetree.c:345-431 pseudo particle)
             }
           else
             {
@@ -698,22 +713,22 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
     n_count_rw[node] = cnt_acc;
 }
 
-// Global top of a multi-task tree: monopoles and softening flags of the nodes of one top level from the all-reduced cell sums
-// (force_treeupdate_pseudos, forcetree.c:851-947, adds the remote top-leaf moments up the ancestor chain; here every top node
-// takes the sum over ALL tasks directly).  Level `top_level` itself: only the pseudo nodes (the cells present here keep the
-// bottom-up moments of their own subtree).
+// Global top of a multi-task tree: monopoles and softening flags of the tree nodes that are top-tree nodes, from the all-reduced
+// sums (force_treeupdate_pseudos, forcetree.c:851-947, adds the remote top-leaf moments up the ancestor chain; here every top
+// node takes the sum over ALL tasks directly).  Top LEAVES: only the pseudo nodes (the leaves present here keep the bottom-up
+// moments of their own subtree).
 template <int NG>
-__global__ void k_top_moments(const int *__restrict__ n_prefix, const double *__restrict__ gsum_level, const double4 *__restrict__ n_geo,
-                              double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level, int pseudo_only,
-                              WalkParams wp)
+__global__ void k_top_moments(const int *__restrict__ n_top, const int *__restrict__ t_child, const double *__restrict__ gsum,
+                              const double4 *__restrict__ n_geo, double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0,
+                              int nnodes_level, WalkParams wp)
 {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if(t >= nnodes_level)
     return;
-  const int node = node0 + t, fl = n_flags[node];
-  if(pseudo_only && !(fl & FLAG_PSEUDO))
+  const int node = node0 + t, fl = n_flags[node], tn = n_top[node];
+  if(tn < 0 || (t_child[tn] < 0 && !(fl & FLAG_PSEUDO)))
     return;
-  const double *s = gsum_level + (size_t)n_prefix[node] * TOP_CW(NG);
+  const double *s = gsum + (size_t)tn * TOP_CW(NG);
   const double4 geo = n_geo[node];
 #pragma unroll
   for(int g = 0; g < NG; g++)
@@ -749,28 +764,25 @@ static int tree_top_moments(ngravs_ctx *c)
   const TopTree &t = c->top;
   WalkParams wp;
   make_walk_params(c, &wp);
-  const int cw = TOP_CW(c->cfg.n_gravs);
-  for(int l = (t.level < c->nlevels - 1 ? t.level : c->nlevels - 1); l >= 0; l--)
+  for(int l = (t.h.depth < c->nlevels - 1 ? t.h.depth : c->nlevels - 1); l >= 0; l--)
     {
       const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
       if(lc <= 0)
         continue;
       const unsigned nb = (unsigned)((lc + 127) / 128);
-      const double *gs = t.gsum.p + (size_t)t.off[l] * cw;
-      const int pseudo_only = l == t.level ? 1 : 0;
       switch(c->cfg.n_gravs)
         {
         case 1:
-          hipLaunchKernelGGL(k_top_moments<1>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
-                             (int)lc, pseudo_only, wp);
+          hipLaunchKernelGGL(k_top_moments<1>, dim3(nb), dim3(128), 0, c->stream, c->n_top.p, t.child.p, t.gsum.p, c->n_geo.p, c->n_mom.p,
+                             c->n_flags.p, (int)l0, (int)lc, wp);
           break;
         case 2:
-          hipLaunchKernelGGL(k_top_moments<2>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
-                             (int)lc, pseudo_only, wp);
+          hipLaunchKernelGGL(k_top_moments<2>, dim3(nb), dim3(128), 0, c->stream, c->n_top.p, t.child.p, t.gsum.p, c->n_geo.p, c->n_mom.p,
+                             c->n_flags.p, (int)l0, (int)lc, wp);
           break;
         default:
-          hipLaunchKernelGGL(k_top_moments<3>, dim3(nb), dim3(128), 0, c->stream, c->n_prefix.p, gs, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0,
-                             (int)lc, pseudo_only, wp);
+          hipLaunchKernelGGL(k_top_moments<3>, dim3(nb), dim3(128), 0, c->stream, c->n_top.p, t.child.p, t.gsum.p, c->n_geo.p, c->n_mom.p,
+                             c->n_flags.p, (int)l0, (int)lc, wp);
           break;
         }
     }
@@ -817,7 +829,7 @@ int tree_moments(ngravs_ctx *c, bool refit, bool counts)
         }
     }
   HIP_TRY(c, hipGetLastError());
-  if(c->top.level > 0)
+  if(c->top.on)
     return tree_top_moments(c);
   return NGRAVS_OK;
 }
@@ -828,13 +840,13 @@ int tree_build(ngravs_ctx *c)
   double taf = c->cfg.tree_alloc_factor > 0 ? c->cfg.tree_alloc_factor : 0.8;
   long long maxn = (long long)(taf * (double)n) + 1024;
   const TopTree &top = c->top;
-  if(top.level > 0)
-    maxn += top.off[top.level + 1];   // the global top: every cell of its levels may be a node
+  if(top.on)
+    maxn += top.h.nnode;   // the global top: every top node may be a tree node
   c->max_nodes = maxn;
   const int ng = c->cfg.n_gravs;
   if(c->n_first.ensure(maxn) || c->n_count.ensure(maxn) || c->n_child.ensure(8 * maxn) || c->n_flags.ensure(maxn) ||
      c->n_geo.ensure(maxn) || c->n_mom.ensure(maxn * ng) || c->n_nchild.ensure(maxn) || c->scan_out.ensure(maxn) ||
-     c->d_counters.ensure(16) || (c->top.level > 0 && c->n_prefix.ensure(maxn)))
+     c->d_counters.ensure(16) || (c->top.on && c->n_top.ensure(maxn)))
     return NGRAVS_ERR_NOMEM;
   // root = the domain cube (forcetree.c:103-110)
   int h_first = 0, h_count = (int)n, h_flags = 0;
@@ -847,13 +859,13 @@ int tree_build(ngravs_ctx *c)
   HIP_TRY(c, hipMemcpyAsync(c->n_count.p, &h_count, sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->n_geo.p, &h_geo, sizeof(double4), hipMemcpyHostToDevice, c->stream));
-  if(top.level > 0)
+  if(top.on)
     {
       unsigned char part0 = 0;
-      HIP_TRY(c, hipMemsetAsync(c->n_prefix.p, 0, sizeof(int), c->stream));
-      HIP_TRY(c, hipMemcpyAsync(&part0, top.partial.p, 1, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->n_top.p, 0, sizeof(int), c->stream));   // the root is top node 0
+      HIP_TRY(c, hipMemcpyAsync(&part0, top.info.p, 1, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      h_flags = part0 ? FLAG_PARTIAL : 0;
+      h_flags = (part0 & 8) ? FLAG_PARTIAL : 0;
       HIP_TRY(c, hipMemcpyAsync(c->n_flags.p, &h_flags, sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
   double fac21 = c->dom[7] * (double)(1 << (TREE_BITS - NGRAVS_BITS_PER_DIMENSION));
@@ -864,7 +876,7 @@ int tree_build(ngravs_ctx *c)
   int h_lv[2 * (MAX_LEVELS + 2) + 2];
   memset(h_lv, 0, sizeof(h_lv));
   h_lv[1] = 1;   // the root
-  const bool onepass = top.level == 0 && n >= 2 && !c->tune.tree_levelwise;
+  const bool onepass = !top.on && n >= 2 && !c->tune.tree_levelwise;
   if(onepass)
     {
       // the whole topology from one pass over the sorted keys (see k_tb_nodes)
@@ -894,19 +906,17 @@ int tree_build(ngravs_ctx *c)
   for(int level = 0; level < TREE_BITS && !onepass; level++)
     {
       long long guess = c->level_hint[level] > 0 ? c->level_hint[level] + c->level_hint[level] / 8 : ((level < 8) ? (1ll << (3 * level)) : (n + 1) / 2);
-      if(guess > (n + 1) / 2 + 1 && level > 0 && top.level == 0)
+      if(guess > (n + 1) / 2 + 1 && level > 0 && !top.on)
         guess = (n + 1) / 2 + 1;
       unsigned nb = (unsigned)((guess + TB - 1) / TB);
       nb = nb < 1 ? 1 : (nb > 262144u ? 262144u : nb);
-      const bool in_top = top.level > 0 && level < top.level;   // children of this level are cells of the global top
+      const bool in_top = top.on && level < top.h.depth;   // nodes of this level may be split nodes of the global top tree
       hipLaunchKernelGGL(k_split, dim3(nb), dim3(TB), 0, c->stream, c->s_key.p, c->n_first.p, c->n_count.p, c->d_levels.p, level, c->n_child.p,
-                         c->n_nchild.p, c->scan_out.p, in_top ? top.gcnt.p + top.off[level + 1] : (const int *)nullptr,
-                         in_top ? c->n_prefix.p : (const int *)nullptr);
+                         c->n_nchild.p, c->scan_out.p, in_top ? c->n_top.p : (const int *)nullptr, top.child.p, top.gcnt.p);
       hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, c->stream, c->scan_out.p, c->d_levels.p, level, (int)maxn);
       hipLaunchKernelGGL(k_link, dim3(nb), dim3(TB), 0, c->stream, c->s_pm.p, c->n_first.p, c->n_count.p, c->n_child.p, c->n_geo.p,
                          c->n_flags.p, c->n_nchild.p, c->scan_out.p, c->d_levels.p, level, c->dom[0], c->dom[1], c->dom[2], fac21,
-                         in_top ? c->n_prefix.p : (int *)nullptr, in_top ? top.cellxyz.p + top.off[level + 1] : (const int *)nullptr,
-                         in_top ? top.partial.p + top.off[level + 1] : (const unsigned char *)nullptr, top.level);
+                         in_top ? c->n_top.p : (int *)nullptr, top.child.p, top.info.p);
     }
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(h_lv, c->d_levels.p, sizeof(int) * LVN, hipMemcpyDeviceToHost, c->stream));

@@ -1,16 +1,21 @@
-"""Multi-task (one process per GPU) host layer over torch.distributed.
+"""Multi-task (one process per GPU) host layer.
 
-The choreography itself -- domain_Decomposition() with work-weighted cuts, particle migration and the short-range halo
-(reference domain.c:62-330, 347-544, 695-795; gravtree.c:112-285) and pmforce_periodic() on the x-slab decomposed mesh
-(pm_periodic.c:204-790) -- is plain C inside libngravs_hip.so (host/ngravs_host.c, include/ngravs_host.h), written over a
-three-function communicator vtable.  This module only fills that vtable with torch.distributed collectives: backend
-"nccl" (= RCCL over xGMI) on the library's device buffers in production, "gloo" through host copies for the CPU-side
-rehearsal.  The reference glue fills the same vtable with MPI (host/gadget_glue.c).
+The choreography itself -- domain_Decomposition() with the adaptive top tree, work-weighted cuts, particle migration and the
+import of the top leaves a task may open (reference domain.c:62-330, 347-544, 695-795, 933-1138; forcetree.c:766-996;
+gravtree.c:112-285) and pmforce_periodic() on the x-slab decomposed mesh (pm_periodic.c:204-790) -- is plain C inside
+libngravs_hip.so (host/ngravs_host.c, include/ngravs_host.h), written over a communicator vtable.  This module only provides
+that vtable:
 
-Collectives per step (payload per task in DistributedEngine.info / .pm_bytes):
-  all-reduce  extent (2 x 3 f64), per-cell count + work histograms (8^level i64 + f64)
-  all-gather  send-count vectors, PM bricks' bounding boxes (6 i32)
-  all-to-all-v  migrating particles, halo particles (56-byte records), and the four mesh exchanges of the slab PM
+  RcclComm   production: libngravs_rccl.so (host/ngravs_comm_rccl.c, include/ngravs_comm_rccl.h) -- ncclAllReduce /
+             ncclAllGather / grouped ncclSend+ncclRecv straight on the library's device buffers, in C.  No Python runs inside a
+             step.  torch.distributed is used ONCE, to broadcast the 128-byte ncclUniqueId (the reference glue does that with
+             MPI_Bcast), so a Python host and a C host share one RCCL path.
+  TorchComm  rehearsal: torch.distributed "gloo" through host copies (several tasks on one GPU, or no RCCL).
+
+Collectives per step in the steady state (DistributedEngine.info.collectives, .pm_bytes):
+  all-reduce   MIN of extent + target bounds (9 f64); SUM of the per-leaf sums (NGRAVS_TOP_CW doubles per top leaf)
+  all-gather   migration counts + import requests (one call); PM bricks' bounding boxes (7 i32)
+  all-to-all-v imported leaves (56-byte records), the four mesh exchanges of the slab PM; migrating particles only when any move
 """
 import ctypes as C
 
@@ -28,14 +33,70 @@ _ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, _I64P, _I64P, C.c_void
 class Comm(C.Structure):
     """struct ngravs_comm (include/ngravs_host.h)"""
     _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("device_buffers", C.c_int32), ("reserved", C.c_int32),
-                ("user", C.c_void_p), ("allreduce", _ALLREDUCE), ("allgather", _ALLGATHER), ("alltoallv", _ALLTOALLV)]
+                ("user", C.c_void_p), ("allreduce", _ALLREDUCE), ("allgather", _ALLGATHER), ("alltoallv", _ALLTOALLV),
+                ("allreduce_dev", _ALLREDUCE)]
 
 
 class DDInfo(C.Structure):
     """struct ngravs_dd_info (include/ngravs_host.h)"""
-    _fields_ = [("level", C.c_int32), ("reserved", C.c_int32), ("n_local", C.c_int64), ("n_halo", C.c_int64),
+    _fields_ = [("n_topnodes", C.c_int32), ("n_topleaves", C.c_int32), ("n_local", C.c_int64), ("n_halo", C.c_int64),
                 ("n_migrated_in", C.c_int64), ("work_balance", C.c_double), ("memory_balance", C.c_double),
-                ("bytes_migration", C.c_double), ("bytes_halo", C.c_double), ("seconds", C.c_double * 8)]
+                ("bytes_migration", C.c_double), ("bytes_halo", C.c_double), ("seconds", C.c_double * 8),
+                ("toptree_rounds", C.c_int32), ("collectives", C.c_int32)]
+
+
+class RcclComm:
+    """struct ngravs_comm filled by libngravs_rccl.so (C): RCCL on the library's device buffers, no Python in the data path"""
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import RCCL_LIB_PATH
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = "rccl (libngravs_rccl.so)"
+        self.error = None
+        L = self._L = C.CDLL(RCCL_LIB_PATH)
+        L.ngravs_rccl_last_error.restype = C.c_char_p
+        L.ngravs_rccl_last_error.argtypes = [C.c_void_p]
+        L.ngravs_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.ngravs_rccl_fill.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_rccl_destroy.argtypes = [C.c_void_p]
+        L.ngravs_rccl_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.ngravs_rccl_world.argtypes = [C.c_void_p]
+        ident = C.create_string_buffer(128)
+        if self.rank == 0 and L.ngravs_rccl_unique_id(ident) != 0:
+            raise NgravsError("ncclGetUniqueId failed")
+        box = [ident.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = C.c_void_p()
+        dev = device.index if hasattr(device, "index") else int(device)
+        if L.ngravs_rccl_create(box[0], self.rank, self.size, dev, C.byref(self._h)) != 0:
+            raise NgravsError("ngravs_rccl_create failed (one task per GPU: RCCL refuses two ranks of a communicator on one device)")
+        self.c = Comm()
+        L.ngravs_rccl_fill(self._h, C.byref(self.c))
+        self.world_reported = int(L.ngravs_rccl_world(self._h))
+
+    def stats(self):
+        calls, sec, byt = C.c_int64(0), C.c_double(0), C.c_double(0)
+        self._L.ngravs_rccl_stats(self._h, C.byref(calls), C.byref(sec), C.byref(byt), 0)
+        return int(calls.value), float(sec.value), float(byt.value)
+
+    @property
+    def seconds(self):
+        return self.stats()[1]
+
+    @property
+    def calls(self):
+        return self.stats()[0]
+
+    def last_error(self):
+        m = self._L.ngravs_rccl_last_error(self._h)
+        return m.decode() if m else ""
+
+    def close(self):
+        if self._h:
+            self._L.ngravs_rccl_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class _DevArray:
@@ -61,7 +122,14 @@ class TorchComm:
         self.error = None
         self.seconds, self.calls = 0.0, 0
         self._cb = (_ALLREDUCE(self._allreduce), _ALLGATHER(self._allgather), _ALLTOALLV(self._alltoallv))
-        self.c = Comm(self.rank, self.size, 1, 0, None, *self._cb)
+        self.c = Comm(self.rank, self.size, 1, 0, None, *self._cb, C.cast(None, _ALLREDUCE))   # no device-side reduction
+        self.world_reported = self.size
+
+    def close(self):
+        pass
+
+    def last_error(self):
+        return repr(self.error) if self.error is not None else ""
 
     def _guard(self, fn, *a):
         import time
@@ -134,22 +202,29 @@ class TorchComm:
 
 
 class DistributedEngine(Engine):
-    def __init__(self, cfg, level=None, group=None):
+    def __init__(self, cfg, leaf_max=None, group=None, comm=None):
+        """leaf_max: a top-tree node is split while it holds more particles (None: the reference's TotNumPart / (20 NTask), at
+        most NGRAVS_TOPLEAF_MAX).  comm: "rccl" (C, libngravs_rccl.so) | "torch" | None = rccl when the process group's backend
+        is nccl, else torch."""
         import torch
-        cfg.rank, cfg.world_size = 0, 1          # the library sees its working set (own + halo) as a single task
+        import torch.distributed as dist
+        cfg.rank, cfg.world_size = 0, 1          # the library sees its working set (own + imported) as a single task
         super().__init__(cfg)
-        self.comm = TorchComm(torch.device("cuda", cfg.device), group)
+        dev = torch.device("cuda", cfg.device)
+        if comm is None:
+            comm = "rccl" if dist.get_backend(group) == "nccl" else "torch"
+        self.comm = RcclComm(dev, group) if comm == "rccl" else TorchComm(dev, group)
         self.rank, self.world, self.backend = self.comm.rank, self.comm.size, self.comm.backend
         if self.world > 64:
             raise NgravsError("at most 64 tasks")
-        self.level = level
+        self.leaf_max = leaf_max
         self.info = DDInfo()
         self.timings = {}
         self.reset_wall()
         L = self._L = lib()
         L.ngravs_dd_num_local.restype = C.c_int64
         L.ngravs_dd_num_local.argtypes = [C.c_void_p]
-        L.ngravs_host_domain_decomposition.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]
+        L.ngravs_host_domain_decomposition.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.ngravs_host_pmforce_periodic.argtypes = [C.c_void_p, C.c_void_p]
         L.ngravs_pm_slab_bytes.argtypes = [C.c_void_p, C.c_void_p]
 
@@ -157,7 +232,15 @@ class DistributedEngine(Engine):
         if self.comm.error is not None:
             e, self.comm.error = self.comm.error, None
             raise e
+        if rc != 0 and self.comm.last_error():
+            raise NgravsError("%s failed: status %d; communicator: %s" % (what, rc, self.comm.last_error()))
         self._check(rc, what)
+
+    def close(self):
+        super().close()
+        if getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = None
 
     # ---- particle hand-over ----------------------------------------------------------------------------------
     def set_particles(self, pos, mass, ptype, old_acc=None, active=None, ids=None, grav_pm=None, grav_cost=None):
@@ -176,9 +259,8 @@ class DistributedEngine(Engine):
 
     # ---- the step (the reference's names) ----------------------------------------------------------------------------
     def domain_Decomposition(self):
-        rc = self._L.ngravs_host_domain_decomposition(self._h, C.byref(self.comm.c), self.level or 0, 0.0, C.byref(self.info))
+        rc = self._L.ngravs_host_domain_decomposition(self._h, C.byref(self.comm.c), float(self.leaf_max or 0.0), 0.0, C.byref(self.info))
         self._host(rc, "ngravs_host_domain_decomposition")
-        self.level_used = self.info.level
         self.timings["migrated"], self.timings["halo"] = int(self.info.n_migrated_in), int(self.info.n_halo)
         self.n = self.num_local()
 

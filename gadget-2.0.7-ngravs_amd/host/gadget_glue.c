@@ -36,6 +36,10 @@
 #include "ngravs.h"
 #include "ngravs_hip.h"
 #include "ngravs_host.h"
+#ifdef NGRAVS_WITH_RCCL
+#include "ngravs_comm_rccl.h"	/* the exchanges of the path on RCCL over xGMI instead of MPI (link libngravs_rccl.so) */
+static ngravs_rccl *Rccl = NULL;
+#endif
 
 #ifndef DOUBLEPRECISION
 #error "libngravs_hip reads P[].Pos / Mass / OldAcc as double: build the reference with -DDOUBLEPRECISION (FLOAT = double, allvars.h:93-97)"
@@ -104,7 +108,8 @@ static void must(int rc, int code)
     }
 }
 
-/* ---- the communicator vtable over MPI (include/ngravs_host.h) --------------------------------------------------------- */
+#ifndef NGRAVS_WITH_RCCL
+/* ---- the communicator vtable over MPI (include/ngravs_host.h); with -DNGRAVS_WITH_RCCL: include/ngravs_comm_rccl.h instead ---- */
 static int mpi_allreduce(void *user, void *buf, int64_t count, int dtype, int op)
 {
   MPI_Op o = op == NGRAVS_OP_SUM ? MPI_SUM : (op == NGRAVS_OP_MIN ? MPI_MIN : MPI_MAX);
@@ -154,6 +159,7 @@ static int mpi_alltoallv(void *user, const void *send, const int64_t *sbytes, co
   free(sc);
   return err;
 }
+#endif
 
 static void ensure_ctx(void)
 {
@@ -206,12 +212,31 @@ static void ensure_ctx(void)
     endrun(1053);
   ngravs_set_fatal_handler(Ctx, on_fatal);
   memset(&Comm, 0, sizeof(Comm));
+#ifdef NGRAVS_WITH_RCCL
+  /* RCCL over xGMI: every exchange of the path (domain.c:695-747, gravtree.c:195-257, forcetree.c:811-816, pm_periodic.c:385-389,
+   * 433, 525, 655-660) on the library's device buffers.  MPI only hands the ncclUniqueId round, once. */
+  {
+    char id[NGRAVS_RCCL_ID_BYTES];
+    memset(id, 0, sizeof(id));
+    if(ThisTask == 0 && ngravs_rccl_unique_id(id))
+      endrun(1071);
+    MPI_Bcast(id, NGRAVS_RCCL_ID_BYTES, MPI_BYTE, 0, MPI_COMM_WORLD);
+    if(ngravs_rccl_create(id, ThisTask, NTask, cfg.device, &Rccl))
+      {
+	printf("ngravs-hip: ncclCommInitRank failed on task %d (one task per GPU)\n", ThisTask);
+	endrun(1072);
+      }
+    ngravs_rccl_fill(Rccl, &Comm);
+  }
+#else
   Comm.rank = ThisTask;
   Comm.size = NTask;
-  Comm.device_buffers = 0;	/* set to 1 with a GPU-aware MPI: the exchanges then never touch host memory (RCCL: ngravs_comm_rccl.h) */
+  Comm.device_buffers = 0;	/* plain MPI: ngravs_host stages the exchange buffers through host memory (1 with a GPU-aware MPI) */
   Comm.allreduce = mpi_allreduce;
   Comm.allgather = mpi_allgather;
   Comm.alltoallv = mpi_alltoallv;
+  Comm.allreduce_dev = NULL;
+#endif
 #if defined(PERIODIC) && !defined(PMGRID)
   if(NTask > 1)
     {
@@ -353,7 +378,7 @@ void domain_Decomposition(void)
 	  int32_t *dest;
 	  must(ngravs_host_domain_owners(Ctx, &Comm, 0, All.PartAllocFactor, &plan, &info), 1058);
 	  dest = malloc(sizeof(int32_t) * (NumPart > 0 ? NumPart : 1));
-	  must(ngravs_dd_get_dest(Ctx, plan.level, plan.owner_ph, dest), 1059);
+	  must(ngravs_dd_get_dest(Ctx, plan.leaf_owner, dest), 1059);
 	  exchange_particles(dest);
 	  free(dest);
 	  push_particles(0);	/* the migrated P[]: its order is the order of the library's results */

@@ -182,7 +182,7 @@ static int glue_decomposition(ngravs_ctx *ctx, ngravs_comm *cm, shm_rank *u, str
   err |= ngravs_set_particles(ctx, &pp);
   err |= ngravs_host_domain_owners(ctx, cm, 0, 1.5, &plan, info);
   dest = malloc(sizeof(int32_t) * (n > 0 ? n : 1));
-  err |= ngravs_dd_get_dest(ctx, plan.level, plan.owner_ph, dest);
+  err |= ngravs_dd_get_dest(ctx, plan.leaf_owner, dest);
   if(err)
     return 21;
   for(r = 0; r < NT; r++)
@@ -284,8 +284,8 @@ static void *task_main(void *arg)
       }
   }
   if(me == 0)
-    printf("two tasks: level %d, work balance %.3f, memory balance %.3f; task 0 holds %ld own + %ld halo particles\n", info.level,
-           info.work_balance, info.memory_balance, (long)info.n_local, (long)info.n_halo);
+    printf("two tasks: top tree of %d nodes / %d leaves (%d counting rounds), work balance %.3f, memory balance %.3f; task 0 holds %ld own + %ld imported particles\n",
+           info.n_topnodes, info.n_topleaves, info.toptree_rounds, info.work_balance, info.memory_balance, (long)info.n_local, (long)info.n_halo);
   /* ---- step 2 (no PM): P[].GravPM of step 1 is handed over with the particles and must enter OldAcc although the task's
    * working set holds imported rows (gravtree.c:318-330) ---- */
   if((err = glue_decomposition(ctx, &cm, u, P, &n, 1, &info)))
@@ -395,6 +395,80 @@ static int two_tasks(void)
   free(Pall);
   return 0;
 }
+
+#ifdef WITH_RCCL
+#include "ngravs_comm_rccl.h"
+/* =====================================================================================================================
+ *  Part 3: one task over RCCL, in C.  The communicator of include/ngravs_comm_rccl.h (host/ngravs_comm_rccl.c) with world size 1 --
+ *  one GPU on the box means one task; RCCL refuses two ranks of a communicator on one device -- carries EVERY collective of a
+ *  step: the two all-reduces of the decomposition (the per-leaf sums in place on the device), the count/request all-gather, the
+ *  import all-to-all-v, the bounding-box all-gather and the four plane exchanges of the slab PM, all on the library's device
+ *  buffers.  Forces and GravPM must be the single-task engine's.
+ * ===================================================================================================================== */
+static int rccl_one_task(void)
+{
+  char id[NGRAVS_RCCL_ID_BYTES];
+  ngravs_rccl *r = NULL;
+  ngravs_comm cm;
+  ngravs_config_t cfg;
+  ngravs_ctx *ctx = NULL;
+  ngravs_particles_t pp;
+  ngravs_dd_info info;
+  int64_t calls = 0;
+  double secs = 0, bytes = 0, worst = 0, dpm = 0, pmax = 0;
+  double *a = malloc(sizeof(double) * 3 * N2), *pm = malloc(sizeof(double) * 3 * N2);
+  int i, k;
+  if(ngravs_rccl_unique_id(id) || ngravs_rccl_create(id, 0, 1, 0, &r))
+    return 40;
+  ngravs_rccl_fill(r, &cm);
+  if(ngravs_rccl_world(r) != 1 || !cm.device_buffers || !cm.allreduce_dev)
+    return 41;
+  box_config(&cfg);
+  if(ngravs_create(&cfg, &ctx))
+    return 42;
+  Pall = calloc(N2, sizeof(*Pall));
+  srand(4711);   /* the particles of part 2: Acc1 / Pm1 hold the single-task answer */
+  for(i = 0; i < N2; i++)
+    {
+      for(k = 0; k < 3; k++)
+        Pall[i].Pos[k] = (float)(rand() / (RAND_MAX + 1.0));
+      Pall[i].Mass = 1.0 / N2;
+      Pall[i].Type = 1 + (i & 1);
+      Pall[i].ID = i;
+    }
+  hand_over(ctx, Pall, N2, &pp, 0);
+  if(ngravs_set_particles(ctx, &pp) || ngravs_host_compute_accelerations(ctx, &cm, 1, &info) ||
+     ngravs_get_accel(ctx, a, 24, pm, 24, NULL, 0, NULL, 0, 0, 0))
+    {
+      fprintf(stderr, "rccl task: %s / %s\n", ngravs_last_error(ctx), ngravs_rccl_last_error(r));
+      return 43;
+    }
+  ngravs_rccl_stats(r, &calls, &secs, &bytes, 0);
+  for(i = 0; i < N2; i++)
+    {
+      double d2 = 0, a2 = 0;
+      for(k = 0; k < 3; k++)
+        {
+          d2 += (a[3 * i + k] - Acc1[i][k]) * (a[3 * i + k] - Acc1[i][k]);
+          a2 += Acc1[i][k] * Acc1[i][k];
+          pmax = fmax(pmax, fabs(Pm1[i][k]));
+          dpm = fmax(dpm, fabs(pm[3 * i + k] - Pm1[i][k]));
+        }
+      worst = fmax(worst, sqrt(d2 / a2));
+    }
+  printf("one task over RCCL (C): %ld collectives, %.2f ms inside them, %.0f bytes; %d in the decomposition (%d counting rounds); "
+         "tree force worst |da|/|a| %.2e, GravPM max diff %.2e of max\n", (long)calls, 1e3 * secs, bytes, info.collectives,
+         info.toptree_rounds, worst, dpm / pmax);
+  ngravs_destroy(ctx);
+  ngravs_rccl_destroy(r);
+  free(a);
+  free(pm);
+  free(Pall);
+  if(!(worst < 1e-10 && dpm / pmax < 1e-10 && calls >= 8))
+    return 44;
+  return 0;
+}
+#endif
 
 int main(void)
 {
@@ -565,5 +639,12 @@ int main(void)
   ngravs_destroy(ctx);
   if(!(bad == 0 && st.n_active == nact && sum / nact < 5e-3 && worst < 0.1))
     return 1;
-  return two_tasks();
+  {
+    int rc = two_tasks();
+#ifdef WITH_RCCL
+    if(!rc)
+      rc = rccl_one_task();
+#endif
+    return rc;
+  }
 }

@@ -1,7 +1,13 @@
 /* ngravs_host.c -- multi-task drivers of the gravity path in plain C over a communicator vtable (include/ngravs_host.h).
  * Linked into libngravs_hip.so; uses nothing but the public C ABI of include/ngravs_hip.h and the caller's callbacks, so the
- * same code runs under MPI (host/gadget_glue.c), under RCCL through torch.distributed (distributed.py) and under the
- * shared-memory communicator of host/host_shim_test.c.
+ * same code runs under RCCL (host/ngravs_comm_rccl.c: gadget_glue.c, distributed.py), under MPI (gadget_glue.c's fallback),
+ * under torch.distributed "gloo" (rehearsals) and under the shared-memory communicator of host/host_shim_test.c.
+ *
+ * Collectives of one decomposition in the steady state: (1) all-reduce MIN of the extent and the target bounds, (2) all-reduce
+ * SUM of the per-leaf sums, (3) all-gather of the migration counts and the import requests, (4) all-to-all-v of migrating
+ * particles -- skipped by every task when the count matrix says nothing moves --, (5) all-to-all-v of the imported leaves.
+ * The receive counts of (5) need no collective: a leaf's owner holds ALL its particles after (4) and every task knows the
+ * global count of every leaf.
  */
 #define _POSIX_C_SOURCE 199309L
 #include <math.h>
@@ -10,6 +16,7 @@
 #include <string.h>
 #include <time.h>
 #include "ngravs_host.h"
+#include "ngravs_peano.h"
 
 #define CHECK(expr)            \
   do                           \
@@ -20,38 +27,6 @@
     }                          \
   while(0)
 
-/* Peano-Hilbert key of every cell (x, y, z) of level d, [x][y][z] order: depends on the level only, so it is computed once per
- * process (three loops over 8^level cells per step cost 3 ms each at level 5).  Lock-free publication: a second thread that
- * raced builds the same table and drops it. */
-static int32_t *ph_tables[8];
-static const int32_t *ph_table(int d)
-{
-  int32_t *t;
-  int x, y, z, nc;
-  if(d < 0 || d > 7)
-    return NULL;
-  t = __atomic_load_n(&ph_tables[d], __ATOMIC_ACQUIRE);
-  if(t)
-    return t;
-  nc = 1 << d;
-  t = malloc(sizeof(int32_t) * ((size_t)nc * nc * nc));
-  if(!t)
-    return NULL;
-  for(x = 0; x < nc; x++)
-    for(y = 0; y < nc; y++)
-      for(z = 0; z < nc; z++)
-        t[((size_t)x * nc + y) * nc + z] = (int32_t)ngravs_peano_hilbert_key(x, y, z, d);
-  {
-    int32_t *expected = NULL;
-    if(!__atomic_compare_exchange_n(&ph_tables[d], &expected, t, 0, __ATOMIC_RELEASE, __ATOMIC_ACQUIRE))
-      {
-        free(t);
-        t = expected;
-      }
-  }
-  return t;
-}
-
 static double wall_now(void)
 {
   struct timespec ts;
@@ -59,14 +34,17 @@ static double wall_now(void)
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+static int status_of(int rc) { return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE); }
+
 /* all-to-all-v of library device buffers; counts in bytes.  Without device-capable transport the blocks go through host memory. */
 static int exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const void *dsend, const int64_t *sbytes, void *drecv, const int64_t *rbytes)
 {
   const int W = cm->size;
-  int64_t *sd = malloc(sizeof(int64_t) * 2 * (size_t)(W + 1)), *rd = sd + W + 1;
+  int64_t *sd = malloc(sizeof(int64_t) * 2 * (size_t)(W + 1)), *rd;
   int r, rc = 0;
   if(!sd)
     return NGRAVS_ERR_NOMEM;
+  rd = sd + W + 1;
   sd[0] = rd[0] = 0;
   for(r = 0; r < W; r++)
     {
@@ -90,362 +68,374 @@ static int exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const void *dsend, c
       free(hr);
     }
   free(sd);
-  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+  return status_of(rc);
 }
 
-/* ---- the split of the Peano-cell sequence over the tasks --------------------------------------------------------------- */
-typedef struct
+/* =========================================================================================================================
+ *  The top tree (TopNodes[], domain.c:933-1138)
+ * ========================================================================================================================= */
+void ngravs_host_toptree_free(ngravs_toptree *t)
 {
-  const int64_t *count;
-  double maxload;
-  int32_t *owner;
-  int *start, *end;      /* first / last cell of every task */
-  double *load;          /* particles of every task          */
-} split_t;
+  if(!t)
+    return;
+  free(t->child);   /* one block: child, level, leaf, xyz; node_of_leaf separately */
+  free(t->node_of_leaf);
+  memset(t, 0, sizeof(*t));
+}
 
-/* domain_findSplit (domain.c:347-456): bisect the cells [first, last] among ncpu tasks so that the larger of the two average
- * particle loads is minimal, recursively; fails if a side would exceed maxload per task */
-static int find_split(split_t *S, int cpustart, int ncpu, int first, int last)
+static int tt_alloc(ngravs_toptree *t, int32_t nnode)
 {
-  const int nleft = ncpu / 2, nright = ncpu - nleft;
-  double load = 0, left = 0;
-  int i, split = first + nleft;
-  for(i = first; i <= last; i++)
-    load += (double)S->count[i];
-  for(i = first; i < split; i++)
-    left += (double)S->count[i];
-  while(split < last - (nright - 1) && split > 0)   /* every task keeps at least one cell */
-    {
-      const double cur = fmax(left / nleft, (load - left) / nright);
-      const double nxt = fmax((left + (double)S->count[split]) / nleft, (load - left - (double)S->count[split]) / nright);
-      if(nxt > cur)
-        break;
-      left += (double)S->count[split];
-      split++;
-    }
-  if(left > S->maxload * nleft || load - left > S->maxload * nright)
-    return -1;
-  if(nleft >= 2 && find_split(S, cpustart, nleft, first, split - 1))
-    return -1;
-  if(nright >= 2 && find_split(S, cpustart + nleft, nright, split, last))
-    return -1;
-  if(nleft == 1)
-    {
-      for(i = first; i < split; i++)
-        S->owner[i] = cpustart;
-      S->load[cpustart] = left;
-      S->start[cpustart] = first;
-      S->end[cpustart] = split - 1;
-    }
-  if(nright == 1)
-    {
-      for(i = split; i <= last; i++)
-        S->owner[i] = cpustart + nleft;
-      S->load[cpustart + nleft] = load - left;
-      S->start[cpustart + nleft] = split;
-      S->end[cpustart + nleft] = last;
-    }
+  memset(t, 0, sizeof(*t));
+  t->child = malloc(sizeof(int32_t) * 6 * (size_t)(nnode > 0 ? nnode : 1));
+  if(!t->child)
+    return NGRAVS_ERR_NOMEM;
+  t->level = t->child + nnode;
+  t->leaf = t->level + nnode;
+  t->xyz = t->leaf + nnode;
+  t->nnode = nnode;
   return 0;
 }
 
-int ngravs_host_split(const int64_t *count, const double *work, int64_t ncell, int ntask, double max_load, int32_t *owner)
+/* levels, cell coordinates and the numbering of the leaves along the curve from the child table.  The children of a node are
+ * stored in key order; which octant the r-th child is follows from the Peano-Hilbert state of the node (include/ngravs_peano.h:
+ * step[state][octant] = digit | next state << 3), carried down from the root. */
+static int tt_finish(ngravs_toptree *t)
 {
-  split_t S;
-  double *wk;
-  int t, moved, rc;
-  int64_t iter = 0, i;
-  if(!count || !owner || ntask < 1 || ncell < ntask)
+  const int32_t n = t->nnode;
+  int32_t *stack, *state, sp = 0, nleaf = 0, i;
+  if(n < 1)
+    return NGRAVS_ERR_ARG;
+  for(i = 0; i < n; i++)
+    if(t->child[i] >= 0 && (t->child[i] < 1 || t->child[i] > n - 8))
+      return NGRAVS_ERR_ARG;
+  stack = malloc(sizeof(int32_t) * 2 * (size_t)n);
+  if(!stack)
+    return NGRAVS_ERR_NOMEM;
+  state = stack + n;
+  for(i = 0; i < n; i++)
+    t->leaf[i] = -2;   /* not reached yet */
+  t->level[0] = 0;
+  t->xyz[0] = t->xyz[1] = t->xyz[2] = 0;
+  state[0] = 0;
+  t->depth = 0;
+  stack[sp++] = 0;
+  /* depth-first, children in key order: the leaves come out in curve order */
+  while(sp > 0)
+    {
+      const int32_t p = stack[--sp];
+      int oct;
+      if(t->child[p] < 0)
+        {
+          t->leaf[p] = nleaf++;
+          continue;
+        }
+      t->leaf[p] = -1;
+      if(t->level[p] + 1 > t->depth)
+        t->depth = t->level[p] + 1;
+      for(oct = 0; oct < 8; oct++)
+        {
+          const unsigned v = ngravs_ph_step_host[state[p]][oct];
+          const int32_t c = t->child[p] + (int32_t)(v & 7u);
+          if(t->leaf[c] != -2)
+            {
+              free(stack);
+              return NGRAVS_ERR_ARG;   /* two parents */
+            }
+          t->leaf[c] = -3;
+          t->level[c] = t->level[p] + 1;
+          t->xyz[3 * c + 0] = 2 * t->xyz[3 * p + 0] + ((oct >> 2) & 1);
+          t->xyz[3 * c + 1] = 2 * t->xyz[3 * p + 1] + ((oct >> 1) & 1);
+          t->xyz[3 * c + 2] = 2 * t->xyz[3 * p + 2] + (oct & 1);
+          state[c] = (int32_t)(v >> 3);
+        }
+      for(oct = 7; oct >= 0; oct--)   /* pushed in reverse: child 0 is popped first */
+        stack[sp++] = t->child[p] + oct;
+    }
+  free(stack);
+  for(i = 0; i < n; i++)
+    if(t->leaf[i] < -1)
+      return NGRAVS_ERR_ARG;   /* unreachable node */
+  t->nleaf = nleaf;
+  free(t->node_of_leaf);
+  t->node_of_leaf = malloc(sizeof(int32_t) * (size_t)nleaf);
+  if(!t->node_of_leaf)
+    return NGRAVS_ERR_NOMEM;
+  for(i = 0; i < n; i++)
+    if(t->leaf[i] >= 0)
+      t->node_of_leaf[t->leaf[i]] = i;
+  return 0;
+}
+
+int ngravs_host_toptree_from_children(ngravs_toptree *t, const int32_t *child, int32_t nnode)
+{
+  int rc;
+  if(!t || !child || nnode < 1)
+    return NGRAVS_ERR_ARG;
+  CHECK(tt_alloc(t, nnode));
+  memcpy(t->child, child, sizeof(int32_t) * (size_t)nnode);
+  rc = tt_finish(t);
+  if(rc)
+    ngravs_host_toptree_free(t);
+  return rc;
+}
+
+int ngravs_host_toptree_init(ngravs_toptree *t, int level)
+{
+  int64_t nn = 0, first, cnt, i;
+  int d, rc;
+  if(!t || level < 0 || level > 7)
+    return NGRAVS_ERR_ARG;
+  for(d = 0; d <= level; d++)
+    nn += 1ll << (3 * d);
+  CHECK(tt_alloc(t, (int32_t)nn));
+  /* breadth-first numbering: the nodes of level d start at (8^d - 1) / 7 */
+  for(d = 0, first = 0; d <= level; d++)
+    {
+      cnt = 1ll << (3 * d);
+      for(i = 0; i < cnt; i++)
+        t->child[first + i] = d < level ? (int32_t)(first + cnt + 8 * i) : -1;
+      first += cnt;
+    }
+  rc = tt_finish(t);
+  if(rc)
+    ngravs_host_toptree_free(t);
+  return rc;
+}
+
+/* global particle count of every node from the leaf counts (children before parents: a child's index is larger than its
+ * parent's in every tree this file builds -- checked) */
+static int tt_node_counts(const ngravs_toptree *t, const double *leaf_count, double *cnt)
+{
+  int32_t i, k;
+  for(i = t->nnode - 1; i >= 0; i--)
+    if(t->child[i] < 0)
+      cnt[i] = leaf_count[t->leaf[i]];
+    else
+      {
+        if(t->child[i] <= i)
+          return NGRAVS_ERR_ARG;
+        cnt[i] = 0;
+        for(k = 0; k < 8; k++)
+          cnt[i] += cnt[t->child[i] + k];
+      }
+  return 0;
+}
+
+/* One round of the reference's rule (domain_topsplit, domain.c:1060-1138: the root is split; a daughter is split if
+ * Count > TotNumPart / (TOPNODEFACTOR * NTask); cells of the deepest key level are never split) applied to a tree whose leaf
+ * counts are known.  A heavy leaf is split by as many levels at once as a uniform filling would need, at most three (its new
+ * leaves' counts are unknown: the caller counts again, and the next round merges what was split too far), so that a centrally
+ * concentrated set needs a few rounds instead of one per level.  The new tree is written breadth-first. */
+int ngravs_host_toptree_adapt(const ngravs_toptree *t, const double *leaf_count, double thresh, int max_level, ngravs_toptree *out)
+{
+  double *cnt;
+  int32_t *queue, qh = 0, qt = 0, unknown = 0, i;
+  int64_t cap;
+  int rc;
+  if(!t || !leaf_count || !out || t->nnode < 1 || !(thresh >= 1.0))
+    return NGRAVS_ERR_ARG;
+  if(max_level > NGRAVS_TOPLEVEL_MAX)
+    max_level = NGRAVS_TOPLEVEL_MAX;
+  cnt = malloc(sizeof(double) * (size_t)t->nnode);
+  if(!cnt)
+    return NGRAVS_ERR_NOMEM;
+  if((rc = tt_node_counts(t, leaf_count, cnt)))
+    {
+      free(cnt);
+      return rc;
+    }
+  cap = (int64_t)t->nnode + 64;
+  for(i = 0; i < t->nnode; i++)
+    if(t->child[i] < 0 && cnt[i] > thresh)
+      cap += 8 + 64 + 512;   /* <= 3 levels per heavy leaf */
+  if(cap > NGRAVS_TOPNODES_MAX)
+    cap = NGRAVS_TOPNODES_MAX;
+  queue = malloc(sizeof(int32_t) * 2 * (size_t)cap);   /* queue[2 q] = old node, or -1 - (levels still to split blindly); queue[2 q + 1] = level */
+  if(!queue || tt_alloc(out, (int32_t)cap))
+    {
+      free(cnt);
+      free(queue);
+      return NGRAVS_ERR_NOMEM;
+    }
+  queue[0] = 0;
+  queue[1] = 0;
+  qt = 1;
+  while(qh < qt && !rc)
+    {
+      const int32_t src = queue[2 * qh], lvl = queue[2 * qh + 1], me = qh;   /* the q-th node of the queue is node q of the new tree */
+      int32_t first_src = -1, blind = -1;
+      int split;
+      qh++;
+      if(src >= 0)
+        {
+          split = lvl == 0 || (cnt[src] > thresh && lvl < max_level);   /* the root is always split (TopNodes[0].Size >= 8) */
+          if(split && t->child[src] >= 0)
+            first_src = t->child[src];
+          else if(split)
+            {
+              double c = cnt[src] / 8.0;
+              blind = 0;
+              while(blind < 2 && c > thresh && lvl + 1 + blind < max_level)
+                {
+                  c /= 8.0;
+                  blind++;
+                }
+            }
+        }
+      else
+        {
+          blind = -1 - src - 1;   /* levels left below this one */
+          split = blind >= 0;
+          if(!split)
+            unknown++;
+        }
+      if(!split)
+        {
+          out->child[me] = -1;   /* a leaf of the old tree that stays one, a light subtree merged into one leaf, or a new leaf */
+          continue;
+        }
+      if((int64_t)qt + 8 > cap)
+        {
+          rc = NGRAVS_ERR_NOMEM;
+          break;
+        }
+      out->child[me] = qt;
+      for(i = 0; i < 8; i++)
+        {
+          queue[2 * qt] = first_src >= 0 ? first_src + i : -1 - blind;
+          queue[2 * qt + 1] = lvl + 1;
+          qt++;
+        }
+    }
+  free(cnt);
+  free(queue);
+  if(!rc)
+    {
+      /* the arrays were laid out for `cap` nodes: repack for the qt nodes there are */
+      ngravs_toptree packed;
+      rc = tt_alloc(&packed, qt);
+      if(!rc)
+        {
+          memcpy(packed.child, out->child, sizeof(int32_t) * (size_t)qt);
+          ngravs_host_toptree_free(out);
+          *out = packed;
+          rc = tt_finish(out);
+        }
+    }
+  if(rc)
+    {
+      ngravs_host_toptree_free(out);
+      return rc;
+    }
+  return unknown;
+}
+
+/* =========================================================================================================================
+ *  The cut of the leaf sequence over the tasks.  The reference bisects the sequence by particle count and then shifts the
+ *  boundaries by work (domain_findSplit / domain_shiftSplit, domain.c:347-544).  Here the whole problem is solved at once: the
+ *  smallest bottleneck B such that the sequence can be cut into NTask contiguous pieces with work <= B and count <= max_load
+ *  each (whether a B is feasible is a greedy sweep; B is found by bisection on the real line), then the greedy cut for that B,
+ *  every task keeping at least one leaf.
+ * ========================================================================================================================= */
+static int cut_sweep(const double *count, const double *work, int64_t n, int ntask, double B, double max_load, int32_t *owner)
+{
+  int64_t i = 0;
+  int t;
+  for(t = 0; t < ntask; t++)
+    {
+      double w = 0, c = 0;
+      const int64_t must_leave = ntask - 1 - t;   /* leaves the later tasks need (one each) */
+      const int64_t first = i;
+      while(i < n - must_leave)
+        {
+          if(i > first && (w + work[i] > B || c + count[i] > max_load))
+            break;
+          if(i == first && count[i] > max_load)
+            return -1;   /* one leaf alone breaks the memory bound */
+          w += work[i];
+          c += count[i];
+          if(owner)
+            owner[i] = t;
+          i++;
+        }
+      if(i == first)
+        return -1;
+    }
+  return i == n ? 0 : -1;
+}
+
+int ngravs_host_split(const double *count, const double *work, int64_t nleaf, int ntask, double max_load, int32_t *owner)
+{
+  double lo = 0, hi = 0, wmax = 0;
+  int64_t i;
+  int it;
+  if(!count || !owner || ntask < 1 || nleaf < ntask)
     return -1;
+  if(!work)
+    work = count;
+  if(!(max_load > 0))
+    max_load = 1e300;
   if(ntask == 1)
     {
-      for(i = 0; i < ncell; i++)
+      for(i = 0; i < nleaf; i++)
         owner[i] = 0;
       return 0;
     }
-  S.count = count;
-  S.maxload = max_load > 0 ? max_load : 1e300;
-  S.owner = owner;
-  S.start = malloc(sizeof(int) * 2 * (size_t)ntask);
-  S.end = S.start + ntask;
-  S.load = malloc(sizeof(double) * 2 * (size_t)ntask);
-  wk = S.load + ntask;
-  rc = find_split(&S, 0, ntask, 0, (int)ncell - 1);
-  if(rc == 0 && work)
+  for(i = 0; i < nleaf; i++)
     {
-      /* domain_shiftSplit (domain.c:468-544): move boundary cells between neighbours while that LOWERS the larger of the
-       * two work sums (strictly: a move that leaves it unchanged would be undone by the next sweep, for ever) and keeps the
-       * particle load within bounds */
-      for(t = 0; t < ntask; t++)
-        wk[t] = 0;
-      for(i = 0; i < ncell; i++)
-        wk[owner[i]] += work[i];
-      do
-        {
-          moved = 0;
-          for(t = 0; t < ntask - 1; t++)
-            {
-              const double maxw = fmax(wk[t], wk[t + 1]);
-              if(wk[t] < wk[t + 1])
-                {
-                  const int cell = S.start[t + 1];
-                  if(S.end[t + 1] <= cell)   /* the neighbour keeps at least one cell */
-                    continue;
-                  if(fmax(wk[t] + work[cell], wk[t + 1] - work[cell]) < maxw && S.load[t] + (double)count[cell] <= S.maxload)
-                    {
-                      wk[t] += work[cell];
-                      wk[t + 1] -= work[cell];
-                      S.load[t] += (double)count[cell];
-                      S.load[t + 1] -= (double)count[cell];
-                      owner[cell] = t;
-                      S.start[t + 1]++;
-                      S.end[t]++;
-                      moved++;
-                    }
-                }
-              else
-                {
-                  const int cell = S.end[t];
-                  if(S.start[t] >= cell)
-                    continue;
-                  if(fmax(wk[t] - work[cell], wk[t + 1] + work[cell]) < maxw && S.load[t + 1] + (double)count[cell] <= S.maxload)
-                    {
-                      wk[t] -= work[cell];
-                      wk[t + 1] += work[cell];
-                      S.load[t] -= (double)count[cell];
-                      S.load[t + 1] += (double)count[cell];
-                      owner[cell] = t + 1;
-                      S.end[t]--;
-                      S.start[t + 1]--;
-                      moved++;
-                    }
-                }
-            }
-          iter++;
-        }
-      while(moved > 0 && iter < 10 * ncell);
+      hi += work[i];
+      if(work[i] > wmax)
+        wmax = work[i];
     }
-  free(S.start);
-  free(S.load);
-  return rc;
-}
-
-/* ---- domain_Decomposition ------------------------------------------------------------------------------------------------ */
-static int choose_level(const ngravs_config_t *cfg)
-{
-  /* the coarsest cells still at least as wide as the short-range cut (the halo looks one cell layer around a task's cells);
-   * the curve's cube is 1.001 x the box */
-  int lvl = 1;
-  if(cfg->pmgrid > 0)
-    {
-      const double reach = 6.0 * NGRAVS_ASMTH * cfg->box_size / cfg->pmgrid;
-      while(lvl < 5 && cfg->box_size / (double)(1 << (lvl + 1)) >= 1.05 * reach)
-        lvl++;
-      return lvl;
-    }
-  return 4;
-}
-
-void ngravs_host_plan_free(ngravs_dd_plan *plan)
-{
-  if(plan)
-    {
-      free(plan->owner_ph);   /* owner_xyz lives in the same block */
-      plan->owner_ph = plan->owner_xyz = NULL;
-      plan->ncell = 0;
-    }
-}
-
-/* domain_findExtent + domain_sumCost + domain_findSplit + domain_shiftSplit (domain.c:882-924, 823-877, 347-544) */
-int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, int level, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info)
-{
-  ngravs_config_t cfg;
-  double lo[3], hi[3], total = 0, wtot = 0, wmax = 0, cmax = 0, *work = NULL, *twork = NULL;
-  int64_t *hist = NULL, ncell, i;
-  int32_t *owner_ph = NULL, *owner_xyz;
-  int r, x, y, z, nc, rc = 0, W, me;
-  ngravs_dd_info local;
-  if(!ctx || !cm || !plan || cm->size < 1 || cm->size > 64 || cm->rank < 0 || cm->rank >= cm->size)
-    return NGRAVS_ERR_ARG;
-  W = cm->size;
-  me = cm->rank;
-  (void)me;
-  if(!info)
-    info = &local;
-  memset(info, 0, sizeof(*info));
-  memset(plan, 0, sizeof(*plan));
-  info->seconds[0] = -wall_now();
-  CHECK(ngravs_get_config(ctx, &cfg));
-  CHECK(ngravs_dd_local_extent(ctx, lo, hi));
-  {
-    /* one collective for both ends: max(hi) = -min(-hi) */
-    double e[6] = {lo[0], lo[1], lo[2], -hi[0], -hi[1], -hi[2]};
-    CHECK(cm->allreduce(cm->user, e, 6, NGRAVS_T_F64, NGRAVS_OP_MIN));
-    for(r = 0; r < 3; r++)
-      {
-        lo[r] = e[r];
-        hi[r] = -e[3 + r];
-      }
-  }
-  CHECK(ngravs_dd_set_extent(ctx, lo, hi));
-  if(level <= 0)
-    level = choose_level(&cfg);
-  while(level < 7 && (1ll << (3 * level)) < 4ll * W)
-    level++;
-  info->level = level;
-  ncell = 1ll << (3 * level);
-  nc = 1 << level;
-  hist = malloc(sizeof(int64_t) * (size_t)ncell);
-  work = malloc(sizeof(double) * (size_t)ncell);
-  owner_ph = malloc(sizeof(int32_t) * 2 * (size_t)ncell);
-  twork = malloc(sizeof(double) * 2 * (size_t)W);
-  if(!hist || !work || !owner_ph || !twork)
-    rc = NGRAVS_ERR_NOMEM;
-  owner_xyz = owner_ph ? owner_ph + ncell : NULL;
-  if(!rc)
-    rc = ngravs_dd_histogram(ctx, level, hist, work);
-  if(!rc)
-    {
-      /* counts and work in ONE collective: whole numbers below 2^53 add up exactly as doubles */
-      double *both = malloc(sizeof(double) * 2 * (size_t)ncell);
-      if(!both)
-        rc = NGRAVS_ERR_NOMEM;
-      else
-        {
-          for(i = 0; i < ncell; i++)
-            {
-              both[i] = (double)hist[i];
-              both[ncell + i] = work[i];
-            }
-          rc = cm->allreduce(cm->user, both, 2 * ncell, NGRAVS_T_F64, NGRAVS_OP_SUM);
-          for(i = 0; i < ncell && !rc; i++)
-            {
-              hist[i] = (int64_t)(both[i] + 0.5);
-              work[i] = both[ncell + i];
-            }
-          free(both);
-        }
-    }
-  if(!rc)
-    {
-      for(i = 0; i < ncell; i++)
-        total += (double)hist[i];
-      if(ngravs_host_split(hist, work, ncell, W, (paf > 0 ? paf : 1.5) * total / W, owner_ph) &&
-         ngravs_host_split(hist, work, ncell, W, 0.0, owner_ph))
-        rc = NGRAVS_ERR_ARG;
-    }
-  if(!rc)
-    {
-      for(r = 0; r < 2 * W; r++)
-        twork[r] = 0;
-      for(i = 0; i < ncell; i++)
-        {
-          twork[owner_ph[i]] += work[i];
-          twork[W + owner_ph[i]] += (double)hist[i];
-        }
-      for(r = 0; r < W; r++)
-        {
-          wtot += twork[r];
-          wmax = fmax(wmax, twork[r]);
-          cmax = fmax(cmax, twork[W + r]);
-        }
-      info->work_balance = wtot > 0 ? wmax / (wtot / W) : 1.0;
-      info->memory_balance = total > 0 ? cmax / (total / W) : 1.0;
-      {
-        const int32_t *pht = ph_table(level);
-        if(!pht)
-          rc = NGRAVS_ERR_NOMEM;
-        else
-          for(x = 0; x < nc; x++)
-            for(y = 0; y < nc; y++)
-              for(z = 0; z < nc; z++)
-                owner_xyz[((size_t)x * nc + y) * nc + z] = owner_ph[pht[((size_t)x * nc + y) * nc + z]];
-      }
-      plan->level = level;
-      plan->ncell = ncell;
-      plan->owner_ph = owner_ph;
-      plan->owner_xyz = owner_xyz;
-      owner_ph = NULL;
-    }
-  free(hist);
-  free(work);
-  free(owner_ph);
-  free(twork);
-  info->seconds[0] += wall_now();
-  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
-}
-
-/* one packed-record exchange: what = 0 particle migration (domain_exchangeParticles, domain.c:695-795), what = 1 the
- * short-range halo (replaces the target export / force import of gravtree.c:195-257) */
-static int record_exchange(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, int what, ngravs_dd_info *info)
-{
-  const int W = cm->size, me = cm->rank;
-  int64_t *counts = malloc(sizeof(int64_t) * (size_t)(3 * 65 + W * W)), *mat, *sb, *rb, nrec = 0, nrecv = 0;
-  void *rec = NULL, *recvbuf = NULL;
-  int r, rc;
-  if(!counts)
-    return NGRAVS_ERR_NOMEM;
-  mat = counts + 65;
-  sb = mat + W * W;
-  rb = sb + 65;
-  rc = ngravs_dd_pack(ctx, what, plan->level, plan->owner_ph, plan->owner_xyz, W, me, counts, &rec, &nrec);
-  if(!rc)
-    rc = cm->allgather(cm->user, counts, mat, (int64_t)sizeof(int64_t) * W);
-  if(!rc)
-    {
-      const int64_t rbytes = ngravs_dd_record_bytes(ctx, what);   /* migration records of TreePM runs carry GravPM */
-      for(r = 0; r < W; r++)
-        {
-          sb[r] = counts[r] * rbytes;
-          rb[r] = mat[(size_t)r * W + me] * rbytes;
-          nrecv += mat[(size_t)r * W + me];
-          if(r != me)
-            *(what == 0 ? &info->bytes_migration : &info->bytes_halo) += (double)sb[r];
-        }
-      rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
-    }
-  if(!rc)
-    rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
-  if(!rc)
-    rc = what == 0 ? ngravs_dd_apply_migration(ctx, recvbuf, nrecv) : ngravs_dd_set_halo(ctx, recvbuf, nrecv);
-  if(what == 0)
-    info->n_migrated_in = nrecv;
+  hi = hi * (1.0 + 1e-12) + 1e-300;
+  if(cut_sweep(count, work, nleaf, ntask, hi, max_load, NULL))
+    return -1;   /* the memory bound alone cannot be met */
+  lo = fmax(wmax, hi / ntask) * (1.0 - 1e-12);
+  if(cut_sweep(count, work, nleaf, ntask, lo, max_load, NULL) == 0)
+    hi = lo;
   else
-    info->n_halo = nrecv;
-  free(counts);
-  return rc;
+    for(it = 0; it < 64 && hi - lo > 1e-13 * hi; it++)
+      {
+        const double mid = 0.5 * (lo + hi);
+        if(cut_sweep(count, work, nleaf, ntask, mid, max_load, NULL) == 0)
+          hi = mid;
+        else
+          lo = mid;
+      }
+  return cut_sweep(count, work, nleaf, ntask, hi, max_load, owner);
 }
 
-/* ---- which foreign top cells may this task's targets have to open? ----------------------------------------------------------
- * The walk's own tests (group traversal of kernels_walk.hip = the conservative form of forcetree.c:1364-1518, 1828-1862) against
- * boxes that enclose the task's domain, applied from the root of the global top tree downwards.  A node no target can open is
- * used as a monopole at most: nothing below it is needed.  A node that may be opened: its single-particle children, and -- if it
- * holds <= 8 particles, which the group walk hands over as a leaf -- everything below it, must be on this task. */
+/* =========================================================================================================================
+ *  Which foreign top leaves may this task's targets have to open?
+ *  The walk's own tests (group traversal of kernels_walk.hip = the conservative form of forcetree.c:1364-1518, 1828-1862)
+ *  against boxes that enclose the task's leaves, applied from the root of the top tree downwards.  A node no target can open is
+ *  used as a monopole at most: nothing below it is needed.  A node that may be opened: its single-particle children, and -- if
+ *  it holds <= 8 particles, which the group walk hands over as a leaf -- everything below it, must be on this task.
+ * ========================================================================================================================= */
 typedef struct
 {
-  int L, ng, periodic, pm, use_theta;
+  int ng, periodic, pm, use_theta;
   double box, theta2, aold_min, h_min, rcut, reach6, fsoft[6], corner[3], len;
-  const double *sums;    /* all levels, TOP_CW doubles per cell */
-  const int64_t *off;    /* first cell of every level */
-  const int32_t *xyz;    /* ix | iy << 10 | iz << 20 per cell */
+  const ngravs_toptree *t;
+  const double *sums;    /* TOP_CW doubles per node */
   int nbox;
   double (*bc)[3], (*bh)[3];
-  uint8_t *need;         /* per level-L cell */
-  const uint8_t *mine;   /* all levels: nothing below this cell could be requested (every top leaf below is this task's own, or empty) */
+  uint8_t *need;         /* per leaf */
+  const uint8_t *mine;   /* per node: nothing below could be requested (every leaf below is this task's own, or empty) */
 } need_t;
 
 static double near_abs(double x, double box) { return x - box * rint(x / box); }
 
-static int may_open(const need_t *T, int d, int64_t prefix)
+static int may_open(const need_t *T, int32_t node)
 {
   const int cw = NGRAVS_TOP_CW(T->ng);
-  const double *s = T->sums + (size_t)(T->off[d] + prefix) * cw;
-  const int32_t xyz = T->xyz[T->off[d] + prefix];
-  const double len = T->len / (double)(1 << d), half = 0.5 * len;
+  const double *s = T->sums + (size_t)node * cw;
+  const int d = T->t->level[node];
+  const double len = ldexp(T->len, -d), half = 0.5 * len;
   double c[3], com[NGRAVS_MAX_GRAVS][3], summass = 0, hs_node = 0;
   int g, j, b, ty, mixed = 0, first = 1;
-  c[0] = T->corner[0] + ((xyz & 1023) + 0.5) * len;
-  c[1] = T->corner[1] + (((xyz >> 10) & 1023) + 0.5) * len;
-  c[2] = T->corner[2] + (((xyz >> 20) & 1023) + 0.5) * len;
+  for(j = 0; j < 3; j++)
+    c[j] = T->corner[j] + (T->t->xyz[3 * node + j] + 0.5) * len;
   for(g = 0; g < T->ng; g++)
     {
       const double m = s[7 + 4 * g];
@@ -515,54 +505,487 @@ static int may_open(const need_t *T, int d, int64_t prefix)
   return 0;
 }
 
-static void need_all_below(const need_t *T, int d, int64_t prefix)
+static void need_all_below(const need_t *T, int32_t node)
 {
-  const int sh = 3 * (T->L - d);
-  int64_t i;
-  for(i = prefix << sh; i < ((prefix + 1) << sh); i++)
-    if(T->sums[(size_t)(T->off[T->L] + i) * NGRAVS_TOP_CW(T->ng)] > 0.5)
-      T->need[i] = 1;
+  if(T->t->child[node] < 0)
+    {
+      if(T->sums[(size_t)node * NGRAVS_TOP_CW(T->ng)] > 0.5)
+        T->need[T->t->leaf[node]] = 1;
+    }
+  else
+    {
+      int k;
+      for(k = 0; k < 8; k++)
+        need_all_below(T, T->t->child[node] + k);
+    }
 }
 
 /* called for the children of a node that may be opened */
-static void need_visit(const need_t *T, int d, int64_t prefix)
+static void need_visit(const need_t *T, int32_t node)
 {
-  const double cnt = T->sums[(size_t)(T->off[d] + prefix) * NGRAVS_TOP_CW(T->ng)];
+  const double cnt = T->sums[(size_t)node * NGRAVS_TOP_CW(T->ng)];
   int k;
-  if(cnt < 0.5 || T->mine[T->off[d] + prefix])
+  if(cnt < 0.5 || T->mine[node])
     return;
   if(cnt < 1.5)   /* a single particle: it hangs directly below the opened parent */
     {
-      need_all_below(T, d, prefix);
+      need_all_below(T, node);
       return;
     }
-  if(!may_open(T, d, prefix))
+  if(!may_open(T, node))
     return;
-  if(d == T->L || cnt < 8.5)   /* a top leaf, or a node the group walk hands over particle by particle (GW_NLEAF) */
+  if(T->t->child[node] < 0 || cnt < 8.5)   /* a top leaf, or a node the group walk hands over particle by particle (GW_NLEAF) */
     {
-      need_all_below(T, d, prefix);
+      need_all_below(T, node);
       return;
     }
   for(k = 0; k < 8; k++)
-    need_visit(T, d + 1, prefix * 8 + k);
+    need_visit(T, T->t->child[node] + k);
+}
+
+int ngravs_host_import_request(const ngravs_config_t *cfg, const double dom[8], const ngravs_toptree *t, const double *node_sums,
+                               const int32_t *leaf_owner, int me, const double bounds[2], uint8_t *need)
+{
+  need_t T;
+  double blo[64][3], bhi[64][3], (*bc)[3], (*bh)[3];
+  uint8_t *mine;
+  int32_t i;
+  int j, k, cw, used[64], rc = 0;
+  if(!cfg || !dom || !t || !node_sums || !leaf_owner || !bounds || !need || t->nnode < 1)
+    return NGRAVS_ERR_ARG;
+  cw = NGRAVS_TOP_CW(cfg->n_gravs);
+  memset(need, 0, (size_t)t->nleaf);
+  mine = malloc((size_t)t->nnode);
+  bc = malloc(sizeof(*bc) * 64);
+  bh = malloc(sizeof(*bh) * 64);
+  if(!mine || !bc || !bh)
+    rc = NGRAVS_ERR_NOMEM;
+  if(!rc)
+    {
+      /* boxes around the own leaves that hold particles, one per block of the level-2 grid (64 blocks) */
+      for(k = 0; k < 64; k++)
+        used[k] = 0;
+      for(i = 0; i < t->nleaf; i++)
+        {
+          const int32_t node = t->node_of_leaf[i];
+          const int d = t->level[node];
+          const double cl = ldexp(dom[6], -d);
+          int b[3];
+          if(leaf_owner[i] != me || node_sums[(size_t)node * cw] < 0.5)
+            continue;
+          for(j = 0; j < 3; j++)
+            b[j] = d >= 2 ? (t->xyz[3 * node + j] >> (d - 2)) : (t->xyz[3 * node + j] << (2 - d));
+          k = (b[0] * 4 + b[1]) * 4 + b[2];
+          for(j = 0; j < 3; j++)
+            {
+              const double lo = dom[j] + t->xyz[3 * node + j] * cl, hi = lo + cl;
+              if(!used[k] || lo < blo[k][j])
+                blo[k][j] = lo;
+              if(!used[k] || hi > bhi[k][j])
+                bhi[k][j] = hi;
+            }
+          used[k] = 1;
+        }
+      T.nbox = 0;
+      for(k = 0; k < 64; k++)
+        if(used[k])
+          {
+            for(j = 0; j < 3; j++)
+              {
+                bc[T.nbox][j] = 0.5 * (blo[k][j] + bhi[k][j]);
+                bh[T.nbox][j] = 0.5 * (bhi[k][j] - blo[k][j]) + 1e-9 * dom[6];   /* rounding slack */
+              }
+            T.nbox++;
+          }
+      T.ng = cfg->n_gravs;
+      T.periodic = cfg->periodic;
+      T.pm = cfg->pmgrid != 0;
+      T.use_theta = cfg->err_tol_theta != 0;
+      T.box = cfg->box_size;
+      T.theta2 = cfg->err_tol_theta * cfg->err_tol_theta;
+      T.aold_min = bounds[0];
+      T.h_min = bounds[1];
+      T.rcut = cfg->rcut;
+      T.reach6 = 6.0 * cfg->asmth;
+      for(j = 0; j < 6; j++)
+        T.fsoft[j] = cfg->force_softening[j];
+      for(j = 0; j < 3; j++)
+        T.corner[j] = dom[j];
+      T.len = dom[6];
+      T.t = t;
+      T.sums = node_sums;
+      T.bc = bc;
+      T.bh = bh;
+      T.need = need;
+      /* below a node whose leaves are all this task's own (or empty) there is nothing to request */
+      for(i = t->nnode - 1; i >= 0; i--)
+        if(t->child[i] < 0)
+          mine[i] = leaf_owner[t->leaf[i]] == me || node_sums[(size_t)i * cw] < 0.5;
+        else
+          {
+            uint8_t a = 1;
+            for(k = 0; k < 8; k++)
+              a &= mine[t->child[i] + k];
+            mine[i] = a;
+          }
+      T.mine = mine;
+      if(T.nbox > 0 && t->child[0] >= 0)   /* the root is opened by every target inside it */
+        for(k = 0; k < 8; k++)
+          need_visit(&T, t->child[0] + k);
+      for(i = 0; i < t->nleaf; i++)
+        if(leaf_owner[i] == me)
+          need[i] = 0;   /* own leaves are here already */
+    }
+  free(mine);
+  free(bc);
+  free(bh);
+  return rc;
+}
+
+/* =========================================================================================================================
+ *  domain_Decomposition
+ * ========================================================================================================================= */
+void ngravs_host_plan_free(ngravs_dd_plan *plan)
+{
+  if(plan)
+    {
+      ngravs_host_toptree_free(&plan->tree);
+      free(plan->leaf_owner);
+      free(plan->node_sums);
+      plan->leaf_owner = NULL;
+      plan->node_sums = NULL;
+    }
+}
+
+/* The all-reduced per-leaf sums of the top tree `t` -> sums (host, nleaf * cw doubles + 1 status word).  One collective, which
+ * a task enters even after a local failure (rc_in != 0, or a failing library call here): with zeros and a raised status word, so
+ * that all tasks return the error together. */
+static int leaf_sums_round(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_toptree *t, int cw, double *sums, int rc_in,
+                           ngravs_dd_info *info)
+{
+  void *dev = NULL;
+  int64_t count = 0;
+  const int64_t want = (int64_t)t->nleaf * cw;
+  int rc = rc_in, rcc;
+  if(!rc)
+    rc = ngravs_dd_set_toptree(ctx, t->nnode, t->child);
+  if(!rc)
+    rc = ngravs_dd_leaf_sums(ctx, &dev, &count);   /* the library keeps one spare word (zero) behind the table: the status */
+  if(!rc && count != want + 1)
+    rc = NGRAVS_ERR_STATE;
+  if(cm->allreduce_dev)
+    {
+      if(rc)
+        {
+          /* take part with zeros and status 1 from a scratch buffer of the library */
+          memset(sums, 0, sizeof(double) * (size_t)want);
+          sums[want] = 1.0;
+          if(ngravs_dd_recv_buffer(ctx, (want + 1) * (int64_t)sizeof(double) / NGRAVS_DD_MAX_RECORD_BYTES + 1, &dev) ||
+             ngravs_memcpy(ctx, dev, sums, (int64_t)sizeof(double) * (want + 1), 1))
+            return status_of(rc);   /* not even that: the other tasks are left waiting */
+        }
+      rcc = cm->allreduce_dev(cm->user, dev, want + 1, NGRAVS_T_F64, NGRAVS_OP_SUM);
+      info->collectives++;
+      if(!rcc)
+        rcc = ngravs_memcpy(ctx, sums, dev, (int64_t)sizeof(double) * (want + 1), 2);
+    }
+  else
+    {
+      if(!rc)
+        rc = ngravs_memcpy(ctx, sums, dev, (int64_t)sizeof(double) * want, 2);
+      if(rc)
+        memset(sums, 0, sizeof(double) * (size_t)want);
+      sums[want] = rc ? 1.0 : 0.0;
+      rcc = cm->allreduce(cm->user, sums, want + 1, NGRAVS_T_F64, NGRAVS_OP_SUM);
+      info->collectives++;
+    }
+  if(rc || rcc)
+    return status_of(rc ? rc : rcc);
+  return sums[want] > 0.5 ? NGRAVS_ERR_STATE : 0;
+}
+
+/* domain_findExtent + domain_determineTopTree + domain_sumCost + the cut (domain.c:882-924, 933-1138, 823-877, 347-544) */
+int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info)
+{
+  ngravs_config_t cfg;
+  ngravs_toptree tree, next;
+  double lo[3], hi[3], bounds[2] = {1e300, 1e300}, e[9], total = 0, wtot = 0, wmax = 0, cmax = 0, *sums = NULL, *lcount = NULL, *lwork,
+         *twork = NULL, thresh, n_own;
+  int32_t *owner = NULL, i;
+  int r, k, q, cw, rc = 0, W, round;
+  ngravs_dd_info local;
+  if(!ctx || !cm || !plan || cm->size < 1 || cm->size > 64 || cm->rank < 0 || cm->rank >= cm->size)
+    return NGRAVS_ERR_ARG;
+  W = cm->size;
+  if(!info)
+    info = &local;
+  memset(info, 0, sizeof(*info));
+  memset(plan, 0, sizeof(*plan));
+  memset(&tree, 0, sizeof(tree));
+  memset(&cfg, 0, sizeof(cfg));
+  info->seconds[0] = -wall_now();
+  rc = ngravs_get_config(ctx, &cfg);
+  cw = NGRAVS_TOP_CW(cfg.n_gravs > 0 ? cfg.n_gravs : 1);
+  if(!rc)
+    rc = ngravs_dd_local_extent(ctx, lo, hi);
+  if(!rc)
+    rc = ngravs_dd_target_bounds(ctx, bounds);
+  n_own = (double)ngravs_dd_num_local(ctx);
+  /* one collective for both ends of the extent (max(hi) = -min(-hi)), the bounds of the opening tests and the status */
+  for(r = 0; r < 3; r++)
+    {
+      e[r] = rc ? 1e300 : lo[r];
+      e[3 + r] = rc ? 1e300 : -hi[r];
+    }
+  e[6] = bounds[0];
+  e[7] = bounds[1];
+  e[8] = rc ? -1.0 : 0.0;
+  {
+    const int rcc = cm->allreduce(cm->user, e, 9, NGRAVS_T_F64, NGRAVS_OP_MIN);
+    info->collectives++;
+    if(rcc)
+      return status_of(rcc);
+  }
+  if(e[8] < -0.5)
+    return rc ? status_of(rc) : NGRAVS_ERR_STATE;
+  for(r = 0; r < 3; r++)
+    {
+      lo[r] = e[r];
+      hi[r] = -e[3 + r];
+    }
+  plan->bounds[0] = e[6];
+  plan->bounds[1] = e[7];
+  rc = ngravs_dd_set_extent(ctx, lo, hi);
+  /* the top tree of the last decomposition, or a first guess: the complete tree whose leaves a uniform filling would leave
+   * with about the threshold */
+  if(!rc)
+    {
+      const int32_t *child = NULL;
+      int32_t nn = 0;
+      rc = ngravs_dd_get_toptree(ctx, &nn, &child);
+      if(!rc && nn > 0)
+        rc = ngravs_host_toptree_from_children(&tree, child, nn);
+      else if(!rc)
+        {
+          const double guess = n_own * W, lm = leaf_max > 0 ? leaf_max : fmin(NGRAVS_TOPLEAF_MAX, guess / (20.0 * W));
+          int lvl = 1;
+          while(lvl < 6 && guess / (double)(1ll << (3 * lvl)) > lm)
+            lvl++;
+          rc = ngravs_host_toptree_init(&tree, lvl);
+        }
+    }
+  if(rc)   /* without a tree the following collective cannot even be sized: the other tasks are left waiting */
+    return status_of(rc);
+  for(round = 0; round < 32; round++)
+    {
+      const int64_t want = (int64_t)tree.nleaf * cw;
+      const double t0 = wall_now();
+      int unknown;
+      free(sums);
+      sums = malloc(sizeof(double) * (size_t)(want + 1));
+      if(!sums)
+        {
+          ngravs_host_toptree_free(&tree);
+          free(lcount);
+          return NGRAVS_ERR_NOMEM;
+        }
+      rc = leaf_sums_round(ctx, cm, &tree, cw, sums, rc, info);
+      info->seconds[2] += wall_now() - t0;
+      info->toptree_rounds = round + 1;
+      if(rc)
+        break;
+      /* per leaf: [0] carries the work; the particle count is the sum of the per-type counts */
+      free(lcount);
+      lcount = malloc(sizeof(double) * 2 * (size_t)tree.nleaf);
+      if(!lcount)
+        {
+          rc = NGRAVS_ERR_NOMEM;
+          break;
+        }
+      total = 0;
+      for(i = 0; i < tree.nleaf; i++)
+        {
+          const double *p = sums + (size_t)i * cw;
+          lcount[i] = p[1] + p[2] + p[3] + p[4] + p[5] + p[6];
+          lcount[tree.nleaf + i] = p[0];
+          total += lcount[i];
+        }
+      thresh = leaf_max > 0 ? leaf_max : fmin(NGRAVS_TOPLEAF_MAX, total / (20.0 * W));   /* domain.c:1127: TotNumPart / (TOPNODEFACTOR * NTask) */
+      if(thresh < 1.0)
+        thresh = 1.0;
+      unknown = ngravs_host_toptree_adapt(&tree, lcount, thresh, NGRAVS_TOPLEVEL_MAX, &next);
+      if(unknown < 0)
+        {
+          rc = unknown;
+          break;
+        }
+      if(unknown == 0 && next.nnode == tree.nnode)
+        {
+          ngravs_host_toptree_free(&next);
+          break;   /* the tree obeys the rule and is the one these sums were taken for */
+        }
+      ngravs_host_toptree_free(&tree);
+      tree = next;   /* new leaves (or merged ones): count again with the new tree */
+    }
+  if(!rc && round >= 32)
+    rc = NGRAVS_ERR_STATE;
+  if(!rc)
+    {
+      owner = malloc(sizeof(int32_t) * (size_t)tree.nleaf);
+      twork = malloc(sizeof(double) * 2 * (size_t)W);
+      plan->node_sums = calloc((size_t)tree.nnode * cw, sizeof(double));
+      if(!owner || !twork || !plan->node_sums)
+        rc = NGRAVS_ERR_NOMEM;
+    }
+  if(!rc)
+    {
+      lwork = lcount + tree.nleaf;
+      if(ngravs_host_split(lcount, lwork, tree.nleaf, W, (paf > 0 ? paf : 1.5) * total / W, owner) &&
+         ngravs_host_split(lcount, lwork, tree.nleaf, W, 0.0, owner))
+        rc = NGRAVS_ERR_ARG;
+    }
+  if(!rc)
+    {
+      lwork = lcount + tree.nleaf;
+      for(r = 0; r < 2 * W; r++)
+        twork[r] = 0;
+      for(i = 0; i < tree.nleaf; i++)
+        {
+          twork[owner[i]] += lwork[i];
+          twork[W + owner[i]] += lcount[i];
+        }
+      for(r = 0; r < W; r++)
+        {
+          wtot += twork[r];
+          wmax = fmax(wmax, twork[r]);
+          cmax = fmax(cmax, twork[W + r]);
+        }
+      info->work_balance = wtot > 0 ? wmax / (wtot / W) : 1.0;
+      info->memory_balance = total > 0 ? cmax / (total / W) : 1.0;
+      /* sums of every top node, children in fixed order: the same numbers on every task (force_treeupdate_pseudos adds the
+       * top-leaf moments up the ancestor chain, forcetree.c:851-947) */
+      for(i = tree.nnode - 1; i >= 0; i--)
+        {
+          double *dst = plan->node_sums + (size_t)i * cw;
+          if(tree.child[i] < 0)
+            {
+              memcpy(dst, sums + (size_t)tree.leaf[i] * cw, sizeof(double) * (size_t)cw);
+              dst[0] = lcount[tree.leaf[i]];
+            }
+          else
+            for(k = 0; k < 8; k++)
+              {
+                const double *src = plan->node_sums + (size_t)(tree.child[i] + k) * cw;
+                for(q = 0; q < cw; q++)
+                  dst[q] += src[q];
+              }
+        }
+      plan->tree = tree;
+      plan->leaf_owner = owner;
+      memset(&tree, 0, sizeof(tree));
+      owner = NULL;
+      info->n_topnodes = plan->tree.nnode;
+      info->n_topleaves = plan->tree.nleaf;
+    }
+  free(sums);
+  free(lcount);
+  free(owner);
+  free(twork);
+  ngravs_host_toptree_free(&tree);
+  if(rc)
+    ngravs_host_plan_free(plan);
+  info->seconds[0] += wall_now();
+  return status_of(rc);
+}
+
+/* particle migration (domain_exchangeParticles, domain.c:695-795) and the import requests of all tasks in ONE all-gather:
+ * every task contributes its send counts (W int64), a status word, and its request bits (one byte per leaf) */
+static int migrate_and_request(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, int do_migration, int rc_in,
+                               const uint8_t *need, uint8_t *allneed, ngravs_dd_info *info)
+{
+  const int W = cm->size, me = cm->rank;
+  const int64_t nleaf = plan->tree.nleaf, head_bytes = (int64_t)sizeof(int64_t) * (W + 1), blk = head_bytes + nleaf;
+  char *mine = malloc((size_t)blk), *all = malloc((size_t)blk * (size_t)W);
+  int64_t counts[65], sb[65], rb[65], head[65], nrec = 0, nrecv = 0, moving = 0;
+  void *rec = NULL, *recvbuf = NULL;
+  int r, q, rc = rc_in, rcc, bad = 0;
+  if(!mine || !all)
+    {
+      free(mine);
+      free(all);
+      return NGRAVS_ERR_NOMEM;   /* the buffers of the collective itself are missing: this task cannot take part */
+    }
+  memset(counts, 0, sizeof(counts));
+  if(!rc && do_migration)
+    rc = ngravs_dd_pack(ctx, 0, plan->leaf_owner, W, me, counts, &rec, &nrec);
+  for(r = 0; r < W; r++)
+    head[r] = rc ? 0 : counts[r];
+  head[W] = rc ? 1 : 0;
+  memcpy(mine, head, (size_t)head_bytes);
+  memcpy(mine + head_bytes, need, (size_t)nleaf);
+  rcc = cm->allgather(cm->user, mine, all, blk);
+  info->collectives++;
+  if(rcc && !rc)
+    rc = rcc;
+  for(r = 0; r < W && !rcc; r++)
+    {
+      memcpy(head, all + (size_t)blk * r, (size_t)head_bytes);
+      if(head[W])
+        bad = 1;
+      memcpy(allneed + (size_t)nleaf * r, all + (size_t)blk * r + head_bytes, (size_t)nleaf);
+      rb[r] = head[me];
+      for(q = 0; q < W; q++)
+        if(q != r)
+          moving += head[q];
+    }
+  free(mine);
+  free(all);
+  if(!rc && bad)
+    rc = NGRAVS_ERR_STATE;   /* all tasks see the raised status word: all stop here */
+  if(!rc && do_migration)
+    {
+      const int64_t rbytes = ngravs_dd_record_bytes(ctx, 0);   /* migration records of TreePM runs carry GravPM */
+      const double t0 = wall_now();
+      for(r = 0; r < W; r++)
+        {
+          nrecv += rb[r];
+          sb[r] = counts[r] * rbytes;
+          rb[r] *= rbytes;
+          if(r != me)
+            info->bytes_migration += (double)sb[r];
+        }
+      info->n_migrated_in = nrecv;
+      if(moving > 0)   /* every task sees the same matrix: all skip the exchange together when nothing moves */
+        {
+          rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
+          if(!rc)
+            {
+              rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
+              info->collectives++;
+            }
+        }
+      if(!rc)
+        rc = ngravs_dd_apply_migration(ctx, recvbuf, nrecv);
+      info->seconds[1] += wall_now() - t0;
+    }
+  return status_of(rc);
 }
 
 /* Top-leaf moments + tree-node import + local Peano order: the second half of domain_Decomposition() for a task whose own
  * particles are in place (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996, and what replaces the
- * export / import loop of gravtree.c:112-285) */
-int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, ngravs_dd_info *info)
+ * export / import loop of gravtree.c:112-285).  `migrate`: the library's own columns still have to move (library-side
+ * migration); 0 when the host has exchanged its P[] itself and handed the result over. */
+static int domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, int migrate, ngravs_dd_info *info)
 {
   ngravs_dd_info local;
   ngravs_config_t cfg;
-  need_t T;
-  double *sums = NULL, dom[8], bounds[2], (*bc)[3] = NULL, (*bh)[3] = NULL, blo[64][3], bhi[64][3];
-  int64_t *off = NULL, ncell, tot, i, *counts = NULL, *mat, *sb, *rb, nrec = 0, nrecv = 0;
-  int32_t *xyz = NULL;
-  uint8_t *need = NULL, *allneed = NULL, *present = NULL, *mine = NULL;
+  double dom[8];
+  int64_t nleaf, i, sc[65], rcn[65], nrec = 0, nrecv = 0;
+  uint8_t *need = NULL, *allneed = NULL, *present = NULL;
   uint64_t *reqmask = NULL;
   void *rec = NULL, *recvbuf = NULL;
-  int L, nc, d, x, y, z, r, j, k, cw, used[64], rc = 0, W, me;
-  if(!ctx || !cm || !plan || !plan->owner_ph)
+  int r, cw, rc = 0, W, me;
+  if(!ctx || !cm || !plan || !plan->leaf_owner || !plan->node_sums)
     return NGRAVS_ERR_ARG;
   W = cm->size;
   me = cm->rank;
@@ -571,175 +994,68 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
       memset(&local, 0, sizeof(local));
       info = &local;
     }
-  CHECK(ngravs_get_config(ctx, &cfg));
-  CHECK(ngravs_get_domain_extent(ctx, dom));
-  L = plan->level;
-  ncell = plan->ncell;
-  nc = 1 << L;
-  cw = NGRAVS_TOP_CW(cfg.n_gravs);
-  off = malloc(sizeof(int64_t) * (size_t)(L + 2));
-  off[0] = 0;
-  for(d = 0; d <= L; d++)
-    off[d + 1] = off[d] + (1ll << (3 * d));
-  tot = off[L + 1];
-  sums = calloc((size_t)tot * cw, sizeof(double));
-  xyz = malloc(sizeof(int32_t) * (size_t)tot);
-  need = calloc((size_t)ncell, 1);
-  mine = malloc((size_t)tot);
-  allneed = malloc((size_t)ncell * (size_t)W);
-  present = malloc((size_t)ncell);
-  reqmask = calloc((size_t)ncell, sizeof(uint64_t));
-  counts = malloc(sizeof(int64_t) * (size_t)(3 * 65 + W * W));
-  if(!sums || !xyz || !need || !mine || !allneed || !present || !reqmask || !counts)
-    rc = NGRAVS_ERR_NOMEM;
-  /* top-leaf sums of all tasks (DomainMoment[], forcetree.c:766-850), then every coarser level */
+  nleaf = plan->tree.nleaf;
+  memset(&cfg, 0, sizeof(cfg));
+  rc = ngravs_get_config(ctx, &cfg);
   if(!rc)
+    rc = ngravs_get_domain_extent(ctx, dom);
+  cw = NGRAVS_TOP_CW(cfg.n_gravs > 0 ? cfg.n_gravs : 1);
+  need = calloc((size_t)nleaf, 1);
+  allneed = malloc((size_t)nleaf * (size_t)W);
+  present = malloc((size_t)nleaf);
+  reqmask = calloc((size_t)nleaf, sizeof(uint64_t));
+  if(!need || !allneed || !present || !reqmask)
     {
-      info->seconds[2] = -wall_now();
-      rc = ngravs_dd_cell_sums(ctx, L, sums + (size_t)off[L] * cw);
+      free(need);
+      free(allneed);
+      free(present);
+      free(reqmask);
+      return NGRAVS_ERR_NOMEM;   /* the buffers of the next collective itself are missing: this task cannot take part */
     }
+  info->seconds[3] = -wall_now();
   if(!rc)
-    rc = cm->allreduce(cm->user, sums + (size_t)off[L] * cw, ncell * cw, NGRAVS_T_F64, NGRAVS_OP_SUM);
-  if(!rc)
-    {
-      info->seconds[2] += wall_now();
-      info->seconds[3] = -wall_now();
-      rc = ngravs_dd_target_bounds(ctx, bounds);
-    }
-  if(!rc)
-    {
-      for(d = L - 1; d >= 0; d--)
-        for(i = 0; i < (1ll << (3 * d)); i++)
-          for(k = 0; k < 8; k++)
-            for(j = 0; j < cw; j++)
-              sums[(size_t)(off[d] + i) * cw + j] += sums[(size_t)(off[d + 1] + i * 8 + k) * cw + j];
-      for(d = 0; d <= L && !rc; d++)
-        {
-          const int32_t *pht = ph_table(d);
-          const int ncd = 1 << d;
-          if(!pht)
-            {
-              rc = NGRAVS_ERR_NOMEM;
-              break;
-            }
-          for(x = 0; x < ncd; x++)
-            for(y = 0; y < ncd; y++)
-              for(z = 0; z < ncd; z++)
-                xyz[off[d] + pht[((size_t)x * ncd + y) * ncd + z]] = x | (y << 10) | (z << 20);
-        }
-      /* boxes around the own cells that hold particles, one per coarse (<= 4^3) block of the domain grid */
-      {
-        const int csh = L > 2 ? L - 2 : 0;
-        const double cl = dom[6] / nc;
-        const int32_t *phL = ph_table(L);
-        for(k = 0; k < 64; k++)
-          used[k] = 0;
-        for(x = 0; x < nc; x++)
-          for(y = 0; y < nc; y++)
-            for(z = 0; z < nc; z++)
-              {
-                const int64_t cell = phL ? phL[((size_t)x * nc + y) * nc + z] : ngravs_peano_hilbert_key(x, y, z, L);
-                const int cxyz[3] = {x, y, z};
-                if(plan->owner_ph[cell] != me || sums[(size_t)(off[L] + cell) * cw] < 0.5)
-                  continue;
-                k = (((x >> csh) & 3) * 4 + ((y >> csh) & 3)) * 4 + ((z >> csh) & 3);
-                for(j = 0; j < 3; j++)
-                  {
-                    const double lo = dom[j] + cxyz[j] * cl, hi = lo + cl;
-                    if(!used[k] || lo < blo[k][j])
-                      blo[k][j] = lo;
-                    if(!used[k] || hi > bhi[k][j])
-                      bhi[k][j] = hi;
-                  }
-                used[k] = 1;
-              }
-        bc = malloc(sizeof(*bc) * 64);
-        bh = malloc(sizeof(*bh) * 64);
-        T.nbox = 0;
-        for(k = 0; k < 64; k++)
-          if(used[k])
-            {
-              for(j = 0; j < 3; j++)
-                {
-                  bc[T.nbox][j] = 0.5 * (blo[k][j] + bhi[k][j]);
-                  bh[T.nbox][j] = 0.5 * (bhi[k][j] - blo[k][j]) + 1e-9 * dom[6];   /* rounding slack */
-                }
-              T.nbox++;
-            }
-      }
-      T.L = L;
-      T.ng = cfg.n_gravs;
-      T.periodic = cfg.periodic;
-      T.pm = cfg.pmgrid != 0;
-      T.use_theta = cfg.err_tol_theta != 0;
-      T.box = cfg.box_size;
-      T.theta2 = cfg.err_tol_theta * cfg.err_tol_theta;
-      T.aold_min = bounds[0];
-      T.h_min = bounds[1];
-      T.rcut = cfg.rcut;
-      T.reach6 = 6.0 * cfg.asmth;
-      for(j = 0; j < 6; j++)
-        T.fsoft[j] = cfg.force_softening[j];
-      for(j = 0; j < 3; j++)
-        T.corner[j] = dom[j];
-      T.len = dom[6];
-      T.sums = sums;
-      T.off = off;
-      T.xyz = xyz;
-      T.bc = bc;
-      T.bh = bh;
-      T.need = need;
-      /* below a cell whose top leaves are all this task's own (or empty) there is nothing to request */
-      for(i = 0; i < ncell; i++)
-        mine[off[L] + i] = plan->owner_ph[i] == me || sums[(size_t)(off[L] + i) * cw] < 0.5;
-      for(d = L - 1; d >= 0; d--)
-        for(i = 0; i < (1ll << (3 * d)); i++)
-          {
-            uint8_t a = 1;
-            for(k = 0; k < 8; k++)
-              a &= mine[off[d + 1] + i * 8 + k];
-            mine[off[d] + i] = a;
-          }
-      T.mine = mine;
-      if(T.nbox > 0)   /* the root is opened by every target inside it */
-        for(k = 0; k < 8; k++)
-          need_visit(&T, 1, k);
-      for(i = 0; i < ncell; i++)
-        if(plan->owner_ph[i] == me)
-          need[i] = 0;   /* own cells are here already */
-      info->seconds[3] += wall_now();
-      info->seconds[4] = -wall_now();
-      rc = cm->allgather(cm->user, need, allneed, ncell);
-    }
+    rc = ngravs_host_import_request(&cfg, dom, &plan->tree, plan->node_sums, plan->leaf_owner, me, plan->bounds, need);
+  info->seconds[3] += wall_now();
+  info->seconds[4] = -wall_now();
+  if(rc)
+    memset(need, 0, (size_t)nleaf);
+  rc = migrate_and_request(ctx, cm, plan, migrate, rc, need, allneed, info);   /* a failed task reports through its status word */
   if(!rc)
     {
-      /* the owners ship every particle of the requested cells (replaces the export of targets, gravtree.c:195-257) */
+      /* the owners ship every particle of the requested leaves (replaces the export of targets, gravtree.c:195-257); a leaf's
+       * owner holds all its particles now, so everybody knows every count: a requester receives from an owner the global
+       * counts of the leaves it asked that owner for */
       for(r = 0; r < W; r++)
-        for(i = 0; i < ncell; i++)
-          if(allneed[(size_t)r * ncell + i] && plan->owner_ph[i] == me)
-            reqmask[i] |= 1ull << r;
-      mat = counts + 65;
-      sb = mat + W * W;
-      rb = sb + 65;
-      rc = ngravs_dd_pack_cells(ctx, L, reqmask, W, me, counts, &rec, &nrec);
-      if(!rc)
-        rc = cm->allgather(cm->user, counts, mat, (int64_t)sizeof(int64_t) * W);
+        rcn[r] = 0;
+      for(r = 0; r < W; r++)
+        for(i = 0; i < nleaf; i++)
+          if(allneed[(size_t)r * nleaf + i] && plan->leaf_owner[i] != r)
+            {
+              if(plan->leaf_owner[i] == me)
+                reqmask[i] |= 1ull << r;
+              if(r == me)
+                rcn[plan->leaf_owner[i]] += (int64_t)(plan->node_sums[(size_t)plan->tree.node_of_leaf[i] * cw] + 0.5);
+            }
+      rc = ngravs_dd_pack_leaves(ctx, reqmask, W, me, sc, &rec, &nrec);
       if(!rc)
         {
           for(r = 0; r < W; r++)
             {
-              sb[r] = counts[r] * NGRAVS_DD_RECORD_BYTES;
-              rb[r] = mat[(size_t)r * W + me] * NGRAVS_DD_RECORD_BYTES;
-              nrecv += mat[(size_t)r * W + me];
+              nrecv += rcn[r];
+              sc[r] *= NGRAVS_DD_RECORD_BYTES;
+              rcn[r] *= NGRAVS_DD_RECORD_BYTES;
               if(r != me)
-                info->bytes_halo += (double)sb[r];
+                info->bytes_halo += (double)sc[r];
             }
           rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
         }
       info->seconds[4] += wall_now();
       info->seconds[5] = -wall_now();
       if(!rc)
-        rc = exchange(ctx, cm, rec, sb, recvbuf, rb);
+        {
+          rc = exchange(ctx, cm, rec, sc, recvbuf, rcn);
+          info->collectives++;
+        }
       if(!rc)
         rc = ngravs_dd_set_halo(ctx, recvbuf, nrecv);
       info->seconds[5] += wall_now();
@@ -748,9 +1064,9 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
   if(!rc)
     {
       info->seconds[6] = -wall_now();
-      for(i = 0; i < ncell; i++)
-        present[i] = (plan->owner_ph[i] == me || need[i]) ? 1 : 0;
-      rc = ngravs_dd_set_top(ctx, L, sums + (size_t)off[L] * cw, present);
+      for(i = 0; i < nleaf; i++)
+        present[i] = (plan->leaf_owner[i] == me || need[i]) ? 1 : 0;
+      rc = ngravs_dd_set_top(ctx, plan->node_sums, present);
       info->seconds[6] += wall_now();
     }
   if(!rc)
@@ -760,39 +1076,35 @@ int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs
       rc = ngravs_domain_decomposition(ctx);
       info->seconds[7] += wall_now();
     }
-  free(off);
-  free(sums);
-  free(xyz);
   free(need);
-  free(mine);
   free(allneed);
   free(present);
   free(reqmask);
-  free(counts);
-  free(bc);
-  free(bh);
-  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+  return status_of(rc);
 }
 
-int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, int level, double paf, ngravs_dd_info *info)
+int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_plan *plan, ngravs_dd_info *info)
+{
+  return domain_halo(ctx, cm, plan, 0, info);
+}
+
+int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max, double paf, ngravs_dd_info *info)
 {
   ngravs_dd_plan plan;
   ngravs_dd_info local;
   int rc;
   if(!info)
     info = &local;
-  CHECK(ngravs_host_domain_owners(ctx, cm, level, paf, &plan, info));
-  info->seconds[1] = -wall_now();
-  rc = record_exchange(ctx, cm, &plan, 0, info);
-  info->seconds[1] += wall_now();
-  if(!rc)
-    rc = ngravs_host_domain_halo(ctx, cm, &plan, info);
+  CHECK(ngravs_host_domain_owners(ctx, cm, leaf_max, paf, &plan, info));
+  rc = domain_halo(ctx, cm, &plan, 1, info);
   ngravs_host_plan_free(&plan);
-  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+  return status_of(rc);
 }
 
 /* ---- pmforce_periodic on the slab-decomposed mesh -------------------------------------------------------------------------- */
-static __thread double pm_seconds[13];   /* per host thread (host_shim_test runs two tasks as two threads); last call: [0] deposit + bounding boxes, then per stage s: [1+3s] pack, [2+3s] exchange, [3+3s] unpack */
+/* per host thread (host_shim_test runs two tasks as two threads); last call: [0] deposit + bounding boxes, then per stage s:
+ * [1+3s] pack, [2+3s] exchange, [3+3s] unpack */
+static __thread double pm_seconds[13];
 
 void ngravs_host_pm_seconds(double out[13])
 {
@@ -803,14 +1115,14 @@ void ngravs_host_pm_seconds(double out[13])
 
 int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
 {
-  const int W = cm->size;
-  int32_t bb[6], *all;
+  int32_t bb[7], *all;
   int64_t *sc, *rc_;
   void *send = NULL, *recv = NULL;
-  int stage, r, rc;
-  if(!ctx || !cm || W < 1)
+  int stage, r, rc, rcc, W, bad = 0;
+  if(!ctx || !cm || cm->size < 1)
     return NGRAVS_ERR_ARG;
-  all = malloc(sizeof(int32_t) * 6 * (size_t)W);
+  W = cm->size;
+  all = malloc(sizeof(int32_t) * 7 * (size_t)W);
   sc = malloc(sizeof(int64_t) * 2 * (size_t)W);
   if(!all || !sc)
     {
@@ -821,9 +1133,19 @@ int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
   rc_ = sc + W;
   memset(pm_seconds, 0, sizeof(pm_seconds));
   pm_seconds[0] = -wall_now();
+  memset(bb, 0, sizeof(bb));
   rc = ngravs_pm_slab_begin(ctx, cm->rank, W, bb);
-  if(!rc)
-    rc = cm->allgather(cm->user, bb, all, (int64_t)sizeof(bb));   /* meshmin/meshmax lists, pm_periodic.c:285-291 */
+  bb[6] = rc ? 1 : 0;   /* the status travels with the boxes: all tasks stop together */
+  rcc = cm->allgather(cm->user, bb, all, (int64_t)sizeof(bb));   /* meshmin/meshmax lists, pm_periodic.c:285-291 */
+  if(rcc && !rc)
+    rc = rcc;
+  for(r = 0; r < W && !rcc; r++)
+    {
+      bad |= all[7 * r + 6];
+      memmove(all + 6 * r, all + 7 * r, sizeof(int32_t) * 6);
+    }
+  if(!rc && bad)
+    rc = NGRAVS_ERR_STATE;
   pm_seconds[0] += wall_now();
   for(stage = 0; stage < 4 && !rc; stage++)
     {
@@ -846,7 +1168,7 @@ int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *cm)
     }
   free(all);
   free(sc);
-  return rc == 0 ? 0 : (rc < 0 ? rc : NGRAVS_ERR_STATE);
+  return status_of(rc);
 }
 
 /* compute_accelerations(0), gravity part (accel.c:24-58) */
@@ -854,7 +1176,7 @@ int ngravs_host_compute_accelerations(ngravs_ctx *ctx, const ngravs_comm *cm, in
 {
   ngravs_config_t cfg;
   CHECK(ngravs_get_config(ctx, &cfg));
-  CHECK(ngravs_host_domain_decomposition(ctx, cm, 0, 0.0, info));
+  CHECK(ngravs_host_domain_decomposition(ctx, cm, 0.0, 0.0, info));
   if(pm_step && cfg.pmgrid)
     CHECK(ngravs_host_pmforce_periodic(ctx, cm));
   return ngravs_gravity_tree(ctx);

@@ -269,20 +269,20 @@ int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, doubl
 int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *acc);
 
 /* ---- multi-task domain decomposition ------------------------------------------------------------------
- * The role of domain_decompose()/domain_exchangeParticles() (domain.c:164-330, 554-760) and of the
- * target export of gravity_tree() (gravtree.c:112-285).  The Peano curve is cut at the boundaries of
- * level-`level` Peano cells; a task owns a run of cells, holds its own particles plus a halo of copies of
- * every foreign particle within the short-range cut of its cells, and then needs no communication for
- * tree build and walk.  The library packs/unpacks; the HOST performs the collectives (MPI_Allreduce /
- * MPI_Alltoallv in the reference glue, RCCL through torch.distributed in bench.py):
- *   lo,hi   = ngravs_dd_local_extent()        -> all-reduce min/max    -> ngravs_dd_set_extent()
- *   hist    = ngravs_dd_histogram(level)       -> all-reduce sum        -> host cuts the curve: owner maps
- *   records = ngravs_dd_pack(0, ...)           -> all-to-all-v          -> ngravs_dd_apply_migration()
- *   records = ngravs_dd_pack(1, ...)           -> all-to-all-v          -> ngravs_dd_set_halo()
- *   ngravs_domain_decomposition(); ngravs_pm_deposit() -> all-reduce of ngravs_pm_density() -> ngravs_pm_finish();
- *   ngravs_gravity_tree();  results: the first ngravs_dd_num_local() rows of ngravs_get_accel(), ids from ngravs_dd_get_ids().
- * Records are 56 bytes (NGRAVS_DD_RECORD_BYTES): x,y,z,mass,old_acc,grav_cost (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64.
- * ngravs_host.h holds this sequence as plain C over a communicator vtable (MPI in the reference glue, RCCL in bench.py). */
+ * The role of domain_decompose()/domain_exchangeParticles() (domain.c:164-330, 554-760) and of the target export of
+ * gravity_tree() (gravtree.c:112-285).  The Peano curve is cut at the leaves of an adaptive TOP TREE in key space (the
+ * reference's TopNodes[], domain.c:933-1138: a cell is split while it holds more than a threshold of particles); a task owns a
+ * run of leaves, holds its own particles plus copies of the particles of every foreign leaf one of its targets may open, and
+ * then needs no communication for tree build and walk.  The library packs/unpacks; the HOST performs the collectives (RCCL /
+ * MPI behind the vtable of ngravs_host.h, where this sequence lives as plain C):
+ *   lo,hi   = ngravs_dd_local_extent()                 -> all-reduce min/max -> ngravs_dd_set_extent()
+ *   ngravs_dd_set_toptree(child[])  the current top tree (every task the same)
+ *   sums    = ngravs_dd_leaf_sums()                    -> all-reduce sum (device or host) -> host adapts the tree, cuts the curve
+ *   records = ngravs_dd_pack(0, leaf_owner, ...)       -> all-to-all-v          -> ngravs_dd_apply_migration()
+ *   records = ngravs_dd_pack_leaves(reqmask, ...)      -> all-to-all-v          -> ngravs_dd_set_halo()
+ *   ngravs_dd_set_top(node sums, present leaves); ngravs_domain_decomposition(); slab PM (below); ngravs_gravity_tree();
+ *   results: ngravs_get_accel() (own rows), ids from ngravs_dd_get_ids().
+ * Records are 56 bytes (NGRAVS_DD_RECORD_BYTES): x,y,z,mass,old_acc,grav_cost (f64), meta (i64: type | active<<8 | id<<16).  world_size <= 64. */
 #define NGRAVS_DD_RECORD_BYTES 56
 #define NGRAVS_DD_MAX_RECORD_BYTES 80
 /* bytes per record of ngravs_dd_pack(what, ...): what = 0 (migration) of a TreePM run appends P[].GravPM[3] (the particle's
@@ -292,43 +292,46 @@ int64_t ngravs_dd_record_bytes(ngravs_ctx *ctx, int what);
 int64_t ngravs_dd_num_local(ngravs_ctx *ctx);
 int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);             /* domain.c:894-905 */
 int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */
-/* 8^level particle counts and work sums sum(1 + GravCost) (domain_sumCost, domain.c:823-877; work may be NULL), Peano-cell order, host arrays */
-int ngravs_dd_histogram(ngravs_ctx *ctx, int level, int64_t *hist, double *work);
 /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac as set by ngravs_dd_set_extent (before the local Peano order exists) */
 int ngravs_get_domain_extent(ngravs_ctx *ctx, double out[8]);
-int ngravs_dd_pack(ngravs_ctx *ctx, int what, int level, const int32_t *owner_ph, const int32_t *owner_xyz, int nranks,
-                   int my_rank, int64_t *counts, void **dev_records, int64_t *nrec);
-/* ---- the global top of the tree: top-leaf moments and tree-node import (force_exchange_pseudodata / force_treeupdate_pseudos,
- * forcetree.c:766-996; replaces the target export / partial-force import of gravtree.c:112-285) ---------------------------------
- * The Peano cells of one level play the role of the reference's top leaves.  Every task contributes the sums of its own
- * particles per cell (ngravs_dd_cell_sums: count, particles per type [6], per species mass and mass-weighted position:
- * NGRAVS_TOP_CW(n_gravs) doubles per cell, Peano-cell order); the host all-reduces the table, decides which foreign cells the
- * task's targets may have to open (ngravs_host.c: the walk's own opening tests against the task's domain), the owners ship ALL
- * particles of the requested cells (ngravs_dd_pack_cells: reqmask[cell] bit r = task r asked for it), and
- * ngravs_dd_set_top() hands the global table over: the next tree build forces the topology of the levels above from the
- * global counts -- it is the single-task tree's -- gives the top nodes global monopoles, and turns every cell of that level
- * whose particles are elsewhere into a pseudo node.  Forces are then independent of the number of tasks (domain.c:18-21). */
+/* The top tree as its child table: child[t] = index of the first of the 8 consecutive children (key order) of node t, or -1 for a
+ * leaf; node 0 = the root.  The library numbers the leaves in depth-first (= curve) order.  It keeps the table between steps
+ * (ngravs_dd_get_toptree: *child points into the context, valid until the next set; nnode 0: none yet). */
+int ngravs_dd_set_toptree(ngravs_ctx *ctx, int32_t nnode, const int32_t *child);
+int ngravs_dd_get_toptree(ngravs_ctx *ctx, int32_t *nnode, const int32_t **child);
+/* Per top LEAF, curve order, NGRAVS_TOP_CW(n_gravs) doubles: [0] the work sum(1 + GravCost) (domain_sumCost, domain.c:859-862),
+ * [1..6] particles per type, then per species mass and mass-weighted position (the local part of DomainMoment[],
+ * forcetree.c:766-850) -- of the own particles.  DEVICE buffer owned by the library (valid until the next call);
+ * *count = nleaf * NGRAVS_TOP_CW doubles.  The host all-reduces it (in place on the device if it can) and reads it back. */
 #define NGRAVS_TOP_CW(ng) (7 + 4 * (ng))
-int ngravs_dd_cell_sums(ngravs_ctx *ctx, int level, double *cells);
+int ngravs_dd_leaf_sums(ngravs_ctx *ctx, void **dev_sums, int64_t *count);
 /* min over the own active particles of ErrTolForceAcc * OldAcc and of the softening length: out[2] */
 int ngravs_dd_target_bounds(ngravs_ctx *ctx, double out[2]);
-int ngravs_dd_pack_cells(ngravs_ctx *ctx, int level, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts,
-                         void **dev_records, int64_t *nrec);
-/* gcells: the all-reduced table; present[cell] != 0: the cell's particles are on this task (own or imported).  level 0: off. */
-int ngravs_dd_set_top(ngravs_ctx *ctx, int level, const double *gcells, const uint8_t *present);
+/* what = 0: the records of the own particles whose leaf belongs to another task (leaf_owner[leaf], host array), grouped by
+ * destination; counts[r] records go to task r */
+int ngravs_dd_pack(ngravs_ctx *ctx, int what, const int32_t *leaf_owner, int nranks, int my_rank, int64_t *counts, void **dev_records,
+                   int64_t *nrec);
 /* destination task of every local particle under the owner map (its own rank if it stays), host array of ngravs_dd_num_local() ints */
-int ngravs_dd_get_dest(ngravs_ctx *ctx, int level, const int32_t *owner_ph, int32_t *dest);
+int ngravs_dd_get_dest(ngravs_ctx *ctx, const int32_t *leaf_owner, int32_t *dest);
+/* ---- the global top of the tree: top-leaf moments and tree-node import (force_exchange_pseudodata / force_treeupdate_pseudos,
+ * forcetree.c:766-996; replaces the target export / partial-force import of gravtree.c:112-285) ---------------------------------
+ * The host decides which foreign leaves the task's targets may have to open (ngravs_host_import_request: the walk's own opening
+ * tests against the task's domain), the owners ship ALL particles of the requested leaves (ngravs_dd_pack_leaves: reqmask[leaf]
+ * bit r = task r asked for it), and ngravs_dd_set_top() hands the global sums of every top node over: the next tree build
+ * forces the topology of the top tree from the global counts -- it is the single-task tree's --, gives the top nodes global
+ * monopoles, and turns every leaf whose particles are elsewhere into a pseudo node.  Forces are then independent of the
+ * number of tasks (domain.c:18-21). */
+int ngravs_dd_pack_leaves(ngravs_ctx *ctx, const uint64_t *reqmask, int nranks, int my_rank, int64_t *counts, void **dev_records,
+                          int64_t *nrec);
+/* node_sums: NGRAVS_TOP_CW doubles per top NODE ([0] = global particle count); present[leaf] != 0: the leaf's particles are on
+ * this task (own or imported).  NULL, NULL: single-task trees again. */
+int ngravs_dd_set_top(ngravs_ctx *ctx, const double *node_sums, const uint8_t *present);
 /* a library-owned device buffer for nrec incoming records (valid until the next ngravs_dd_recv_buffer call) */
 int ngravs_dd_recv_buffer(ngravs_ctx *ctx, int64_t nrec, void **dev_records);
 int ngravs_dd_apply_migration(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
 int ngravs_dd_set_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
 int ngravs_dd_set_ids(ngravs_ctx *ctx, const int64_t *ids, int on_device);
 int ngravs_dd_get_ids(ngravs_ctx *ctx, int64_t *ids, int on_device);
-/* pmforce_periodic() in two halves around an all-reduce of the whole density mesh: the simple (replicated-mesh) variant */
-int ngravs_pm_deposit(ngravs_ctx *ctx);
-int ngravs_pm_density(ngravs_ctx *ctx, void **dev, int64_t *count);
-int ngravs_pm_finish(ngravs_ctx *ctx);
-
 /* ---- pmforce_periodic() for many tasks: x-slab decomposed mesh -----------------------------------------------------------
  * The reference's scheme (pm_periodic.c:74-123 slab tables; :336-427 density patches -> slab owners; :433,:525 distributed
  * FFT in transposed order; :436-520 Green's function on the transposed layout; :529-670 potential bricks with ghost planes

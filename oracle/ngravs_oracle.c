@@ -782,8 +782,19 @@ void orc_tree_drift(orc_tree *t, const ngravs_config_t *cfg, const double *newpo
  * ------------------------------------------------------------------------------------------ */
 #define NEAREST(x) (((x) > boxhalf) ? ((x)-boxsize) : (((x) < -boxhalf) ? ((x) + boxsize) : (x)))
 
+/* `reach` (may be NULL; test instrumentation, not part of the reference): reach[p] = the smallest side of a tree node through
+ * which particle p contributed to this target -- 0 for a particle-particle interaction, len for every particle below a node
+ * that was used as a monopole.  It tells which parts of the tree a task must hold for the walk of its targets. */
+static void reach_mark_subtree(const orc_tree *t, int64_t a, double len, double *reach);
+static int walk_one_r(const orc_tree *t, const ngravs_config_t *cfg, int64_t target, double aold_in,
+                      const double *table, double acc[3], double *reach);
 static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t target, double aold_in,
                     const double *table, double acc[3])
+{
+  return walk_one_r(t, cfg, target, aold_in, table, acc, NULL);
+}
+static int walk_one_r(const orc_tree *t, const ngravs_config_t *cfg, int64_t target, double aold_in,
+                      const double *table, double acc[3], double *reach)
 {
   const int ng = t->ng, pm = cfg->pmgrid != 0, periodic = cfg->periodic != 0;
   const double boxsize = cfg->box_size, boxhalf = 0.5 * cfg->box_size;
@@ -828,6 +839,8 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
           h = cfg->force_softening[ptype];
           if(h < cfg->force_softening[t->type[no]])
             h = cfg->force_softening[t->type[no]];
+          if(reach)
+            reach[no] = 0.0;
           no = t->pnext[no];
         }
       else
@@ -919,6 +932,8 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
                   continue;
                 }
             }
+          if(reach)
+            reach_mark_subtree(t, a, len, reach);
           no = t->sibling[a];
         }
       /* interaction(s): forcetree.c:1534-1585 / :1953-2032 */
@@ -961,6 +976,41 @@ static int walk_one(const orc_tree *t, const ngravs_config_t *cfg, int64_t targe
   acc[1] = ay;
   acc[2] = az;
   return nint;
+}
+
+/* every particle below node a, along the thread of the tree (nextnode descends, pnext / sibling move on) */
+static void reach_mark_subtree(const orc_tree *t, int64_t a, double len, double *reach)
+{
+  const int end = t->sibling[a];
+  int q = t->nextnode[a];
+  while(q != end && q >= 0)
+    {
+      if(q < t->maxpart)
+        {
+          if(len < reach[q])
+            reach[q] = len;
+          q = t->pnext[q];
+        }
+      else
+        q = t->nextnode[q - t->maxpart];
+    }
+}
+
+/* test instrumentation: the walks of targets idx[0..nt), serially; reach[n] must come in filled with a large value */
+int orc_walk_reach(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,
+                   const double *table, double *reach)
+{
+  if(cfg->pmgrid && !table)
+    return -1;
+  if(!idx)
+    nt = t->n;
+  for(int64_t k = 0; k < nt; k++)
+    {
+      int64_t i = idx ? idx[k] : k;
+      double a[3];
+      walk_one_r(t, cfg, i, old_acc ? old_acc[i] : 0.0, table, a, reach);
+    }
+  return 0;
 }
 
 int orc_walk(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,

@@ -49,6 +49,10 @@ void orc_tree_get_node(const orc_tree *t, int64_t i, double *out, int32_t *bitfl
  * table = shortrange_fourier_force[tg][sg][NTAB] when cfg->pmgrid != 0. */
 int orc_walk(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt,
              const double *old_acc, const double *table, double *acc, int32_t *nint, int nthreads);
+/* test instrumentation (not a reference function): reach[p] = min(reach[p], smallest side of a node through which particle p
+ * entered the walk of one of the targets; 0 = particle-particle) -- what a task must hold to walk these targets */
+int orc_walk_reach(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,
+                   const double *table, double *reach);
 /* gravtree.c:318-341: old_acc_out = |acc + pm/G|, acc *= G */
 void orc_finish(const ngravs_config_t *cfg, int64_t n, double *acc, const double *pm, double *old_acc_out);
 

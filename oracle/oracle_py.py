@@ -127,6 +127,19 @@ class Tree:
             raise RuntimeError("orc_walk failed: %d" % rc)
         return acc, nint
 
+    def walk_reach(self, idx, old_acc=None, table=None, cfg=None):
+        """test instrumentation: per particle, the smallest node side through which it entered the walk of one of the targets
+        idx (0: particle-particle interaction, inf: not reached except through larger nodes)"""
+        cfg = cfg if cfg is not None else self.cfg
+        idx_a = _i32(idx)
+        reach = np.full(self.n, np.inf)
+        oa = _f64(old_acc) if old_acc is not None else None
+        tb = _f64(table) if table is not None else None
+        rc = lib().orc_walk_reach(self.h, C.byref(cfg), _p(idx_a), C.c_int64(len(idx_a)), _p(oa), _p(tb), _p(reach))
+        if rc != 0:
+            raise RuntimeError("orc_walk_reach failed: %d" % rc)
+        return reach
+
     def close(self):
         if self.h:
             lib().orc_tree_free(self.h)

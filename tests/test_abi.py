@@ -22,14 +22,14 @@ def test_exports_the_c_host_layer(pkg, have_lib):
 
 
 def test_host_split_balances_work_within_the_memory_bound(pkg, have_lib):
-    """ngravs_host_split = domain_findSplit (by count, under max_load) + domain_shiftSplit (by work), reference
-    domain.c:347-544: contiguous runs of cells, every task gets cells, the work maximum never exceeds the count-only cut's,
-    and a clustered work distribution is balanced far better than by count."""
+    """ngravs_host_split does the job of domain_findSplit + domain_shiftSplit (reference domain.c:347-544): contiguous runs of
+    top leaves, every task gets leaves, the particle count of a task stays below max_load, and under that bound the largest work
+    sum is as small as a contiguous cut allows (bottleneck-optimal: checked against the lower bounds)."""
     import numpy as np
     rng = np.random.default_rng(3)
     ncell, ntask = 4096, 8
-    count = rng.integers(50, 150, ncell).astype(np.int64)
-    work = count.astype(np.float64)
+    count = rng.integers(50, 150, ncell).astype(np.float64)
+    work = count.copy()
     work[1000:1200] *= 40.0                         # a clump: few particles more, many interactions more
     owner_c = np.zeros(ncell, dtype=np.int32)
     owner_w = np.zeros(ncell, dtype=np.int32)
@@ -45,8 +45,93 @@ def test_host_split_balances_work_within_the_memory_bound(pkg, have_lib):
     cc = np.bincount(owner_c, weights=count)
     assert cc.max() / cc.mean() < 1.02                                                      # count cut: balanced by count
     assert ww.max() <= wc.max() and ww.max() / ww.mean() < 0.75 * wc.max() / wc.mean()       # work cut: better by work
+    # the bottleneck cannot be lowered by moving one boundary leaf: the cut is optimal under the bound
+    for t in range(ntask - 1):
+        first_next = np.searchsorted(owner_w, t + 1)
+        give, take = work[first_next - 1], work[first_next]
+        assert max(ww[t] - give, ww[t + 1] + give) >= ww.max() - 1e-9 or np.bincount(owner_w, weights=count)[t + 1] + count[first_next - 1] > maxload \
+            or ww[t] < ww.max() - 1e-9
+        assert max(ww[t] + take, ww[t + 1] - take) >= min(ww.max(), max(ww[t], ww[t + 1])) - 1e-9 or \
+            np.bincount(owner_w, weights=count)[t] + count[first_next] > maxload
     # an impossible memory bound is reported, not silently violated
     assert have_lib.ngravs_host_split(count.ctypes.data, None, ncell, ntask, 0.5 * count.sum() / ntask, owner_c.ctypes.data) == -1
+
+
+def _tree_struct():
+    class TopTree(C.Structure):
+        _fields_ = [("nnode", C.c_int32), ("nleaf", C.c_int32), ("depth", C.c_int32), ("reserved", C.c_int32),
+                    ("child", C.POINTER(C.c_int32)), ("level", C.POINTER(C.c_int32)), ("xyz", C.POINTER(C.c_int32)),
+                    ("leaf", C.POINTER(C.c_int32)), ("node_of_leaf", C.POINTER(C.c_int32))]
+    return TopTree
+
+
+def leaf_counts(tree, key21):
+    """particles per top leaf (curve order) from 63-bit Peano keys: the leaves are consecutive key ranges"""
+    import numpy as np
+    nn = tree.nnode
+    child = np.ctypeslib.as_array(tree.child, (nn,))
+    level = np.ctypeslib.as_array(tree.level, (nn,))
+    leaf = np.ctypeslib.as_array(tree.leaf, (nn,))
+    # start key of every node: descend
+    start = np.zeros(nn, dtype=np.int64)
+    for i in range(nn):
+        if child[i] >= 0:
+            for k in range(8):
+                start[child[i] + k] = int(start[i]) + (k << (3 * (21 - int(level[i]) - 1)))
+    nodes = np.flatnonzero(leaf >= 0)
+    nodes = nodes[np.argsort(leaf[nodes])]
+    lo = start[nodes]
+    hi = lo.astype(np.uint64) + (np.uint64(1) << (3 * (21 - level[nodes])).astype(np.uint64))    # 2^63 for the root's end
+    ks = np.sort(key21).astype(np.uint64)
+    return (np.searchsorted(ks, hi) - np.searchsorted(ks, lo.astype(np.uint64))).astype(np.float64)
+
+
+def build_toptree(lib, key21, thresh, start_level=1, max_level=18):
+    """the top tree of a particle set by rounds of ngravs_host_toptree_adapt, as ngravs_host_domain_owners does with all-reduced
+    counts"""
+    TopTree = _tree_struct()
+    t = TopTree()
+    assert lib.ngravs_host_toptree_init(C.byref(t), start_level) == 0
+    rounds = 0
+    while True:
+        cnt = leaf_counts(t, key21)
+        assert cnt.sum() == len(key21)
+        nxt = TopTree()
+        unknown = lib.ngravs_host_toptree_adapt(C.byref(t), cnt.ctypes.data, float(thresh), max_level, C.byref(nxt))
+        assert unknown >= 0
+        rounds += 1
+        if unknown == 0 and nxt.nnode == t.nnode:
+            lib.ngravs_host_toptree_free(C.byref(nxt))
+            return t, cnt, rounds
+        lib.ngravs_host_toptree_free(C.byref(t))
+        t = nxt
+        assert rounds < 40
+
+
+def test_top_tree_is_the_references_on_its_own_ic(pkg, have_lib, O, kats):
+    """domain_determineTopTree on GalaxyCollision.IC with one task: 176 top leaves (recorded from the reference, SURVEY.md 8(c);
+    the oracle's restatement reproduces it).  The product's rule -- rounds of ngravs_host_toptree_adapt on leaf counts, from any
+    starting tree -- must arrive at the same tree: same number of nodes and leaves, every leaf within the threshold, every split
+    node above it."""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(pkg.__file__), "..", "tests"))
+    from conftest import galaxy_ic
+    ic = galaxy_ic(pkg)
+    pos = ic["pos"]
+    dom = O.domain_extent(pos)
+    key18 = O.keys(pos, dom)
+    ntop, nleaves = O.toptree_count(key18)
+    assert nleaves == kats["galaxy_collision"]["ntopleaves"] == 176
+    thresh = len(pos) / 20.0                                   # TotNumPart / (TOPNODEFACTOR * NTask), NTask = 1
+    key21 = key18.astype(np.int64) << 9                        # the engine's 21-bit keys: the reference's 18-bit keys are their prefix
+    for start in (1, 3, 5):                                    # from a coarser and from a finer tree than the answer
+        t, cnt, rounds = build_toptree(have_lib, key21, thresh, start_level=start)
+        child = np.ctypeslib.as_array(t.child, (t.nnode,))
+        assert t.nleaf == nleaves and t.nnode == ntop, (start, t.nleaf, t.nnode, ntop, nleaves)
+        assert cnt.max() <= thresh and (child >= 0).sum() * 8 + 1 == t.nnode
+        print("start level %d: %d rounds -> %d nodes, %d leaves, largest leaf %d particles" % (start, rounds, t.nnode, t.nleaf, cnt.max()))
+        have_lib.ngravs_host_toptree_free(C.byref(t))
 
 
 def test_struct_sizes_match_header(pkg, have_lib):

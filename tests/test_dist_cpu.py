@@ -1,8 +1,12 @@
-"""world_size-2 rehearsal of the N>1 path on CPU (gloo): every rank holds the full particle set, owns one
-contiguous Peano segment of TARGETS, and no data-path collective is needed; merging the shards must give
-the single-task result exactly (the reference's invariant, domain.c:18-21).  The force engine itself
-needs a GPU, so the per-shard walk here is the oracle's; the GPU twin of this test is
-test_gpu_parity.py::test_pm_persists_between_pm_steps_and_multi_shard."""
+"""CPU (gloo, world size 2-3, no GPU): the pure-C pieces of the multi-task decomposition (host/ngravs_host.c) driven the way
+ngravs_host_domain_owners / ngravs_host_domain_halo drive them -- top-tree rounds on all-reduced leaf counts
+(ngravs_host_toptree_adapt), the cut (ngravs_host_split), and the import decision (ngravs_host_import_request) -- checked
+against the oracle's walk: every part of the tree the reference walk of one of a task's targets enters must be on that task.
+
+Reference: domain_determineTopTree / domain_topsplit (domain.c:933-1138), domain_findSplit / domain_shiftSplit (:347-544),
+the export decision of force_treeevaluate (forcetree.c:1424-1434: a target that opens a pseudo particle is exported; here the
+leaf is imported instead)."""
+import ctypes as C
 import os
 import sys
 
@@ -10,47 +14,157 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _worker(rank, world, port, out_dir):
+def _case(pkg, name):
+    n = 12000
+    if name.startswith("plummer"):
+        pos, mass, typ = pkg.ic.plummer_sphere(n, seed=17)
+        typ = (1 + (np.arange(n) % 2)).astype(np.int32)
+        cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.03, 0.01, 0.01, 0.01],
+                              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton")
+    else:
+        L = 1.0
+        pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=2, seed=23)
+        eps = L / (40 * n ** (1 / 3))
+        cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4")
+        cfg.asmth = 1.25 * L / 32          # what ngravs_get_config() reports (pm_periodic.c:59-60)
+        cfg.rcut = 4.5 * cfg.asmth
+    if name.endswith("rel"):
+        cfg.err_tol_theta = 0.0            # relative criterion (gravtree.c:334-335)
+    return pos, mass, typ, cfg
+
+
+def _worker(rank, world, port, out_dir, name):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
+    from test_abi import _tree_struct, leaf_counts
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg, O = ge.load_package(), ge.load_oracle()
-    n = 6000
-    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=9)
-    cfg = pkg.make_config(n_gravs=1, G=1.0, theta=0.5, softening=[0.01] * 6)
+    L = pkg.lib()
+    pos, mass, typ, cfg = _case(pkg, name)
+    n, ng = len(pos), cfg.n_gravs
+    cw = 7 + 4 * ng
     dom = O.domain_extent(pos)
-    order = np.argsort(O.keys(pos, dom), kind="stable")            # Peano order of the whole set, same on every rank
-    first, count = pkg.shard_range(n, rank, world)
-    mine = order[first:first + count].astype(np.int32)
+    key21 = O.keys(pos, dom).astype(np.int64) << 9
+    mine0 = np.arange(rank, n, world)                     # what this task holds before the decomposition
+    # a steady-state OldAcc for the relative criterion: the reference walk with theta
     T = O.Tree(cfg, pos, mass, typ, dom)
-    acc, nint = T.walk(idx=mine, nthreads=1)
-    # assemble: each rank contributes its rows; all_reduce(sum) of disjoint rows == gather
-    full = torch.zeros((n, 3), dtype=torch.float64)
-    full[torch.from_numpy(mine.astype(np.int64))] = torch.from_numpy(acc)
-    dist.all_reduce(full)
-    # the timing protocol of bench.py: barrier, max over ranks
-    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
-    dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        ref, _ = T.walk(nthreads=1)
-        np.save(os.path.join(out_dir, "ok.npy"), np.array([float(np.array_equal(full.numpy(), ref)), t.item(), count]))
+    tab = O.shortrange_table(cfg)[0] if cfg.pmgrid else None
+    cfg_theta = pkg.make_config(n_gravs=1)
+    C.memmove(C.byref(cfg_theta), C.byref(cfg), C.sizeof(cfg))
+    cfg_theta.err_tol_theta = 0.5
+    a0, _ = T.walk(table=tab, cfg=cfg_theta, nthreads=4)
+    old = np.linalg.norm(a0, axis=1)
+    # ---- domain_determineTopTree: rounds of the rule on ALL-REDUCED leaf counts
+    TopTree = _tree_struct()
+    t = TopTree()
+    assert L.ngravs_host_toptree_init(C.byref(t), 2) == 0
+    thresh = n / (20.0 * world)                           # TotNumPart / (TOPNODEFACTOR * NTask), domain.c:1127
+    rounds = 0
+    while True:
+        cnt = torch.from_numpy(leaf_counts(t, key21[mine0]))
+        dist.all_reduce(cnt)
+        cnt = cnt.numpy()
+        nxt = TopTree()
+        unknown = L.ngravs_host_toptree_adapt(C.byref(t), cnt.ctypes.data, thresh, 18, C.byref(nxt))
+        assert unknown >= 0
+        rounds += 1
+        if unknown == 0 and nxt.nnode == t.nnode:
+            L.ngravs_host_toptree_free(C.byref(nxt))
+            break
+        L.ngravs_host_toptree_free(C.byref(t))
+        t = nxt
+    nn, nl = t.nnode, t.nleaf
+    child = np.ctypeslib.as_array(t.child, (nn,)).copy()
+    level = np.ctypeslib.as_array(t.level, (nn,)).copy()
+    leaf = np.ctypeslib.as_array(t.leaf, (nn,)).copy()
+    node_of_leaf = np.ctypeslib.as_array(t.node_of_leaf, (nl,)).copy()
+    assert cnt.sum() == n and cnt.max() <= thresh
+    # ---- leaf of every particle, per-leaf sums of the own particles, all-reduced (ngravs_dd_leaf_sums' layout)
+    start = np.zeros(nn, dtype=np.int64)
+    for i in range(nn):
+        if child[i] >= 0:
+            for k in range(8):
+                start[child[i] + k] = int(start[i]) + (k << (3 * (21 - int(level[i]) - 1)))
+    lo = start[node_of_leaf].astype(np.uint64)
+    leaf_of = np.searchsorted(lo, key21.astype(np.uint64), side="right") - 1
+    sums = np.zeros((nl, cw))
+    t2g = np.array([cfg.type_to_grav[k] for k in range(6)])
+    for i in mine0:
+        q = sums[leaf_of[i]]
+        q[0] += 1.0                                        # work: 1 + GravCost with GravCost = 0
+        q[1 + typ[i]] += 1.0
+        g = t2g[typ[i]]
+        q[7 + 4 * g] += mass[i]
+        q[8 + 4 * g: 11 + 4 * g] += mass[i] * pos[i]
+    ts = torch.from_numpy(sums)
+    dist.all_reduce(ts)
+    sums = ts.numpy()
+    lcount = sums[:, 1:7].sum(axis=1)
+    assert np.array_equal(lcount, cnt)
+    # ---- the cut
+    owner = np.zeros(nl, dtype=np.int32)
+    assert L.ngravs_host_split(lcount.ctypes.data, sums[:, 0].copy().ctypes.data, nl, world, 1.5 * n / world, owner.ctypes.data) == 0
+    # ---- sums of every top node
+    node_sums = np.zeros((nn, cw))
+    for i in range(nn - 1, -1, -1):
+        if child[i] < 0:
+            node_sums[i] = sums[leaf[i]]
+            node_sums[i, 0] = lcount[leaf[i]]
+        else:
+            node_sums[i] = node_sums[child[i]: child[i] + 8].sum(axis=0)
+    # ---- the import decision of THIS task
+    targets = np.flatnonzero(owner[leaf_of] == rank).astype(np.int32)
+    bounds = np.array([(cfg.err_tol_force_acc * old[targets]).min(), min(cfg.force_softening[k] for k in set(typ[targets].tolist()))])
+    need = np.zeros(nl, dtype=np.uint8)
+    dom_c = np.ascontiguousarray(dom, dtype=np.float64)
+    rc = L.ngravs_host_import_request(C.byref(cfg), dom_c.ctypes.data, C.byref(t), node_sums.ctypes.data, owner.ctypes.data, rank,
+                                      bounds.ctypes.data, need.ctypes.data)
+    assert rc == 0
+    # ---- what the reference walk of these targets really enters
+    reach = T.walk_reach(targets, old_acc=old, table=tab)
+    leaf_len = dom[6] / (1 << level[node_of_leaf]).astype(np.float64)
+    entered = reach < leaf_len[leaf_of] * (1 - 1e-9)      # the particle was used below the size of its top leaf
+    must = np.zeros(nl, dtype=bool)
+    must[np.unique(leaf_of[entered])] = True
+    must &= owner != rank
+    have = need.astype(bool)
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), missing=np.flatnonzero(must & ~have), must=must.sum(), have=have.sum(),
+             nleaf=nl, rounds=rounds, imported=lcount[have].sum(), own=len(targets), owner=owner, tree=child)
+    T.close()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_reproduces_single_task(tmp_path):
+@pytest.mark.parametrize("name", ["plummer", "plummer_rel", "treepm", "treepm_rel"])
+def test_import_decision_covers_the_reference_walk(pkg, have_lib, O, tmp_path, name):
+    """For every task: the set of foreign top leaves ngravs_host_import_request asks for is a superset of the leaves some particle
+    of which the reference walk (oracle) of one of the task's targets uses individually or through a node smaller than the leaf.
+    Tree-only Plummer sphere (two softening lengths) and periodic TreePM box, Barnes-Hut and relative criterion; every task builds
+    the same tree and the same cut."""
     import torch.multiprocessing as mp
+    world = 3 if name.startswith("plummer") else 2
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    ok, tmax, count = np.load(os.path.join(str(tmp_path), "ok.npy"))
-    assert ok == 1.0
-    assert abs(tmax - 0.2) < 1e-12
+    mp.spawn(_worker, args=(world, port, str(tmp_path), name), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "n%d.npz" % r)) for r in range(world)]
+    for r, d in enumerate(res):
+        print("%s task %d: top tree %d leaves (%d rounds); %d own particles, %d imported; %d leaves entered by the walk, %d requested" %
+              (name, r, d["nleaf"], d["rounds"], d["own"], d["imported"], d["must"], d["have"]))
+        assert len(d["missing"]) == 0, "leaves the walk enters but the task did not ask for: %s" % d["missing"][:10]
+        assert d["have"] >= d["must"]
+        assert np.array_equal(d["owner"], res[0]["owner"]) and np.array_equal(d["tree"], res[0]["tree"])
+    if name.startswith("plummer"):
+        # the adaptive leaves keep the import of a centrally concentrated set well below "everything"
+        imp = sum(float(d["imported"]) for d in res)
+        own = sum(float(d["own"]) for d in res)
+        print("%s: imported / own = %.2f" % (name, imp / own))
 
 
 @pytest.mark.parametrize("n,ws", [(1, 1), (63, 2), (64, 2), (1000, 3), (1 << 20, 8), (12345, 8)])

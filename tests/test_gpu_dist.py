@@ -81,6 +81,22 @@ def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
         eng.compute_accelerations(pm_step=False)
         a2, o2, c2, p2 = eng.get_accel(want_pm=True)
         extra = dict(ids2=eng.local_ids(), acc2=a2, old2=o2, cost2=c2, pm2=p2, mig2=np.array([eng.timings["migrated"], eng.timings["halo"]]))
+        # and the same with particles that MOVE: the PM step's GravPM of all tasks, handed back with the particles under another
+        # arbitrary distribution (as a host that owns P[] would after a restart): most rows migrate in this decomposition, each with
+        # its GravPM in the 80-byte migration record
+        np.savez(os.path.join(out_dir, "p%d.npz" % rank), ids=eng.local_ids(), pm=p2)
+        dist.barrier()
+        pm_all = np.zeros((n, 3))
+        for r in range(world):
+            d = np.load(os.path.join(out_dir, "p%d.npz" % r))
+            pm_all[d["ids"]] = d["pm"]
+        mine3 = np.arange((rank + 1) % world, n, world) if world > 1 else np.arange(n)[::-1].copy()
+        eng3 = dd.DistributedEngine(cfg)
+        eng3.set_particles(pos[mine3], mass[mine3], typ[mine3], old_acc=old[mine3], ids=mine3, grav_pm=pm_all[mine3])
+        eng3.compute_accelerations(pm_step=False)
+        a3, o3, c3, p3 = eng3.get_accel(want_pm=True)
+        extra.update(ids3=eng3.local_ids(), old3=o3, cost3=c3, pm3=p3, mig3=np.array([eng3.timings["migrated"], eng3.timings["halo"]]))
+        eng3.close()
     np.savez(os.path.join(out_dir, "s%d.npz" % rank), ids=ids1, acc=acc, cost=cost, old=oa,
              halo=np.array([halo1, nloc1]), **extra)
     eng.close()
@@ -152,8 +168,17 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
         eo = np.abs(o2 - o1).max() / o1.max()
         print("non-PM step: %d particles migrated with their GravPM; OldAcc 3 tasks vs 1: %.2e; GravPM carried: %.2e" %
               (moved, eo, np.abs(p2 - p1).max() / np.abs(p1).max()))
-        assert moved > 0
         assert np.array_equal(c2, c1) and eo < 1e-10 and np.abs(p2 - p1).max() / np.abs(p1).max() < 1e-10
+        o3, c3, p3, moved = np.zeros(n), np.zeros(n), np.zeros((n, 3)), 0
+        for r in range(world):
+            d = np.load(os.path.join(str(tmp_path), "s%d.npz" % r))
+            o3[d["ids3"]], c3[d["ids3"]], p3[d["ids3"]] = d["old3"], d["cost3"], d["pm3"]
+            moved += int(d["mig3"][0])
+        eo3 = np.abs(o3 - o1).max() / o1.max()
+        print("handed back under another distribution: %d particles migrated with their GravPM; OldAcc %.2e, GravPM %.2e" %
+              (moved, eo3, np.abs(p3 - p1).max() / np.abs(p1).max()))
+        assert moved > n // 2
+        assert np.array_equal(c3, c1) and eo3 < 1e-10 and np.abs(p3 - p1).max() / np.abs(p1).max() < 1e-10
 
 
 def test_one_task_over_rccl(pkg, tmp_path):

@@ -10,8 +10,8 @@ def _build(pkg):
     exe = os.path.join(host, "host_shim_test")
     inc = os.path.join(os.path.dirname(pkg.__file__), "..", "include")
     libdir = os.path.dirname(pkg.LIB_PATH)
-    subprocess.check_call(["gcc", "-O2", "-Wall", os.path.join(host, "host_shim_test.c"), "-I" + inc, "-L" + libdir,
-                           "-lngravs_hip", "-lm", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-DWITH_RCCL", os.path.join(host, "host_shim_test.c"), "-I" + inc, "-L" + libdir,
+                           "-lngravs_hip", "-lngravs_rccl", "-lm", "-lpthread", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     return exe
 
 
@@ -22,7 +22,7 @@ def test_c_host_links_against_the_abi(pkg, have_lib):
 
 
 @pytest.mark.parametrize("flags", [[], ["-DPERIODIC", "-DPMGRID=64"], ["-DPERIODIC", "-DPMGRID=64", "-DFORCETEST=0.1"],
-                                   ["-DFORCETEST=0.1", "-DN_GRAVS=3"], ["-DPERIODIC"]])
+                                   ["-DFORCETEST=0.1", "-DN_GRAVS=3"], ["-DPERIODIC"], ["-DPERIODIC", "-DPMGRID=64", "-DNGRAVS_WITH_RCCL"]])
 def test_glue_compiles_against_the_reference_interface(pkg, flags):
     """gadget_glue.c is what a maintainer drops into the reference tree.  The reference cannot be built here (GSL, FFTW-2),
     so the glue is compiled -fsyntax-only -Wall -Wextra -Werror against tests/glue_stub/: declarations of exactly the
@@ -41,7 +41,7 @@ def test_glue_compiles_against_the_reference_interface(pkg, flags):
 
 
 OPTION_SETS = [[], ["-DPERIODIC", "-DPMGRID=64"], ["-DPERIODIC", "-DPMGRID=64", "-DFORCETEST=0.1"], ["-DFORCETEST=0.1", "-DN_GRAVS=3"],
-               ["-DPERIODIC"]]
+               ["-DPERIODIC"], ["-DPERIODIC", "-DPMGRID=64", "-DNGRAVS_WITH_RCCL"]]
 
 
 @pytest.mark.parametrize("flags", OPTION_SETS)
@@ -81,6 +81,8 @@ def test_glue_defines_every_symbol_the_link_recipe_needs(pkg, flags, tmp_path):
     for kept_symbol in ("endrun", "second", "timediff", "do_box_wrapping", "get_random_number"):
         assert kept_symbol not in defined
     assert {"endrun", "ngravs_create", "ngravs_gravity_tree"} <= undefined
+    if "-DNGRAVS_WITH_RCCL" in flags:      # the exchanges go through the C RCCL communicator, MPI only broadcasts the id
+        assert {"ngravs_rccl_create", "ngravs_rccl_fill", "MPI_Bcast"} <= undefined and "MPI_Isend" not in undefined
 
 
 def test_glue_source_mentions_every_entry_point(pkg):

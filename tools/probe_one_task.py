@@ -50,9 +50,12 @@ def main():
         pm_s += np.array(eng.pm_seconds())
     st = eng.stats()
     w = eng.wall
-    names = ["extent+histogram+split", "migration", "top_cell_sums", "need_test_host", "requests+pack", "import_exchange+unpack",
-             "global_top", "local_decomposition"]
-    out = {"particles": n, "pmgrid": pmgrid, "backend": "nccl, world size 1",
+    names = bench.DD_STAGES
+    calls, secs, byt = eng.comm.stats() if hasattr(eng.comm, "stats") else (w["collective_calls"], 0.0, 0.0)
+    out = {"particles": n, "pmgrid": pmgrid, "backend": "%s, world size %d" % (eng.backend, eng.comm.world_reported),
+           "top_tree": {"nodes": int(eng.info.n_topnodes), "leaves": int(eng.info.n_topleaves), "counting_rounds": int(eng.info.toptree_rounds)},
+           "decomposition_collectives_last_step": int(eng.info.collectives),
+           "communicator_totals": {"calls": calls, "seconds_inside": secs, "bytes": byt, "mean_latency_ms": 1e3 * secs / max(1, calls)},
            "wall_ms_per_step": {k[:-2]: 1e3 * v / steps for k, v in w.items() if k.endswith("_s")},
            "collective_calls_per_step": w["collective_calls"] / steps,
            "decomposition_stage_ms": {k: 1e3 * v / steps for k, v in zip(names, dd_s)},
