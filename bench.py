@@ -417,6 +417,17 @@ def main():
                          "algorithmic_bytes_per_launch": alg, "avg_launch_ms": k_ms},
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_provenance"] = walk_traffic(args, n, world, split["launches_per_step"] if split else 1)
+        if args.walk == "group" and split:
+            # the kernel's own bound: fp64 VALU issue.  Every evaluated pair costs the force loop's common path (static count
+            # from the ISA of this build's profile, profiles/r02_eval_isa_mix.txt: 49 VALU + 3 extra issue slots for the
+            # quarter-rate v_rsq_f64), one wave-instruction issues in 4 cycles on a SIMD for 64 lanes, 4 SIMDs per CU
+            pairs = st.interactions / max(1, split["launches_per_step"])
+            slots, clock_hz, simds = 52, 2.4e9, 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            floor_ms = pairs * slots * 4.0 / 64.0 / (simds * clock_hz) * 1e3
+            out["roofline"]["secondary"] = {"bound": "fp64 VALU issue", "floor_ms": floor_ms, "achieved_ms": k_ms, "frac": floor_ms / k_ms,
+                                            "issue_slots_per_pair": slots, "pairs_per_launch": pairs, "simds": simds, "clock_ghz": clock_hz / 1e9,
+                                            "note": "perfectly packed lanes, nothing but the force loop; the kernel also fetches, culls and "
+                                                    "masks its lists and idles ~31 % of its force-loop slots (DESIGN.md 5)"}
         if domain:
             # rank 0's host wall clock per step: the three stages of compute_accelerations() and the part of each spent inside
             # collectives (waiting for the slowest task included); payloads of the last step

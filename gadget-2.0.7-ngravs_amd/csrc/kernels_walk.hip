@@ -9,8 +9,8 @@
 //  k_walk_strict : the reference semantics per target.  The wave walks the tree depth-first in
 //      lock-step (control flow is wave-uniform: node indices live in SGPRs, node records are
 //      scalar loads); every lane takes its OWN prune / open / accept decision exactly as the
-//      reference does, and a lane that has used or pruned a node sleeps until the walk leaves
-//      that node's particle range (`resume_at`).  Interaction set, interaction count and
+//      reference does, and a lane that has used or pruned a node sleeps until the walk has left
+//      that node's subtree (`lane_skip`: a stack depth).  Interaction set, interaction count and
 //      summation order per target equal the reference's (children are visited in Peano instead
 //      of Morton order, which only reorders the fp64 sum).
 //
@@ -275,7 +275,12 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
     }
   double ax = 0, ay = 0, az = 0;
   int nint = 0;
-  int resume_at = valid ? 0 : 0x7fffffff;
+  // The wave walks the tree in lock-step; a lane that has dealt with a node (used it, or pruned it) while another lane wants it
+  // opened sits out until the walk has left that node's subtree: lane_skip = the stack depth of the node, the lane takes part only
+  // while sp < lane_skip.  (Depth, not particle ranges: the pseudo nodes of a multi-task tree have EMPTY ranges, which a test on
+  // particle indices cannot tell from "behind the subtree".)
+  const int NO_SKIP = 0x7fffffff;
+  int lane_skip = valid ? NO_SKIP : -1;
   int *sn = st_node[wave], *ss = st_slot[wave];
   int sp = -1;
 
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
   auto do_particle = [&](int p) {
     double4 q = s_pm[p];          // uniform address -> scalar load
     int qt = s_type[p];
-    if(p >= resume_at)
+    if(lane_skip > sp)
       {
         int sg = wp.t2g[qt];
         double dx = q.x - px, dy = q.y - py, dz = q.z - pz;
@@ -334,14 +339,15 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 
   // returns true if some lane wants the node opened
   auto visit = [&](int c) -> bool {
-    int first = tv.first[c], cnt = tv.count[c], fl = tv.flags[c];
+    int fl = tv.flags[c];
     double4 geo = tv.geo[c];
     double4 mom[NG];
 #pragma unroll
     for(int g = 0; g < NG; g++)
       mom[g] = tv.mom[(long long)c * NG + g];
     bool open = false;
-    if(first >= resume_at)
+    const bool takes_part = lane_skip > sp;
+    if(takes_part)
       {
         double dx[NG], dy[NG], dz[NG], r2[NG];
         double r2min = INFINITY, r2max = -INFINITY, summass = 0;
@@ -421,10 +427,11 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
                   }
               }
           }
-        if(!open)
-          resume_at = first + cnt;
       }
-    return __any(open ? 1 : 0) != 0;
+    const bool wave_open = __any(open ? 1 : 0) != 0;
+    if(wave_open && takes_part && !open)
+      lane_skip = sp + 1;   // the node goes onto the stack at depth sp + 1: this lane is done with everything below it
+    return wave_open;
   };
 
   // lock-step depth-first driver, shared by the force walk and the lattice-correction walk
@@ -447,6 +454,8 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
             if(slot >= cnt)
               {
                 sp--;
+                if(lane_skip > sp && lane_skip >= 0)
+                  lane_skip = NO_SKIP;
                 continue;
               }
             ss[sp] = slot + 1;
@@ -456,6 +465,8 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
         if(slot >= 8)
           {
             sp--;
+            if(lane_skip > sp && lane_skip >= 0)
+              lane_skip = NO_SKIP;   // the walk has left the subtree this lane sat out
             continue;
           }
         ss[sp] = slot + 1;
@@ -482,11 +493,11 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
       // force_treeevaluate_lattice_correction (forcetree.c:2077-2455): its own walk -- a node the opening criterion
       // rejects may still be used if it is small (<= 0.2 box) and does not straddle the half-box seam
       const double *lat = table;   // [tg][sg][3][E1^3]
-      resume_at = valid ? 0 : 0x7fffffff;
+      lane_skip = valid ? NO_SKIP : -1;
       auto lat_particle = [&](int p) {
         double4 q = s_pm[p];
         int qt = s_type[p];
-        if(p >= resume_at)
+        if(lane_skip > sp)
           {
             int sg = wp.t2g[qt];
             double dx = nearest(q.x - px, wp.box, wp.boxhalf), dy = nearest(q.y - py, wp.box, wp.boxhalf),
@@ -500,14 +511,14 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
           }
       };
       auto lat_visit = [&](int c) -> bool {
-        int first = tv.first[c], cnt = tv.count[c];
         double4 geo = tv.geo[c];
         double4 mom[NG];
 #pragma unroll
         for(int g = 0; g < NG; g++)
           mom[g] = tv.mom[(long long)c * NG + g];
         bool open = false;
-        if(first >= resume_at)
+        const bool takes_part = lane_skip > sp;
+        if(takes_part)
           {
             double dx[NG], dy[NG], dz[NG];
             double r2min = INFINITY, summass = 0;
@@ -554,10 +565,12 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
                       az += mom[g].w * fz;
                     }
                 nint++;
-                resume_at = first + cnt;
               }
           }
-        return __any(open ? 1 : 0) != 0;
+        const bool wave_open = __any(open ? 1 : 0) != 0;
+        if(wave_open && takes_part && !open)
+          lane_skip = sp + 1;
+        return wave_open;
       };
       dfs(lat_visit, lat_particle);
     }
