@@ -228,6 +228,9 @@ def main():
                          "moments + import of the top-tree cells a task may open, x-slab decomposed PM with four plane exchanges "
                          "(DESIGN.md 7); 'replicated' = every rank holds all particles and only the walk is sharded (no data-path "
                          "collective; default for the tree-only configs)")
+    ap.add_argument("--leaf-max", type=float, default=0.0,
+                    help="N>1: split top-tree nodes above this many particles (0: TotNumPart/(20 NTask), at most NGRAVS_TOPLEAF_MAX = 3000); "
+                         "smaller leaves = finer import granularity, larger per-leaf tables")
     ap.add_argument("--config", default="c4", choices=["c1", "c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c4 (default, the metric's) | c5: 256M N_GRAVS=3 PMGRID=1024 | c3: 16M N_GRAVS=1 PMGRID=256 | "
                          "c2: 4M Plummer tree-only | c1: the reference's own GalaxyCollision.IC (60k particles, N_GRAVS=2, tree-only)")
@@ -313,7 +316,7 @@ def main():
     if domain:
         import importlib
         dd = importlib.import_module("ngravs_amd.distributed")
-        eng = dd.DistributedEngine(cfg)
+        eng = dd.DistributedEngine(cfg, leaf_max=args.leaf_max or None, comm=os.environ.get("NGRAVS_BENCH_COMM") or None)
         sel = torch.arange(rank, n, world, device=dev)          # arbitrary initial ownership; the first step migrates
         l_pos, l_mass, l_type = d_pos[sel].contiguous(), d_mass[sel].contiguous(), d_type[sel].contiguous()
         eng.set_particles_device(int(sel.numel()), l_pos.data_ptr(), l_mass.data_ptr(), l_type.data_ptr())

@@ -32,7 +32,7 @@ EXPORTS = [
     "ngravs_force_treebuild", "ngravs_gravity_tree",
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
-    "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum",
+    "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum", "ngravs_direct_sum_targets",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
     "ngravs_dd_get_toptree", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
     "ngravs_dd_pack_leaves", "ngravs_dd_set_top", "ngravs_dd_recv_buffer", "ngravs_dd_apply_migration", "ngravs_dd_set_halo",
@@ -99,6 +99,7 @@ def lib():
         L.ngravs_peano_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_int, C.c_void_p]
         L.ngravs_shortrange_table.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_direct_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.ngravs_direct_sum_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.ngravs_dd_local_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_dd_set_extent.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_get_config.argtypes = [C.c_void_p, C.c_void_p]
@@ -352,6 +353,16 @@ class Engine:
         out = np.zeros(len(pos), dtype=np.int64)
         self._check(lib().ngravs_peano_keys(self._h, pos.ctypes.data, len(pos), corner.ctypes.data, float(fac), bits,
                                             out.ctypes.data), "ngravs_peano_keys")
+        return out
+
+    def direct_sum_targets(self, pos, ptype, mass=None):
+        """partial direct sums of explicit targets over this task's OWN particles (distributed gravity_forcetest): add over tasks"""
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        ptype = np.ascontiguousarray(ptype, dtype=np.int32)
+        mass = np.ascontiguousarray(mass, dtype=np.float64) if mass is not None else None
+        out = np.zeros((len(pos), 3))
+        self._check(lib().ngravs_direct_sum_targets(self._h, pos.ctypes.data, _ptr(mass), ptype.ctypes.data, len(pos), out.ctypes.data),
+                    "ngravs_direct_sum_targets")
         return out
 
     def direct_sum(self, idx):

@@ -1125,6 +1125,42 @@ extern "C" int ngravs_direct_sum(ngravs_ctx *c, const int32_t *idx, int64_t nt, 
   return rc;
 }
 
+extern "C" int ngravs_direct_sum_targets(ngravs_ctx *c, const double *pos, const double *mass, const int32_t *type, int64_t nt, double *acc)
+{
+  if(!c || !c->have_order || !pos || !type || !acc || nt <= 0)
+    return NGRAVS_ERR_STATE;
+  for(int64_t k = 0; k < nt; k++)
+    if(type[k] < 0 || type[k] >= NGRAVS_NTYPES)
+      return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  DevBuf<double4> dt;
+  DevBuf<int> dty;
+  DevBuf<double> dacc;
+  if(dt.ensure(nt) || dty.ensure(nt) || dacc.ensure(3 * nt))
+    return NGRAVS_ERR_NOMEM;
+  std::vector<double4> h((size_t)nt);
+  for(int64_t k = 0; k < nt; k++)
+    {
+      h[k].x = pos[3 * k];
+      h[k].y = pos[3 * k + 1];
+      h[k].z = pos[3 * k + 2];
+      h[k].w = mass ? mass[k] : 1.0;
+    }
+  int rc = NGRAVS_OK;
+  if(hipMemcpyAsync(dt.p, h.data(), sizeof(double4) * nt, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+     hipMemcpyAsync(dty.p, type, sizeof(int) * nt, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  if(!rc)
+    rc = direct_run_targets(c, dt.p, dty.p, nt, dacc.p);
+  if(!rc && hipMemcpyAsync(acc, dacc.p, sizeof(double) * 3 * nt, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+    rc = NGRAVS_ERR_NO_DEVICE;
+  (void)hipStreamSynchronize(c->stream);
+  dt.release();
+  dty.release();
+  dacc.release();
+  return rc;
+}
+
 // ---- multi-task domain decomposition (host-driven collectives; see kernels_domain.hip) -------------------------------
 extern "C" int64_t ngravs_dd_num_local(ngravs_ctx *c) { return c ? c->n_local : NGRAVS_ERR_ARG; }
 
@@ -1220,11 +1256,9 @@ extern "C" int ngravs_dd_set_top(ngravs_ctx *c, const double *node_sums, const u
 {
   if(!c)
     return NGRAVS_ERR_ARG;
-  if(node_sums && c->cfg.periodic && !c->cfg.pmgrid)
-    {
-      ngravs_report(c, NGRAVS_ERR_ARG, "multi-task periodic tree-only runs (lattice correction walk) are not supported");
-      return NGRAVS_ERR_ARG;
-    }
+  // (periodic tree-only runs: the lattice-correction walk, forcetree.c:2077-2455, opens a node only if the force walk's criterion
+  // opens it AND the node is large or straddles the half-box seam -- a subset of what the force walk opens, so the leaves the
+  // import decision brings in for the force walk serve it too)
   (void)hipSetDevice(c->cfg.device);
   return dd_set_top(c, node_sums, present);
 }

@@ -290,6 +290,7 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp);
 int walk_run(ngravs_ctx *c);
 int walk_finish(ngravs_ctx *c);
 int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc);
+int direct_run_targets(ngravs_ctx *c, const double4 *d_tpm, const int *d_ttype, int64_t nt, double *d_acc);
 // ---- kernels_pm.hip
 int pm_run(ngravs_ctx *c);
 int pm_deposit(ngravs_ctx *c);

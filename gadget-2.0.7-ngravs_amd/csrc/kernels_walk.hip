@@ -1954,20 +1954,38 @@ __global__ void k_finish(long long t_first, long long t_count, const unsigned ch
 //  direct summation for a list of targets (forcetree.c:3428-3548, no Ewald term)
 // =============================================================================================
 #pragma clang fp contract(off)
+// targets: particles tidx[k] of the working set, or (tidx == nullptr) explicit records t_pm[k] / t_type[k] -- a test particle of
+// ANOTHER task in the distributed gravity_forcetest(); own_only: the imported copies (active bit 1) are not sources, each task
+// contributes its own particles and the host adds the partial sums up
 __global__ __launch_bounds__(256) void k_direct(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
                                                  long long n, const int *__restrict__ tidx, long long nt, WalkParams wp,
-                                                 LawIds li, double G, const double *__restrict__ lat, double *__restrict__ acc)
+                                                 LawIds li, double G, const double *__restrict__ lat, double *__restrict__ acc,
+                                                 const double4 *__restrict__ t_pm = nullptr, const int *__restrict__ t_type = nullptr,
+                                                 const unsigned char *__restrict__ s_active = nullptr, int own_only = 0)
 {
   // one block per target, threads stride over sources, fp64 block reduction
   long long k = blockIdx.x;
   if(k >= nt)
     return;
-  int t = tidx[k];
-  double4 p = s_pm[t];
-  int ptype = s_type[t], tg = wp.t2g[ptype];
+  double4 p;
+  int ptype;
+  if(tidx)
+    {
+      const int t = tidx[k];
+      p = s_pm[t];
+      ptype = s_type[t];
+    }
+  else
+    {
+      p = t_pm[k];
+      ptype = t_type[k];
+    }
+  const int tg = wp.t2g[ptype];
   double ax = 0, ay = 0, az = 0;
   for(long long i = threadIdx.x; i < n; i += blockDim.x)
     {
+      if(own_only && (s_active[i] & 2))
+        continue;
       double4 q = s_pm[i];
       int qt = s_type[i], sg = wp.t2g[qt];
       double h = wp.fsoft[qt] > wp.fsoft[ptype] ? wp.fsoft[qt] : wp.fsoft[ptype];
@@ -2645,6 +2663,26 @@ int walk_finish(ngravs_ctx *c)
   hipLaunchKernelGGL(k_finish, dim3(nb), dim3(bs), 0, c->stream, (long long)c->shard_first, (long long)c->shard_count,
                      c->s_active.p, c->r_acc.p, c->r_pm.p, c->r_oldacc.p, c->cfg.G, (c->have_pm && c->cfg.pmgrid) ? 1 : 0,
                      c->r_nint.p, c->red_tmp.p);
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+// direct sum for explicit target records over the OWN particles of this task (distributed gravity_forcetest)
+int direct_run_targets(ngravs_ctx *c, const double4 *d_tpm, const int *d_ttype, int64_t nt, double *d_acc)
+{
+  WalkParams wp;
+  make_walk_params(c, &wp);
+  LawIds li;
+  make_law_ids(c, &li);
+  const bool latt = c->cfg.periodic != 0;
+  if(latt)
+    {
+      int rcl = ensure_lattice(c);
+      if(rcl)
+        return rcl;
+    }
+  hipLaunchKernelGGL(k_direct, dim3((unsigned)nt), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, (long long)c->n, (const int *)nullptr,
+                     (long long)nt, wp, li, c->cfg.G, latt ? c->lat.p : (const double *)nullptr, d_acc, d_tpm, d_ttype, c->s_active.p, 1);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }

@@ -237,13 +237,6 @@ static void ensure_ctx(void)
   Comm.alltoallv = mpi_alltoallv;
   Comm.allreduce_dev = NULL;
 #endif
-#if defined(PERIODIC) && !defined(PMGRID)
-  if(NTask > 1)
-    {
-      printf("ngravs-hip: periodic tree-only runs (lattice-correction walk, forcetree.c:2077-2455) run on one task only\n");
-      endrun(1054);
-    }
-#endif
   if(NTask > 1 && All.TotN_gas > 0)
     {
       printf("ngravs-hip: gas particles (SphP[]) are not migrated by this glue\n");
@@ -576,53 +569,116 @@ void pmforce_periodic(void)
 
 #ifdef FORCETEST
 /* proto.h:113 -- gravtree_forcetest.c:28-356: direct sums for a random FORCETEST fraction of the active particles, one line
- * per tested particle in forcetest.txt.  Single task (the direct sum runs over the library's working set). */
+ * per tested particle in forcetest.txt.  One task: ngravs_direct_sum() over the library's particles.  Several tasks
+ * (gravtree_forcetest.c:100-260 exports the test particles to every task and imports the partial sums): the test particles of
+ * all tasks are all-gathered, every task sums over the particles it OWNS (ngravs_direct_sum_targets), and the partial sums
+ * are added up; the tasks append their lines to the file one after the other (:283-315). */
 void gravity_forcetest(void)
 {
-  int i, k, nt = 0, *idx;
-  double *acc;
+  int i, k, nt = 0, *idx, nthis;
+  double *acc = NULL;
   char buf[200];
 #ifdef PMGRID
   if(All.PM_Ti_endstep != All.Ti_Current)
     return;
 #endif
-  if(NTask > 1)
-    return;
   idx = malloc(sizeof(int) * (NumPart > 0 ? NumPart : 1));
   for(i = 0; i < NumPart; i++)
     if(P[i].Ti_endstep == All.Ti_Current && get_random_number(P[i].ID) < FORCETEST)	/* :54-63 */
       idx[nt++] = i;
-  if(nt > 0)
+  if(NTask == 1)
     {
-      acc = malloc(sizeof(double) * 3 * nt);
-      must(ngravs_direct_sum(Ctx, idx, nt, acc), 1068);
-      for(k = 0; k < nt; k++)
-	for(i = 0; i < 3; i++)
-	  P[idx[k]].GravAccelDirect[i] = acc[3 * k + i];
-      free(acc);
-      sprintf(buf, "%s%s", All.OutputDir, "forcetest.txt");
-      if(!(FdForceTest = fopen(buf, "a")))
+      if(nt > 0)
 	{
-	  printf("error in opening file '%s'\n", buf);
-	  endrun(17);
+	  acc = malloc(sizeof(double) * 3 * nt);
+	  must(ngravs_direct_sum(Ctx, idx, nt, acc), 1068);
+	}
+    }
+  else
+    {
+      int *cnt = malloc(sizeof(int) * 4 * NTask), *off = cnt + NTask, *cnt3 = off + NTask, *off3 = cnt3 + NTask, tot = 0;
+      double *mypos = malloc(sizeof(double) * 4 * (nt > 0 ? nt : 1)), *allpos, *allacc;
+      int *mytype = malloc(sizeof(int) * (nt > 0 ? nt : 1)), *alltype;
+      MPI_Allgather(&nt, 1, MPI_INT, cnt, 1, MPI_INT, MPI_COMM_WORLD);
+      for(i = 0; i < NTask; i++)
+	{
+	  off[i] = tot;
+	  off3[i] = 4 * tot;
+	  cnt3[i] = 4 * cnt[i];
+	  tot += cnt[i];
 	}
       for(k = 0; k < nt; k++)
 	{
-	  i = idx[k];
+	  for(i = 0; i < 3; i++)
+	    mypos[4 * k + i] = P[idx[k]].Pos[i];
+	  mypos[4 * k + 3] = P[idx[k]].Mass;
+	  mytype[k] = P[idx[k]].Type;
+	}
+      allpos = malloc(sizeof(double) * 4 * (tot > 0 ? tot : 1));
+      alltype = malloc(sizeof(int) * (tot > 0 ? tot : 1));
+      allacc = malloc(sizeof(double) * 3 * (tot > 0 ? tot : 1));
+      MPI_Allgatherv(mypos, 4 * nt, MPI_DOUBLE, allpos, cnt3, off3, MPI_DOUBLE, MPI_COMM_WORLD);
+      MPI_Allgatherv(mytype, nt, MPI_INT, alltype, cnt, off, MPI_INT, MPI_COMM_WORLD);
+      if(tot > 0)
+	{
+	  double *p3 = malloc(sizeof(double) * 3 * tot), *m1 = malloc(sizeof(double) * tot);
+	  for(k = 0; k < tot; k++)
+	    {
+	      for(i = 0; i < 3; i++)
+		p3[3 * k + i] = allpos[4 * k + i];
+	      m1[k] = allpos[4 * k + 3];
+	    }
+	  must(ngravs_direct_sum_targets(Ctx, p3, m1, alltype, tot, allacc), 1068);
+	  MPI_Allreduce(MPI_IN_PLACE, allacc, 3 * tot, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
+	  free(p3);
+	  free(m1);
+	}
+      if(nt > 0)
+	{
+	  acc = malloc(sizeof(double) * 3 * nt);
+	  memcpy(acc, allacc + 3 * off[ThisTask], sizeof(double) * 3 * nt);
+	}
+      free(cnt);
+      free(mypos);
+      free(mytype);
+      free(allpos);
+      free(alltype);
+      free(allacc);
+    }
+  for(k = 0; k < nt; k++)
+    for(i = 0; i < 3; i++)
+      P[idx[k]].GravAccelDirect[i] = acc[3 * k + i];
+  free(acc);
+  for(nthis = 0; nthis < NTask; nthis++)
+    {
+      if(nthis == ThisTask && nt > 0)
+	{
+	  sprintf(buf, "%s%s", All.OutputDir, "forcetest.txt");
+	  if(!(FdForceTest = fopen(buf, "a")))
+	    {
+	      printf("error in opening file '%s'\n", buf);
+	      endrun(17);
+	    }
+	  for(k = 0; k < nt; k++)
+	    {
+	      i = idx[k];
 #ifndef PMGRID
-	  fprintf(FdForceTest, "%d %g %g %g %g %g %g %g %g %g %g %g %d\n", P[i].Type, All.Time,
-		  All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2], P[i].GravAccelDirect[0],
-		  P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0], P[i].GravAccel[1], P[i].GravAccel[2],
-		  (int)P[i].ID);	/* :297-303 */
+	      fprintf(FdForceTest, "%d %g %g %g %g %g %g %g %g %g %g %g %d\n", P[i].Type, All.Time,
+		      All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2], P[i].GravAccelDirect[0],
+		      P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0], P[i].GravAccel[1], P[i].GravAccel[2],
+		      (int)P[i].ID);	/* :297-303 */
 #else
-	  fprintf(FdForceTest, "%d %f %f %f %f %f %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %d\n", P[i].Type,
-		  All.Time, All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2],
-		  P[i].GravAccelDirect[0], P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0],
-		  P[i].GravAccel[1], P[i].GravAccel[2], P[i].GravPM[0] + P[i].GravAccel[0], P[i].GravPM[1] + P[i].GravAccel[1],
-		  P[i].GravPM[2] + P[i].GravAccel[2], (int)P[i].ID);	/* :305-311 */
+	      fprintf(FdForceTest, "%d %f %f %f %f %f %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e %d\n", P[i].Type,
+		      All.Time, All.Time - TimeOfLastTreeConstruction, P[i].Pos[0], P[i].Pos[1], P[i].Pos[2],
+		      P[i].GravAccelDirect[0], P[i].GravAccelDirect[1], P[i].GravAccelDirect[2], P[i].GravAccel[0],
+		      P[i].GravAccel[1], P[i].GravAccel[2], P[i].GravPM[0] + P[i].GravAccel[0], P[i].GravPM[1] + P[i].GravAccel[1],
+		      P[i].GravPM[2] + P[i].GravAccel[2], (int)P[i].ID);	/* :305-311 */
 #endif
+	    }
+	  fclose(FdForceTest);
 	}
-      fclose(FdForceTest);
+      if(NTask > 1)
+	MPI_Barrier(MPI_COMM_WORLD);
     }
   free(idx);
 }

@@ -267,6 +267,11 @@ int ngravs_shortrange_table(const ngravs_config_t *cfg, double *force_out, doubl
  * sum plus lattice_corr (Ewald / lattice-sum tables, forcetree.c:3515-3529, 3803-3885), i.e. the truth
  * gravity_forcetest() compares the tree / TreePM force against; result xG into acc[3*nt]. */
 int ngravs_direct_sum(ngravs_ctx *ctx, const int32_t *idx, int64_t nt, double *acc);
+/* The same truth with several tasks (gravity_forcetest's export of the test particles, gravtree_forcetest.c:100-260): the direct
+ * sum for nt EXPLICIT targets (position, mass -- only the BAM laws read it, may be NULL --, type; host arrays) over the particles
+ * this task OWNS (not its imported copies).  Every task calls it with the test particles of ALL tasks and the host adds the
+ * partial sums up (MPI_Allreduce / ncclAllReduce).  xG, lattice correction included when PERIODIC. */
+int ngravs_direct_sum_targets(ngravs_ctx *ctx, const double *pos, const double *mass, const int32_t *type, int64_t nt, double *acc);
 
 /* ---- multi-task domain decomposition ------------------------------------------------------------------
  * The role of domain_decompose()/domain_exchangeParticles() (domain.c:164-330, 554-760) and of the target export of

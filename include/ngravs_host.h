@@ -99,7 +99,7 @@ typedef struct ngravs_dd_plan
  * part_alloc_factor: the memory bound of the cut, particles per task <= part_alloc_factor * N/NTask (All.PartAllocFactor;
  * <= 0 => 1.5).  info may be NULL.
  * The library migrates its device-resident particle columns itself.  This is the whole domain_Decomposition(). */
-#define NGRAVS_TOPLEAF_MAX 4096.0
+#define NGRAVS_TOPLEAF_MAX 3000.0   /* not a power of two: uniform boxes of 2^k particles put 8^-level of them into a cell */
 #define NGRAVS_TOPLEVEL_MAX 18   /* BITS_PER_DIMENSION: the reference's keys resolve no finer cell (domain.c:1004) */
 #define NGRAVS_TOPNODES_MAX 2400000   /* MAXTOPNODES is 200000 in the reference (allvars.h:70); here the table is cheap */
 int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *comm, double leaf_max, double part_alloc_factor,

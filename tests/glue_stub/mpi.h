@@ -15,6 +15,8 @@ typedef struct { int s; } MPI_Status;
 #define MPI_MIN 2
 #define MPI_MAX 3
 int MPI_Allreduce(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm);
+int MPI_Barrier(MPI_Comm);
+int MPI_Allgatherv(const void *, int, MPI_Datatype, void *, const int *, const int *, MPI_Datatype, MPI_Comm);
 int MPI_Bcast(void *, int, MPI_Datatype, int, MPI_Comm);
 int MPI_Allgather(const void *, int, MPI_Datatype, void *, int, MPI_Datatype, MPI_Comm);
 int MPI_Alltoall(const void *, int, MPI_Datatype, void *, int, MPI_Datatype, MPI_Comm);

@@ -68,19 +68,30 @@ def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
     pos, mass, typ, old, cfg = _strict_case(pkg, case)
     n = len(pos)
     mine = np.arange(rank, n, world)
-    eng = dd.DistributedEngine(cfg)
+    eng = dd.DistributedEngine(cfg, leaf_max=LEAF_MAX.get(case))
     eng.set_particles(pos[mine], mass[mine], typ[mine], old_acc=old[mine], ids=mine)
     eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
     acc, oa, cost = eng.get_accel()[:3]
     ids1, halo1, nloc1 = eng.local_ids(), eng.timings["halo"], eng.num_local()
     extra = {}
+    # distributed gravity_forcetest (gravtree_forcetest.c:100-260): test particles of all tasks, every task sums over the particles
+    # it owns, the partial sums are added up
+    import torch
+    tid = [None] * world
+    dist.all_gather_object(tid, [int(v) for v in ids1[:12]])
+    tid = np.array(sum(tid, []), dtype=np.int64)
+    part = torch.from_numpy(eng.direct_sum_targets(pos[tid], typ[tid], mass[tid]))
+    if backend == "nccl":
+        part = part.cuda()
+    dist.all_reduce(part)
+    extra["direct_ids"], extra["direct"] = tid, part.cpu().numpy()
     if cfg.pmgrid:
         # a step WITHOUT the PM force: GravPM of the PM step must still enter OldAcc (gravtree.c:318-330) although the cut moves
         # (now weighted by the first step's GravCost: particles migrate, and their GravPM with them) and although the working
         # set holds imported rows
         eng.compute_accelerations(pm_step=False)
         a2, o2, c2, p2 = eng.get_accel(want_pm=True)
-        extra = dict(ids2=eng.local_ids(), acc2=a2, old2=o2, cost2=c2, pm2=p2, mig2=np.array([eng.timings["migrated"], eng.timings["halo"]]))
+        extra.update(ids2=eng.local_ids(), acc2=a2, old2=o2, cost2=c2, pm2=p2, mig2=np.array([eng.timings["migrated"], eng.timings["halo"]]))
         # and the same with particles that MOVE: the PM step's GravPM of all tasks, handed back with the particles under another
         # arbitrary distribution (as a host that owns P[] would after a restart): most rows migrate in this decomposition, each with
         # its GravPM in the 80-byte migration record
@@ -103,6 +114,11 @@ def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
     dist.destroy_process_group()
 
 
+# top-tree thresholds of the test cases (None: the reference's TotNumPart / (20 NTask)); small ones so that tasks really lack
+# parts of the tree at these particle numbers
+LEAF_MAX = {"plummer": 100.0, "periodic": 60.0}
+
+
 def _strict_case(pkg, case):
     if case == "plummer":          # tree-only, non-periodic, Barnes-Hut criterion, two species with different softening
         n = 24000
@@ -110,6 +126,14 @@ def _strict_case(pkg, case):
         typ = (1 + (np.arange(n) % 2)).astype(np.int32)
         cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.02, 0.01, 0.01, 0.01],
                               type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton", walk_mode=pkg.WALK_STRICT)
+        return pos, mass, typ, np.zeros(n), cfg
+    if case == "periodic":         # periodic tree-only: nearest-image tree force + the lattice-correction walk (forcetree.c:2077-2455)
+        n, L = 16000, 1.0
+        pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=2, seed=77)
+        pos[: n // 4] = (0.35 + 0.3 * pos[: n // 4]) % L          # a denser region: leaves of several levels
+        eps = L / (40 * n ** (1 / 3))
+        cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=0, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
         return pos, mass, typ, np.zeros(n), cfg
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     from make_ewald_golden import N, L, SEED, case_config
@@ -120,13 +144,13 @@ def _strict_case(pkg, case):
     return pos, mass, typ, gold["old_acc"], cfg
 
 
-@pytest.mark.parametrize("case", ["plummer", "c4"])
+@pytest.mark.parametrize("case", ["plummer", "c4", "periodic"])
 def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
     """The reference's invariant (domain.c:18-21): the tree force does not depend on the number of tasks.  With the global top
     of the tree (top-leaf moments of all tasks) and the imported top cells every task's tree IS the single-task tree wherever
     its targets look, so the reference walk (WALK_STRICT) on 3 tasks must give the single-task forces to summation-order
     noise -- identical interaction counts, max |da|/|a| < 1e-10 -- for a tree-only run (no finite cut: no halo could do it)
-    and for TreePM."""
+    for TreePM, and for a periodic tree-only run (the force walk and the lattice-correction walk on the same tree)."""
     import torch.multiprocessing as mp
     world = 3
     port = 29700 + (os.getpid() % 2000)
@@ -151,6 +175,16 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
           (case, err.max(), np.array_equal(cost, c1), c1.mean()))
     assert np.array_equal(cost, c1)
     assert err.max() < 1e-10
+    # the distributed direct sum == the single-task direct sum (same pairs, another summation order)
+    d0 = np.load(os.path.join(str(tmp_path), "s0.npz"))
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=old)
+    eng.domain_Decomposition()
+    truth = eng.direct_sum(d0["direct_ids"].astype(np.int32))
+    eng.close()
+    ed = np.linalg.norm(d0["direct"] - truth, axis=1) / np.linalg.norm(truth, axis=1)
+    print("%s: distributed direct sum of %d test particles vs single task: max %.2e" % (case, len(truth), ed.max()))
+    assert ed.max() < 1e-10
     if cfg.pmgrid:
         # the following non-PM step: OldAcc = |GravAccel + GravPM/G| with the GravPM of the PM step
         eng = pkg.Engine(cfg)
