@@ -52,7 +52,7 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
 DD_STAGES = ["extent+leaf_sums+top_tree+cut", "migration", "of_the_first:leaf_sum_passes+allreduce", "import_decision_host",
              "count/request_allgather+pack", "import_exchange+unpack", "global_top", "local_decomposition"]
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_walk_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_walk_traffic.json")
 
 
 def walk_source_hash():

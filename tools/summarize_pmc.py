@@ -69,8 +69,10 @@ def main():
                        "launches_per_step": len(traffic.get("FETCH_SIZE", [0])) - len(traffic.get("FETCH_SIZE", [0])) // 2,
                        "fetch_bytes_reported": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the evaluation-kernel "
-                               "launches of the timed relative-criterion step; FETCH_SIZE as reported (gather reads, "
-                               "uncalibrated; x2 is the upper bound)"}, f, indent=1)
+                               "launches of the timed relative-criterion step; FETCH_SIZE as reported: the kernel's reads are 16-byte list "
+                               "quads and 32-byte record gathers, for which FETCH_SIZE counts the fabric bytes 1:1 (64-byte requests; "
+                               "calibrated by tools/ubench/fetch_calib.hip, profiles/r03_fetch_calibration.json -- only wide coalesced "
+                               "streaming reads are reported at 1/2)"}, f, indent=1)
 
 
 if __name__ == "__main__":
