@@ -132,6 +132,7 @@ struct Tuning
 struct TopTree
 {
   bool on = false;                     // sums + presence are set: the next tree build forces the global top (ngravs_dd_set_top)
+  double import_reach = 0;             // short-range reach (units of Asmth) the import decision was made for (walk mode at set_top)
   ngravs_toptree h = {0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // host copy: child, level, xyz, leaf numbers
   DevBuf<int> child, leaf;             // per node: first child or -1; leaf number (curve order) or -1
   DevBuf<int> gcnt;                    // per node: global particle count
@@ -228,6 +229,7 @@ struct ngravs_ctx
   DevBuf<int> walk_tlist;     // compacted active targets of the shard (individual timesteps), Peano order
   DevBuf<unsigned char> walk_tmp;
   long long walk_ntargets = -1;   // >= 0: the group walk runs over walk_tlist[0..walk_ntargets)
+  bool walk_dense_tlist = false;  // ... and that list is the own rows of a multi-task working set, nearly all of them active
   int walk_spread = 0;        // > 1: every group of 64 targets is walked as `spread` sub-groups by the fused kernel
   int walk_sg = 1;            // split walk: groups per traversal unit (shared item lists) of the last launch
   bool all_active = true;     // the caller passed no active flags

@@ -2271,7 +2271,11 @@ struct ActiveFlag
 static int walk_select_targets(ngravs_ctx *c)
 {
   c->walk_ntargets = -1;
-  if(c->all_active || c->shard_count <= 0 || !c->tune.walk_compact)
+  c->walk_dense_tlist = false;
+  // a multi-task working set interleaves the own rows with imported copies (sources only): walking stretches of 64 ROWS would
+  // leave a lane idle for every imported row (30-40 % at 8 tasks), so the own active rows are always compacted
+  const bool imports = c->n_local != c->n;
+  if((c->all_active && !imports) || c->shard_count <= 0 || !c->tune.walk_compact)
     return NGRAVS_OK;
   const int n = (int)c->shard_count;
   if(c->walk_tlist.ensure((size_t)n) || c->walk_counters.ensure(32))
@@ -2286,8 +2290,11 @@ static int walk_select_targets(ngravs_ctx *c)
   int cnt = 0;
   HIP_TRY(c, hipMemcpyAsync(&cnt, c->walk_counters.p + 24, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if(4ll * cnt < 3ll * n)
+  if(4ll * cnt < 3ll * n || imports)
     c->walk_ntargets = cnt;
+  // most own rows active: the list is the Peano order of the own particles with the imported rows taken out -- as contiguous as
+  // a single task's targets, so traversal units of four groups pay off as they do there
+  c->walk_dense_tlist = imports && 4ll * cnt >= 3ll * c->n_local;
   return NGRAVS_OK;
 }
 
@@ -2359,7 +2366,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   // groups per traversal unit: 4 for TreePM walks of Peano-contiguous targets (the short-range region of 256 neighbours is
   // 1.7 x that of 64: lists and traversal work per target fall to ~0.4), 1 for tree-only walks (no cut: a wider box opens more
   // of the tree for every target) and for scattered (compacted / spread) targets
-  int SG = (PM && c->walk_ntargets < 0) ? 4 : 1;
+  int SG = (PM && (c->walk_ntargets < 0 || c->walk_dense_tlist)) ? 4 : 1;
   if(c->tune.walk_sg >= 1)
     SG = c->tune.walk_sg;
   if(SG != c->walk_sg)
@@ -2507,6 +2514,17 @@ int walk_run(ngravs_ctx *c)
   make_law_ids(c, &li);
   c->walk_ntargets = -1;
   const bool strict = c->cfg.walk_mode == NGRAVS_WALK_STRICT || cfg_has_bam(c->cfg);
+  if(c->top.on && c->cfg.pmgrid)
+    {
+      // multi-task tree: the leaves this task imported were chosen for the reach of the walk mode in force at the decomposition
+      const double need = strict ? 6.0 : fmin(6.0, c->cfg.group_reach > 0 ? c->cfg.group_reach : NGRAVS_GROUP_REACH);
+      if(need > c->top.import_reach * (1.0 + 1e-12))
+        {
+          ngravs_report(c, NGRAVS_ERR_STATE, "the walk reaches farther than the multi-task decomposition imported for: set the walk mode "
+                                             "(and group_reach) before the decomposition");
+          return NGRAVS_ERR_STATE;
+        }
+    }
   if(!strict)
     {
       int rct = ensure_level_table(c, sqrt(wp.reach2));
@@ -2569,7 +2587,7 @@ int walk_run(ngravs_ctx *c)
       // group tests would collect (and then mostly discard) huge lists; walk them in sub-groups of 64/S targets, S lanes
       // per target (k_walk_group2).
       c->walk_spread = 0;
-      if(c->walk_ntargets >= 0 && pm && c->cfg.box_size > 0)
+      if(c->walk_ntargets >= 0 && !c->walk_dense_tlist && pm && c->cfg.box_size > 0)
         {
           const double vol_per_target = pow(c->cfg.box_size, 3) * (double)c->shard_count / ((double)c->n * (double)(c->walk_ntargets > 0 ? c->walk_ntargets : 1));
           // measured (16 M particles, 10 % / 1 % / 0.1 % active): S = 1 wins while 64 targets span less than ~2.5 reaches,

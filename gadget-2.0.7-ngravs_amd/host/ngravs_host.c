@@ -606,7 +606,10 @@ int ngravs_host_import_request(const ngravs_config_t *cfg, const double dom[8], 
       T.aold_min = bounds[0];
       T.h_min = bounds[1];
       T.rcut = cfg->rcut;
-      T.reach6 = 6.0 * cfg->asmth;
+      /* how far a target's short-range force reaches: the end of the table (tabindex < NTAB: 6 Asmth, forcetree.c:1962-1967) for
+       * the reference walk, the sphere of group_reach Asmth (default RCUT) for the group walk -- whichever walk the context is
+       * set to; the library refuses a walk that reaches farther than the decomposition assumed (walk_run) */
+      T.reach6 = (cfg->walk_mode == NGRAVS_WALK_GROUP ? fmin(6.0, cfg->group_reach > 0 ? cfg->group_reach : NGRAVS_GROUP_REACH) : 6.0) * cfg->asmth;
       for(j = 0; j < 6; j++)
         T.fsoft[j] = cfg->force_softening[j];
       for(j = 0; j < 3; j++)
