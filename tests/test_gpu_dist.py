@@ -116,7 +116,7 @@ def _strict_worker(rank, world, port, out_dir, case, backend="gloo"):
 
 # top-tree thresholds of the test cases (None: the reference's TotNumPart / (20 NTask)); small ones so that tasks really lack
 # parts of the tree at these particle numbers
-LEAF_MAX = {"plummer": 100.0, "periodic": 60.0}
+LEAF_MAX = {"plummer": 100.0, "periodic": 60.0, "c5": 60.0}
 
 
 def _strict_case(pkg, case):
@@ -126,6 +126,13 @@ def _strict_case(pkg, case):
         typ = (1 + (np.arange(n) % 2)).astype(np.int32)
         cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.02, 0.01, 0.01, 0.01],
                               type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton", walk_mode=pkg.WALK_STRICT)
+        return pos, mass, typ, np.zeros(n), cfg
+    if case == "c5":               # BASELINE's 8-GPU workload in small: N_GRAVS=3 (Newton diagonal, Newton+Yukawa off-diagonal), TreePM
+        n, L = 30000, 1.0
+        pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=3, seed=91)
+        eps = L / (40 * n ** (1 / 3))
+        cfg = pkg.make_config(n_gravs=3, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(3), wiring="c4", walk_mode=pkg.WALK_STRICT)
         return pos, mass, typ, np.zeros(n), cfg
     if case == "periodic":         # periodic tree-only: nearest-image tree force + the lattice-correction walk (forcetree.c:2077-2455)
         n, L = 16000, 1.0
@@ -144,7 +151,7 @@ def _strict_case(pkg, case):
     return pos, mass, typ, gold["old_acc"], cfg
 
 
-@pytest.mark.parametrize("case", ["plummer", "c4", "periodic"])
+@pytest.mark.parametrize("case", ["plummer", "c4", "periodic", "c5"])
 def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
     """The reference's invariant (domain.c:18-21): the tree force does not depend on the number of tasks.  With the global top
     of the tree (top-leaf moments of all tasks) and the imported top cells every task's tree IS the single-task tree wherever
