@@ -691,7 +691,10 @@ peanokey peano_hilbert_key(int x, int y, int z, int bits)
 }
 void peano_hilbert_order(void)
 {
-  /* the device keeps its own Peano order; P[] stays in the host's order */
+  /* The device keeps its own Peano order; P[] stays in the host's order.  The reference sorts P[] by (species, key) so that
+   * pm_periodic.c:251-254 can address the particles of one species as a contiguous block through NgravLocal[]; that reader is
+   * gone with pm_periodic.o (the device PM selects species by TypeToGrav[P[].Type]), and count_types() above still maintains
+   * NgravLocal[] / NtypeLocal[] / Ntype[] for the kept units that print them. */
 }
 
 #endif /* NGRAVS_BUILD_INSIDE_REFERENCE */

@@ -105,3 +105,66 @@ def test_total_force_against_periodic_direct_sum(pkg, big):
           (N_LOG2, np.sqrt(np.mean(e ** 2)), np.median(e), e.max(), cost.mean()))
     assert np.sqrt(np.mean(e ** 2)) <= 9.6e-3 and e.max() < 0.1      # the reference's own measured band
     eng.close()
+
+
+def _four_task_worker(rank, world, port, out_dir):
+    import importlib
+    import os
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    n = 1 << N_LOG2
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=2, seed=2026)
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=PMGRID, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    mine = np.arange(rank, n, world)
+    active = (mine % 16 == 0).astype(np.uint8)            # the reference walk for 1/16 of the particles (gravtree.c:113)
+    eng = dd.DistributedEngine(cfg)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], active=active, ids=mine)
+    eng.compute_accelerations(pm_step=True)
+    acc, _, cost, pm = eng.get_accel(want_pm=True)
+    ids = eng.local_ids()
+    sel = ids % 16 == 0
+    np.savez(os.path.join(out_dir, "t%d.npz" % rank), ids=ids[sel], acc=acc[sel], cost=cost[sel], pm=pm[sel],
+             info=np.array([eng.info.n_local, eng.info.n_halo, eng.info.n_topleaves, eng.info.toptree_rounds]))
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_four_tasks_at_two_million_particles(pkg, big, tmp_path):
+    """The multi-task path where most of the tree is ABSENT on every task (2 M particles, 4 tasks: each imports a shell of its
+    domain, the rest of the box is pseudo nodes): the reference walk for 1/16 of the particles gives the single-task forces with
+    identical interaction counts, GravPM of the slab-decomposed mesh equals the single mesh."""
+    import os
+    import torch.multiprocessing as mp
+    n, pos, mass, typ, kw = big
+    world = 4
+    mp.spawn(_four_task_worker, args=(world, 29300 + os.getpid() % 500, str(tmp_path)), nprocs=world, join=True)
+    active = (np.arange(n) % 16 == 0).astype(np.uint8)
+    eng = pkg.Engine(pkg.make_config(walk_mode=pkg.WALK_STRICT, **kw))
+    eng.set_particles(pos, mass, typ, active=active)
+    eng.compute_accelerations(pm_step=True)
+    a1, _, c1, p1 = eng.get_accel(want_pm=True)
+    eng.close()
+    seen = np.zeros(n, dtype=np.int64)
+    worst, worst_pm = 0.0, 0.0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "t%d.npz" % r))
+        ids = d["ids"]
+        seen[ids] += 1
+        print("task %d: %d own + %d imported particles, %d top leaves, %d counting rounds" % (r, *d["info"]))
+        assert d["info"][1] < 0.6 * d["info"][0]            # a shell, not the box
+        assert np.array_equal(d["cost"], c1[ids])
+        worst = max(worst, rel_err(d["acc"], a1[ids]).max())
+        worst_pm = max(worst_pm, np.abs(d["pm"] - p1[ids]).max() / np.abs(p1).max())
+    assert np.array_equal(seen, active.astype(np.int64))
+    print("4 tasks vs 1 at 2^%d particles: tree force max |da|/|a| %.2e, GravPM max diff %.2e of max" % (N_LOG2, worst, worst_pm))
+    assert worst < 1e-10 and worst_pm < 1e-10
