@@ -480,6 +480,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.pm_tile8 = iv != 0;
   else if(k == "tree_levelwise")
     t.tree_levelwise = iv != 0;
+  else if(k == "moments_octet")
+    t.moments_octet = iv != 0;
   else
     {
       ngravs_report(c, NGRAVS_ERR_ARG, "ngravs_set_tuning: unknown name or value out of range: " + k);

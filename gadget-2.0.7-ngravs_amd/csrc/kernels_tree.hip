@@ -713,6 +713,162 @@ __global__ void k_moments(const double4 *__restrict__ s_pm, const unsigned char 
     n_count_rw[node] = cnt_acc;
 }
 
+// The same pass with EIGHT lanes per node, one per child slot (tuning "moments_octet"): a node's child indices are one 32-byte
+// line, its particle children are consecutive in the sorted array and its child nodes consecutive in the level-contiguous
+// numbering, so the eight record loads of an octet are one contiguous stretch and all in flight at once.  MEASURED SLOWER at C4
+// (tree build 5.74 against 4.95 ms): eight times the threads, three of four lanes without a child at the deep levels, and 48
+// cross-lane moves per node cost more than the coalescing gains -- the one-thread-per-node pass stays the default.
+// The eight partial sums are added in a fixed butterfly order ((0+1)+(2+3))+((4+5)+(6+7)): deterministic, the same on every
+// task and in both build variants.  Lane 0 of the octet writes.
+__device__ __forceinline__ double oct_sum(double v)
+{
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+template <int NG>
+__global__ __launch_bounds__(256) void k_moments8(const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
+                                                   const int *__restrict__ n_first, const int *__restrict__ n_count,
+                                                   const int *__restrict__ n_child, const double4 *__restrict__ n_geo,
+                                                   double4 *__restrict__ n_mom, int *__restrict__ n_flags, int node0, int nnodes_level,
+                                                   WalkParams wp, double4 *__restrict__ geo_rw = nullptr, int *__restrict__ n_npart = nullptr,
+                                                   int *__restrict__ n_count_rw = nullptr)
+{
+  const long long gt = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int t = (int)(gt >> 3), q = threadIdx.x & 7;
+  const bool live = t < nnodes_level;   // uniform over the octet
+  const int node = node0 + (live ? t : 0);
+  double m[NG], sx[NG], sy[NG], sz[NG];
+  int np[NG];
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    {
+      m[g] = sx[g] = sy[g] = sz[g] = 0;
+      np[g] = 0;
+    }
+  SoftAcc sa;
+  sa.maxsofttype = 7;
+  sa.diff = 0;
+  int cnt_acc = 0;
+  const int fl = n_flags[node];
+  const double4 geo0 = n_geo[node];
+  double need = 0;
+  auto add_particle_v = [&](const double4 v, const int ty) {
+    if(geo_rw)
+      need = fmax(need, fmax(fabs(v.x - geo0.x), fmax(fabs(v.y - geo0.y), fabs(v.z - geo0.z))));
+    const int gg = wp.t2g[ty];
+#pragma unroll
+    for(int g = 0; g < NG; g++)
+      if(g == gg)
+        {
+          np[g]++;
+          m[g] += v.w;
+          sx[g] += v.w * v.x;
+          sy[g] += v.w * v.y;
+          sz[g] += v.w * v.z;
+        }
+    soft_merge(sa, ty, 0, wp.fsoft);
+    cnt_acc++;
+  };
+  if(live)
+    {
+      if(fl & FLAG_BUCKET)
+        {
+          const int f = n_first[node], cnt = n_count[node];
+          for(int p = f + q; p < f + cnt; p += 8)
+            add_particle_v(s_pm[p], s_type[p]);
+        }
+      else
+        {
+          const int c = n_child[8 * (long long)node + q];
+          if(c <= -2)
+            add_particle_v(s_pm[-2 - c], s_type[-2 - c]);
+          else if(c >= 0)
+            {
+#pragma unroll
+              for(int g = 0; g < NG; g++)
+                {
+                  const double4 cm = n_mom[(long long)c * NG + g];
+                  if(n_npart)
+                    np[g] += n_npart[(long long)c * NG + g];
+                  m[g] += cm.w;
+                  sx[g] += cm.w * cm.x;
+                  sy[g] += cm.w * cm.y;
+                  sz[g] += cm.w * cm.z;
+                }
+              const int cf = n_flags[c];
+              soft_merge(sa, (cf >> 2) & 7, (cf >> 5) & 1, wp.fsoft);
+              if(n_count_rw)
+                cnt_acc += n_count_rw[c];
+              if(geo_rw)
+                {
+                  const double4 cg = n_geo[c];
+                  need = fmax(need, fmax(fabs(cg.x - geo0.x), fmax(fabs(cg.y - geo0.y), fabs(cg.z - geo0.z))) + 0.5 * cg.w);
+                }
+            }
+        }
+    }
+  // combine the eight lanes of the octet
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    {
+      m[g] = oct_sum(m[g]);
+      sx[g] = oct_sum(sx[g]);
+      sy[g] = oct_sum(sy[g]);
+      sz[g] = oct_sum(sz[g]);
+      if(n_npart)
+        {
+          np[g] += __shfl_xor(np[g], 1);
+          np[g] += __shfl_xor(np[g], 2);
+          np[g] += __shfl_xor(np[g], 4);
+        }
+    }
+#pragma unroll
+  for(int off = 1; off < 8; off <<= 1)
+    {
+      const int ot = __shfl_xor(sa.maxsofttype, off), od = __shfl_xor(sa.diff, off);
+      // the lower lane of a pair merges the higher one's partial (fixed order); the higher lane's copy is never used
+      if(!(q & off))
+        soft_merge(sa, ot, od, wp.fsoft);
+      cnt_acc += __shfl_xor(cnt_acc, off);
+      if(geo_rw)
+        need = fmax(need, __shfl_xor(need, off));
+    }
+  if(!live || q != 0)
+    return;
+  double4 geo = geo0;
+  if(geo_rw && 2.0 * need > geo.w)
+    {
+      geo.w = 2.0 * need;
+      geo_rw[node] = geo;
+    }
+#pragma unroll
+  for(int g = 0; g < NG; g++)
+    {
+      double4 o;
+      if(m[g] > 0)
+        {
+          o.x = sx[g] / m[g];
+          o.y = sy[g] / m[g];
+          o.z = sz[g] / m[g];
+        }
+      else
+        {
+          o.x = geo.x;
+          o.y = geo.y;
+          o.z = geo.z;
+        }
+      o.w = m[g];
+      n_mom[(long long)node * NG + g] = o;
+      if(n_npart)
+        n_npart[(long long)node * NG + g] = np[g];
+    }
+  n_flags[node] = (fl & (FLAG_BUCKET | FLAG_PSEUDO | FLAG_PARTIAL)) | (4 * sa.maxsofttype + 32 * sa.diff);
+  if(n_count_rw && !(fl & FLAG_BUCKET))
+    n_count_rw[node] = cnt_acc;
+}
+
 // Global top of a multi-task tree: monopoles and softening flags of the tree nodes that are top-tree nodes, from the all-reduced
 // sums (force_treeupdate_pseudos, forcetree.c:851-947, adds the remote top-leaf moments up the ancestor chain; here every top
 // node takes the sum over ALL tasks directly).  Top LEAVES: only the pseudo nodes (the leaves present here keep the bottom-up
@@ -812,6 +968,26 @@ int tree_moments(ngravs_ctx *c, bool refit, bool counts)
       if(lc <= 0)
         continue;
       unsigned nb = (unsigned)((lc + bs - 1) / bs);
+      if(c->tune.moments_octet)
+        {
+          const unsigned nb8 = (unsigned)((8 * lc + 255) / 256);
+          switch(ng)
+            {
+            case 1:
+              hipLaunchKernelGGL(k_moments8<1>, dim3(nb8), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p, c->n_count.p,
+                                 c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
+              break;
+            case 2:
+              hipLaunchKernelGGL(k_moments8<2>, dim3(nb8), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p, c->n_count.p,
+                                 c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
+              break;
+            default:
+              hipLaunchKernelGGL(k_moments8<3>, dim3(nb8), dim3(256), 0, c->stream, c->s_pm.p, c->s_type.p, c->n_first.p, c->n_count.p,
+                                 c->n_child.p, c->n_geo.p, c->n_mom.p, c->n_flags.p, (int)l0, (int)lc, wp, grw, npp, cntp);
+              break;
+            }
+          continue;
+        }
       switch(ng)
         {
         case 1:

@@ -193,6 +193,7 @@ int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
  *   "pm_notile" 1: per-particle CIC deposit     "pm_fused_gather" 1: one-pass gradient+gather    "pm_tile_gather" 1: LDS-tiled gather
  *   "pm_tile8" 1: deposit tiles of 8 instead of 16 mesh cells    "tree_levelwise" 1: level-by-level tree build for single-task trees too
  *   "sort_full" 1: Peano order by one radix sort on all key bits (default: top 28 to 42 bits + fix-up of the ties, the same order)
+ *   "moments_octet" 1: node moments with eight lanes per node instead of one thread per node (another summation order; slower)
  * Returns NGRAVS_ERR_ARG for an unknown name or a value out of range. */
 int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
 /* Plain copies for hosts that do not link HIP themselves (a C/MPI host staging exchange buffers through host memory):
