@@ -1680,3 +1680,67 @@ static void orc_direct_impl(const ngravs_config_t *cfg, const double *pos, const
       acc[3 * k + 2] = az * cfg->G;
     }
 }
+
+/* Test instrumentation (not a reference function): the reference's short-range PAIR interaction (forcetree.c:1953-2032: law minus
+ * the tabulated long-range part, spline inside the softening length, nothing beyond the table) applied to EVERY particle within
+ * `reach` of a target -- what a TreePM walk computes when every source inside its cut is taken as a particle.  The production
+ * group walk of the engine cuts at a sphere of group_reach * Asmth; where its lists hold particles only it must reproduce this sum
+ * pair for pair.  acc without G (as the walks leave it); nint = pairs that added something. */
+void orc_direct_shortrange(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                           const int32_t *idx, int64_t nt, const double *table, double reach, double *acc, int32_t *nint, int nthreads)
+{
+  const int ng = cfg->n_gravs;
+  const double boxsize = cfg->box_size, boxhalf = 0.5 * cfg->box_size;
+  const double asmth = cfg_asmth(cfg), asmthfac = 0.5 / asmth * (NTAB / 3.0), utor2wpi = 1.0 / (M_PI * 4 * asmth * asmth);
+  const double reach2 = reach * reach;
+#ifdef _OPENMP
+  if(nthreads > 0)
+    omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+  for(int64_t k = 0; k < nt; k++)
+    {
+      const int64_t t = idx ? idx[k] : k;
+      const int ptype = type[t], tg = cfg->type_to_grav[ptype];
+      double ax = 0, ay = 0, az = 0;
+      int cnt = 0;
+      for(int64_t i = 0; i < n; i++)
+        {
+          double dx = pos[3 * i] - pos[3 * t], dy = pos[3 * i + 1] - pos[3 * t + 1], dz = pos[3 * i + 2] - pos[3 * t + 2];
+          if(cfg->periodic)
+            {
+              dx = NEAREST(dx);
+              dy = NEAREST(dy);
+              dz = NEAREST(dz);
+            }
+          const double r2 = dx * dx + dy * dy + dz * dz;
+          if(!(r2 < reach2))
+            continue;
+          const double r = sqrt(r2);
+          const int tab = (int)(asmthfac * r);
+          if(tab >= NTAB)
+            continue;
+          const int sg = cfg->type_to_grav[type[i]];
+          double h = cfg->force_softening[ptype], fac;
+          if(h < cfg->force_softening[type[i]])
+            h = cfg->force_softening[type[i]];
+          if(r >= h)
+            {
+              fac = law_accel_tn(cfg, cfg->law_accel[tg][sg], mass[t], mass[i], r2, r, 1);
+              fac -= mass[i] * utor2wpi * table[((size_t)tg * ng + sg) * NTAB + tab];
+              fac /= r;
+            }
+          else
+            fac = law_spline_tn(cfg, cfg->law_spline[tg][sg], mass[t], mass[i], h, r, 1);
+          ax += dx * fac;
+          ay += dy * fac;
+          az += dz * fac;
+          cnt++;
+        }
+      acc[3 * k] = ax;
+      acc[3 * k + 1] = ay;
+      acc[3 * k + 2] = az;
+      if(nint)
+        nint[k] = cnt;
+    }
+}

@@ -53,6 +53,10 @@ int orc_walk(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, 
  * entered the walk of one of the targets; 0 = particle-particle) -- what a task must hold to walk these targets */
 int orc_walk_reach(const orc_tree *t, const ngravs_config_t *cfg, const int32_t *idx, int64_t nt, const double *old_acc,
                    const double *table, double *reach);
+/* test instrumentation: the reference's short-range pair interaction summed over every particle within `reach` of each target
+ * (acc without G, nint = pairs) -- the quantity the production group walk computes where its lists hold particles only */
+void orc_direct_shortrange(const ngravs_config_t *cfg, const double *pos, const double *mass, const int32_t *type, int64_t n,
+                           const int32_t *idx, int64_t nt, const double *table, double reach, double *acc, int32_t *nint, int nthreads);
 /* gravtree.c:318-341: old_acc_out = |acc + pm/G|, acc *= G */
 void orc_finish(const ngravs_config_t *cfg, int64_t n, double *acc, const double *pm, double *old_acc_out);
 

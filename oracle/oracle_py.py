@@ -73,6 +73,16 @@ def peano_order(cfg, key, ptype):
     return out
 
 
+def direct_shortrange(cfg, pos, mass, ptype, idx, table, reach, nthreads=0):
+    """test instrumentation: sum of the reference's short-range pair interaction over every particle within `reach`"""
+    pos, mass, ptype, idx, table = _f64(pos), _f64(mass), _i32(ptype), _i32(idx), _f64(table)
+    acc = np.zeros((len(idx), 3))
+    nint = np.zeros(len(idx), dtype=np.int32)
+    lib().orc_direct_shortrange(C.byref(cfg), _p(pos), _p(mass), _p(ptype), C.c_int64(len(pos)), _p(idx), C.c_int64(len(idx)), _p(table),
+                                C.c_double(reach), _p(acc), _p(nint), C.c_int(nthreads))
+    return acc, nint
+
+
 def toptree_count(key):
     key = np.ascontiguousarray(key, dtype=np.int64)
     nl = C.c_int(0)

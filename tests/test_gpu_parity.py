@@ -347,6 +347,45 @@ def test_group_walk_kernels_reproduce_the_reference_interaction_set(pkg, O, wiri
     assert np.all(acc[active == 0] == 0)
 
 
+@pytest.mark.parametrize("ng", [2, 3])
+def test_production_walk_is_the_cut_direct_sum(pkg, O, ng):
+    """The production configuration of the production kernels -- 64 targets per wave, traversal units of four groups, sphere cut at
+    RCUT (group_reach 4.5), leaf shortcut, start table, wrap-free groups: nothing tuned -- against an exact quantity: at the bench's
+    density and criterion every source inside the cut sphere reaches the force loop as a PARTICLE (the relative criterion opens
+    every cell this close for at least one of the 256 targets of a unit), so the group walk's force must be the sum of the
+    reference's short-range pair interaction (forcetree.c:1953-2032) over every particle within RCUT * Asmth, pair for pair:
+    identical interaction counts and forces to rounding for (almost) every target; a target whose list holds a monopole is
+    counted and bounded.  This ties the production path to the oracle's arithmetic, not to an error band."""
+    n, L, pmgrid = 1 << 17, 1.0, 64                               # 2 mesh cells per particle, as C4 / C5
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=123)
+    eps = L / (40 * n ** (1 / 3))
+    cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=pkg.WALK_GROUP)
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=True)                       # theta pass: OldAcc
+    _, old, _ = eng.get_accel()
+    eng.set_old_acc(old)
+    eng.set_opening(0.0, 0.005)                                    # the steady-state relative criterion of the bench
+    eng.compute_accelerations(pm_step=True)
+    acc, _, cost = eng.get_accel()
+    st = eng.stats()
+    eng.close()
+    assert st.reserved[5] >= 1                                     # the split (traversal + evaluation) kernels ran
+    idx = np.sort(np.random.default_rng(11).choice(n, 512, replace=False)).astype(np.int32)
+    tab, _ = O.shortrange_table(cfg)
+    reach = 4.5 * 1.25 * L / pmgrid
+    a_o, n_o = O.direct_shortrange(cfg, pos, mass, typ, idx, tab, reach)
+    err = np.linalg.norm(acc[idx] / cfg.G - a_o, axis=1) / np.linalg.norm(a_o, axis=1)
+    same = cost[idx].astype(np.int64) == n_o.astype(np.int64)
+    exact = err < 1e-10
+    print("production group walk vs cut direct sum [N_GRAVS=%d]: %.1f (oracle %.1f) pairs/target; counts equal for %d, force equal to "
+          "rounding for %d of %d targets (median %.1e, worst of those %.1e); the others: max %.1e" %
+          (ng, cost[idx].mean(), n_o.mean(), same.sum(), exact.sum(), len(idx), np.median(err), err[exact].max(), err.max()))
+    assert same.mean() > 0.97 and exact.mean() > 0.97               # (almost) every target: the same pairs, the same force to rounding
+    assert err.max() < 2e-3                                         # the rest: a cell at the edge of the cut taken as one monopole
+    assert abs(cost[idx].mean() - n_o.mean()) < 0.01 * n_o.mean()
+
+
 def test_group_walk_three_species(pkg, O):
     """N_GRAVS=3 (the C5 wiring: Newton diagonal, Newton+Yukawa off-diagonal; short-range tables read through L1/L2
     instead of LDS): the group walk stays within the reference walk's own error band of the strict result"""
