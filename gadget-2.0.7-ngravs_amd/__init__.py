@@ -28,7 +28,7 @@ EXPORTS = [
     "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_softening", "ngravs_dd_record_bytes", "ngravs_get_config", "ngravs_set_tuning",
     "ngravs_memcpy",
     "ngravs_set_particles",
-    "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition",
+    "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition", "ngravs_discard_grav_pm",
     "ngravs_force_treebuild", "ngravs_gravity_tree",
     "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
@@ -77,7 +77,7 @@ def lib():
         L.ngravs_force_treebuild.restype = C.c_int64
         L.ngravs_force_treebuild.argtypes = [C.c_void_p]
         for name in ("ngravs_destroy", "ngravs_domain_decomposition", "ngravs_gravity_tree",
-                     "ngravs_pmforce_periodic"):
+                     "ngravs_pmforce_periodic", "ngravs_discard_grav_pm"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.ngravs_compute_accelerations.argtypes = [C.c_void_p, C.c_int]
         L.ngravs_set_opening.argtypes = [C.c_void_p, C.c_double, C.c_double]

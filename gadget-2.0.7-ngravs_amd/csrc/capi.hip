@@ -788,6 +788,17 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
 
 extern "C" int ngravs_domain_decomposition(ngravs_ctx *c) { return domain_decomposition_impl(c, true); }
 
+// The step that follows recomputes GravPM (a PM step: long_range_force() comes before gravity_tree(), accel.c:34-46): the stored
+// long-range force need not be parked in caller order, migrated and permuted into the new Peano order only to be overwritten
+extern "C" int ngravs_discard_grav_pm(ngravs_ctx *c)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  c->have_pm = false;
+  c->pm_parked = false;
+  return NGRAVS_OK;
+}
+
 extern "C" int64_t ngravs_force_treebuild(ngravs_ctx *c)
 {
   if(!c || !c->have_order)

@@ -287,6 +287,8 @@ class DistributedEngine(Engine):
         w = self.wall
         c0, n0 = self.comm.seconds, self.comm.calls
         t0 = time.perf_counter()
+        if pm_step and self.cfg.pmgrid:
+            self._check(self._L.ngravs_discard_grav_pm(self._h), "ngravs_discard_grav_pm")    # recomputed below
         self.domain_Decomposition()
         t1 = time.perf_counter()
         c1 = self.comm.seconds

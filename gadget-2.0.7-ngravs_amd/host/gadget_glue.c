@@ -362,6 +362,10 @@ void domain_Decomposition(void)
       do_box_wrapping();
 #endif
       push_particles(0);
+#ifdef PMGRID
+      if(All.PM_Ti_endstep == All.Ti_Current)
+	must(ngravs_discard_grav_pm(Ctx), 1073);	/* a PM step: long_range_force() recomputes GravPM before gravity_tree() reads it */
+#endif
       if(NTask == 1)
 	must(ngravs_domain_decomposition(Ctx), 1057);
       else

@@ -1179,6 +1179,8 @@ int ngravs_host_compute_accelerations(ngravs_ctx *ctx, const ngravs_comm *cm, in
 {
   ngravs_config_t cfg;
   CHECK(ngravs_get_config(ctx, &cfg));
+  if(pm_step && cfg.pmgrid)
+    CHECK(ngravs_discard_grav_pm(ctx));   /* recomputed below: nothing to carry through the decomposition */
   CHECK(ngravs_host_domain_decomposition(ctx, cm, 0.0, 0.0, info));
   if(pm_step && cfg.pmgrid)
     CHECK(ngravs_host_pmforce_periodic(ctx, cm));

@@ -216,6 +216,10 @@ int ngravs_set_old_acc(ngravs_ctx *ctx, const double *old_acc, int64_t stride, i
 /* domain_findExtent + keys + Peano-Hilbert order (domain.c:882-944, peano.c:36-185).  Computes
  * DomainCorner/Center/Len/Fac, the 18-bit reference keys and the device-side Peano order. */
 int ngravs_domain_decomposition(ngravs_ctx *ctx);
+/* Tell the library that the coming step is a PM step: the stored GravPM will be recomputed before anything reads it, so it need
+ * not be carried through the decomposition (ngravs_compute_accelerations(ctx, 1) does this by itself; a multi-task host that
+ * calls the decomposition and the PM force separately saves two passes over the particles) */
+int ngravs_discard_grav_pm(ngravs_ctx *ctx);
 /* force_treebuild(): returns the number of tree nodes (>0) or a negative status. */
 int64_t ngravs_force_treebuild(ngravs_ctx *ctx);
 /* The dynamic tree update between rebuilds (predict.c:79-91 node drift + force_update_len(), forcetree.c:1005-1122,
