@@ -557,7 +557,11 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   c->n_local = n;
   if(!keep_tree)
     {
-      c->own_order_nlocal = -1;   // new rows: the last Peano order says nothing about them
+      // The Peano order of the last decomposition (s_idx) is only a visiting order for the per-leaf sums -- any permutation is
+      // correct, a good one lets a wave add up before it touches memory.  A host that hands the same rows over again with
+      // drifted positions (P[] between two migrations) keeps it; a different row count means other rows.
+      if(c->own_order_nlocal != n)
+        c->own_order_nlocal = -1;
       c->sort_low = 35;
     }
   int rc;

@@ -153,3 +153,45 @@ def test_bad_wiring_is_rejected_without_a_gpu(pkg, have_lib):
     cfg = pkg.make_config(n_gravs=1)
     cfg.n_gravs = 4
     assert have_lib.ngravs_create(C.byref(cfg), C.byref(h)) == -1
+
+
+def test_top_tree_rule_on_degenerate_and_clustered_sets(pkg, have_lib):
+    """ngravs_host_toptree_adapt: the rule "split while count > threshold" reaches a fixed point from any start, merges what a
+    finer start split too far, stops at the key resolution for coincident particles, and every leaf of the result either obeys
+    the threshold or sits at the deepest level."""
+    import numpy as np
+    rng = np.random.default_rng(8)
+    n = 50000
+    # a clump of coincident keys + a Gaussian blob + a uniform background (keys: 63-bit, 21 bits per dimension)
+    blob = np.clip(rng.normal(0.3, 0.01, (n // 2, 3)), 0, 0.999999)
+    back = rng.uniform(0, 1, (n // 2 - 500, 3))
+    same = np.full((500, 3), 0.77)
+    pos = np.concatenate([blob, back, same])
+    ix = (pos * (1 << 21)).astype(np.int64)
+    key21 = np.array([have_lib.ngravs_peano_hilbert_key(int(a), int(b), int(c), 21) for a, b, c in ix[::1]], dtype=np.int64)
+    results = []
+    for start in (1, 4, 6):
+        t, cnt, rounds = build_toptree(have_lib, key21, 64.0, start_level=start)
+        nn = t.nnode
+        child = np.ctypeslib.as_array(t.child, (nn,)).copy()
+        level = np.ctypeslib.as_array(t.level, (nn,)).copy()
+        leaf = np.ctypeslib.as_array(t.leaf, (nn,)).copy()
+        lv = level[np.argsort(np.where(leaf >= 0, leaf, 1 << 30))[: t.nleaf]]
+        assert cnt.sum() == n
+        heavy = cnt > 64.0
+        assert np.all(lv[heavy] == 18) and heavy.sum() >= 1          # only the coincident clump, at the key resolution
+        assert cnt[heavy].sum() >= 500
+        # every split node holds more than the threshold (nothing was split too far and left that way)
+        ncount = np.zeros(nn)
+        for i in range(nn - 1, -1, -1):
+            ncount[i] = cnt[leaf[i]] if child[i] < 0 else ncount[child[i]: child[i] + 8].sum()
+        assert np.all(ncount[(child >= 0) & (np.arange(nn) > 0)] > 64.0)
+        results.append((t.nnode, t.nleaf, child.tobytes()))
+        print("start level %d: %d rounds -> %d nodes / %d leaves, depth %d" % (start, rounds, t.nnode, t.nleaf, t.depth))
+        have_lib.ngravs_host_toptree_free(C.byref(t))
+    assert results[0] == results[1] == results[2]                    # the rule has ONE fixed point
+    # fewer leaves than tasks: the cut reports it instead of inventing owners
+    owner = np.zeros(4, dtype=np.int32)
+    c4 = np.array([5.0, 1.0, 1.0, 1.0])
+    assert have_lib.ngravs_host_split(c4.ctypes.data, None, 4, 8, 0.0, owner.ctypes.data) == -1
+    assert have_lib.ngravs_host_split(c4.ctypes.data, None, 4, 4, 0.0, owner.ctypes.data) == 0 and list(owner) == [0, 1, 2, 3]
