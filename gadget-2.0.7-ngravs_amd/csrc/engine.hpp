@@ -98,6 +98,9 @@ struct WalkParams
   double inv_asmthfac;
   double ec[4];   // (ym / asmthfac)^k / k!, k = 1..4: the polynomial in the bin fraction
   int src_in_box;   // every particle (and so every node centre of mass) lies inside [0, BoxSize]: groups away from the faces skip the image arithmetic
+  // the BAM / NGRAVS_ACCUMULATOR family in the group walk (tree-only wirings): law ids [target][source] and the flag that one is wired
+  int bam;
+  int law_accel[NG_MAX][NG_MAX], law_spline[NG_MAX][NG_MAX];
 
 };
 

@@ -894,6 +894,14 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         }
       // law coefficients and table row of this lane against the source species being evaluated (set by phase2)
       double cNg = 0, cYg = 0, cSg = 0;
+      // BAM / NGRAVS_ACCUMULATOR laws (ngravs.c:495-668; tree-only, non-periodic wirings: this instantiation only): they depend on the
+      // TARGET's mass and on the particle number behind the source, so the lane keeps its mass and the ids of its two laws
+      constexpr bool BAMCAP = !PM && !LATT && !YUK;
+      double pmassT = 1.0;
+      int lawA = 0, lawS = 0;
+      if constexpr(BAMCAP)
+        if(wp.bam && valid)
+          pmassT = s_pm[ti].w;
       const double *trow = tabp;
       const double *const etab = (PM && TAB_LDS) ? tab_s + (size_t)wp.ntab_lds * NTAB : table + (size_t)NG * NG * NTAB;
       // group bounding box and the conservative scalars
@@ -1081,6 +1089,23 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 fac[k] = soft ? fs : fac[k];
               }
           }
+        if constexpr(BAMCAP)
+          if(wp.bam)
+            {
+#pragma unroll
+              for(int k = 0; k < ES; k++)
+                {
+                  // forcetree.c:1534-1583 with AccelFxns / AccelSplines of the BAM family: f(target mass, source mass, r, N)
+                  const int je = is_act(k) ? jj[k] : 127;
+                  const double h = __builtin_fmax(hT, fsT[lty[je]]);
+                  const double Nn = (double)__float_as_int(le2[je]);
+                  double f = 0.0;
+                  if(mw[k] != 0.0)   // (the NULL entry: no mass, and its slot holds no particle number)
+                    f = r[k] >= h ? law_accel_ref(lawA, mw[k], r2[k], r[k], wp.ym, pmassT, Nn, wp.bam_eps) * rinv[k]
+                                  : law_spline_ref(lawS, mw[k], h, r[k], pmassT, Nn, wp.bam_eps);
+                  fac[k] = f;
+                }
+            }
 #pragma unroll
         for(int k = 0; k < ES; k++)
           {
@@ -1202,6 +1227,12 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
         cNg = wp.cN[tg][g];
         cYg = wp.cY[tg][g];
         cSg = wp.cS[tg][g];
+        if constexpr(BAMCAP)
+          if(wp.bam)
+            {
+              lawA = wp.law_accel[tg][g];
+              lawS = wp.law_spline[tg][g];
+            }
         if(PM && TAB_LDS)
           trow = tabp + (size_t)wp.tab_slot[tg * NG + g] * NTAB;
         else
@@ -1260,13 +1291,17 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           if(hv)
             {
               const int k = -1 - item;   // monopole: node * NG + g
+              int nsrc = 0;              // BAM laws: Nparticles[] of the node (allvars.h:645-648), 1 for a particle; carried above the type bits
+              if constexpr(BAMCAP)
+                if(wp.bam)
+                  nsrc = (item >= 0 ? 1 : tv.npart[k]) << 3;
               if(usoft)
                 {
                   // one softening length for all types: a single 32-byte gather per item, no type / flag bytes (each of
                   // which would pull another cache line)
                   const double4 *src = item >= 0 ? s_pm + item : tv.mom + k;
                   q = *src;
-                  hs = 0;
+                  hs = nsrc;
                 }
               else
                 {
@@ -1280,7 +1315,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     ty = s_type[item];
                   else
                     ty = (tv.flags[k / NG] >> 2) & 7;
-                  hs = ty;
+                  hs = ty | nsrc;
                 }
             }
         };
@@ -1327,12 +1362,15 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
               {
                 const int o = npool + lane_prefix(lm);
                 pp[o] = q;
-                ph[o] = (unsigned char)hs;
+                ph[o] = (unsigned char)(hs & 7);
                 const float fx = (float)ex, fy = (float)ey, fz = (float)ez;
                 lfx[o] = fx;
                 lfy[o] = fy;
                 lfz[o] = fz;
                 le2[o] = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                if constexpr(BAMCAP)
+                  if(wp.bam)
+                    le2[o] = __int_as_float(hs >> 3);   // tree-only walks build no fp32 masks: the slot carries the particle number
               }
             npool += __popcll(lm);
             {
@@ -1628,7 +1666,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 {
                   first = tv.first[my];
                   count = tv.count[my];
-                  double r2min = BIG, summass = 0;
+                  double r2min = BIG, r2far = 0, summass = 0;   // r2far: the largest of the species' distances, each to the nearest point of the box
 #pragma unroll
                   for(int g = 0; g < NG; g++)
                     {
@@ -1645,6 +1683,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       double a0 = fmax(0.0, fabs(dx) - bhx), a1 = fmax(0.0, fabs(dy) - bhy), a2 = fmax(0.0, fabs(dz) - bhz);
                       double r2g = a0 * a0 + a1 * a1 + a2 * a2;
                       r2min = r2g < r2min ? r2g : r2min;
+                      r2far = r2g > r2far ? r2g : r2far;
                     }
                   // (ii) the reference's own cut (forcetree.c:1828-1862) holds for every target
                   if(PM && r2min > wp.rcut2)
@@ -1666,7 +1705,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                                    (fabs(cz) - bhz < 0.60 * len);
                         }
                       const double hs_node = usoft ? wp.fsoft[0] : wp.fsoft[mst];   // no dependent table load when all types share one length
-                      if(!open && hT_min < hs_node && r2min < hs_node * hs_node && ((fl >> 5) & 1))
+                      // forcetree.c:1488-1499: a target opens a node of mixed softening if r2max -- the LARGEST of its distances to the
+                      // species' centres of mass -- is inside the softening length.  Every target's r2max is at least r2far (each
+                      // distance to the box is a lower bound), so r2far < h^2 whenever any target would open: conservative, and
+                      // for a one-target box exactly the reference's test
+                      if(!open && hT_min < hs_node && r2far < hs_node * hs_node && ((fl >> 5) & 1))
                         open = true;
                       if(open)
                         dec = ((fl & FLAG_BUCKET) || (count <= wp.nleaf && !(fl & FLAG_PARTIAL))) ? 3 : 2;
@@ -2110,6 +2153,13 @@ void make_walk_params(const ngravs_ctx *c, WalkParams *wp)
     wp->ec[2] = ub * ub * ub / 6.0;
     wp->ec[3] = ub * ub * ub * ub / 24.0;
   }
+  wp->bam = cfg_has_bam(cfg) ? 1 : 0;
+  for(int i = 0; i < NG_MAX; i++)
+    for(int j = 0; j < NG_MAX; j++)
+      {
+        wp->law_accel[i][j] = (i < cfg.n_gravs && j < cfg.n_gravs) ? cfg.law_accel[i][j] : NGRAVS_LAW_NONE;
+        wp->law_spline[i][j] = (i < cfg.n_gravs && j < cfg.n_gravs) ? cfg.law_spline[i][j] : NGRAVS_SPLINE_NONE;
+      }
   wp->fac_intp = cfg.box_size > 0 ? 2.0 * LAT_EN / cfg.box_size : 0.0;   // forcetree.c:3737
   for(int t = 0; t < NGRAVS_NTYPES; t++)
     {
@@ -2513,7 +2563,7 @@ int walk_run(ngravs_ctx *c)
   LawIds li;
   make_law_ids(c, &li);
   c->walk_ntargets = -1;
-  const bool strict = c->cfg.walk_mode == NGRAVS_WALK_STRICT || cfg_has_bam(c->cfg);
+  const bool strict = c->cfg.walk_mode == NGRAVS_WALK_STRICT;   // (the BAM laws run in the group walk too: wp.bam)
   if(c->top.on && c->cfg.pmgrid)
     {
       // multi-task tree: the leaves this task imported were chosen for the reach of the walk mode in force at the decomposition
@@ -2578,8 +2628,7 @@ int walk_run(ngravs_ctx *c)
         break;
       }
   };
-  // the BAM laws depend on the target's mass and on per-node particle counts: only the reference walk evaluates them
-  if(c->cfg.walk_mode == NGRAVS_WALK_STRICT || cfg_has_bam(c->cfg))
+  if(strict)
     strict_launch();
   else
     {
@@ -2599,6 +2648,8 @@ int walk_run(ngravs_ctx *c)
           if(c->walk_spread <= 1)
             c->walk_spread = 0;
         }
+      else if(c->walk_ntargets >= 0 && !c->walk_dense_tlist && c->tune.walk_spread > 1)
+        c->walk_spread = c->tune.walk_spread;   // tree-only walks: sub-groups only on request (tests: one target per wave)
       rc = group_launch(true, nullptr, 0);
     }
   if(rc != NGRAVS_OK)

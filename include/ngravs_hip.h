@@ -58,7 +58,7 @@ typedef enum {
   NGRAVS_LAW_COLOYUK = 4,     /* coloyuk :826, pgcoloyuk :830, normed_pgcoloyuk :834  */
   /* The BAM family (ngravs.c:495-668, NGRAVS_ACCUMULATOR_TESTING wiring :163-210): laws that depend on the TARGET mass and
    * on the number N of particles of the source species a node holds (allvars.h:645-648).  Tree-only (their Green's functions
-   * are `none`); evaluated by the reference walk (NGRAVS_WALK_STRICT) and the direct sum. */
+   * are `none`); evaluated by both walks and the direct sum. */
   NGRAVS_LAW_BAMBAM = 5,      /* bambam :495             BAM target, BAM source              */
   NGRAVS_LAW_SOURCEBAM = 6,   /* sourcebambaryon :590    baryon target, BAM source            */
   NGRAVS_LAW_TARGETBAM = 7,   /* sourcebaryonbam :646    BAM target, baryon source            */

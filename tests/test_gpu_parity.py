@@ -347,6 +347,38 @@ def test_group_walk_kernels_reproduce_the_reference_interaction_set(pkg, O, wiri
     assert np.all(acc[active == 0] == 0)
 
 
+@pytest.mark.parametrize("theta", [0.5, 0.0])
+def test_group_walk_kernels_reproduce_the_reference_set_tree_only(pkg, O, theta):
+    """The same for a tree-only, non-periodic set (no cut, no tables: other instantiations of the same kernels): Plummer sphere,
+    two species with DIFFERENT softening lengths (the per-source softening type travels through the pool), Barnes-Hut and relative
+    criterion; one target per wave, no leaf shortcut, start at the root -> the oracle's forces to rounding."""
+    n = 20000
+    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=78)
+    typ = (1 + (np.arange(n) % 2)).astype(np.int32)
+    cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[0.01, 0.01, 0.03, 0.01, 0.01, 0.01],
+                          type_to_grav=pkg.ic.default_type_to_grav(2), wiring="newton", walk_mode=pkg.WALK_STRICT)
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=False)
+    _, old, _ = eng.get_accel()
+    eng.close()
+    cfg.err_tol_theta = theta
+    active = (np.random.default_rng(6).uniform(size=n) < 0.3).astype(np.uint8)
+    idx = np.nonzero(active)[0].astype(np.int32)
+    T = O.Tree(cfg, pos, mass, typ, O.domain_extent(pos))
+    a_o, n_o = T.walk(old_acc=old, idx=idx)
+    cfg.walk_mode = pkg.WALK_GROUP
+    for fused in (0, 1):
+        eng = _engine(pkg, cfg, pos, mass, typ, old_acc=old, active=active,
+                      tuning={"walk_spread": 64, "walk_nleaf": 0, "walk_root": 1, "walk_sg": 1, "walk_fused": fused})
+        eng.compute_accelerations(pm_step=False)
+        acc, _, cost = eng.get_accel()
+        eng.close()
+        err = np.abs(acc[idx] / cfg.G - a_o).max() / np.abs(a_o).max()
+        print("tree-only group-walk kernels (%s), one target per wave, theta=%g: max force diff %.1e; %.1f (oracle %.1f) interactions" %
+              ("fused" if fused else "split", theta, err, cost[idx].mean(), n_o.mean()))
+        assert err < 1e-11 and np.all(cost[idx] >= n_o)
+
+
 @pytest.mark.parametrize("ng", [2, 3])
 def test_production_walk_is_the_cut_direct_sum(pkg, O, ng):
     """The production configuration of the production kernels -- 64 targets per wave, traversal units of four groups, sphere cut at
@@ -656,7 +688,8 @@ def test_bam_laws_strict_walk_and_direct_sum(pkg, O):
     the TARGET mass and of the number of particles of the source species a node holds (allvars.h:645-648).  Baryons (species
     0) and BAM halos (species 1) with unequal masses so that both dependences matter; the reference walk on the GPU must equal
     the oracle (1e-10, identical interaction counts), the GPU direct sum the oracle's, and the tree error against the direct
-    sum stays at the tree's level.  A group-walk request is served by the reference walk for these laws."""
+    sum stays at the tree's level.  The GROUP walk evaluates the same laws in its own force loop (target mass per lane, particle
+    number per pool entry): conservative group decisions, so at least the reference walk's interactions and accuracy."""
     n = 20000
     pos, mass, typ = pkg.ic.plummer_sphere(n, seed=77)
     rng = np.random.default_rng(3)
@@ -670,20 +703,39 @@ def test_bam_laws_strict_walk_and_direct_sum(pkg, O):
     a_o, _ = O.finish(cfg, a_o)
     idx = np.arange(0, n, 50, dtype=np.int32)
     d_o = O.direct(cfg, pos, mass, typ, idx)
-    for mode in (pkg.WALK_STRICT, pkg.WALK_GROUP):
-        cfg.walk_mode = mode
-        eng = _engine(pkg, cfg, pos, mass, typ)
-        eng.compute_accelerations(pm_step=False)
-        acc, _, cost = eng.get_accel()
-        d_g = eng.direct_sum(idx)
-        eng.close()
-        assert np.array_equal(cost.astype(np.int64), n_o.astype(np.int64))
-        assert np.abs(acc - a_o).max() / np.abs(a_o).max() < TOL
-        assert np.abs(d_g - d_o).max() / np.abs(d_o).max() < 1e-11
+    cfg.walk_mode = pkg.WALK_STRICT
+    eng = _engine(pkg, cfg, pos, mass, typ)
+    eng.compute_accelerations(pm_step=False)
+    acc, _, cost = eng.get_accel()
+    d_g = eng.direct_sum(idx)
+    assert np.array_equal(cost.astype(np.int64), n_o.astype(np.int64))
+    assert np.abs(acc - a_o).max() / np.abs(a_o).max() < TOL
+    assert np.abs(d_g - d_o).max() / np.abs(d_o).max() < 1e-11
     e = rel_err(acc[idx], d_o)
     print("BAM wiring: strict == oracle, tree vs direct rms %.2e max %.2e, %.1f interactions/particle" %
           (np.sqrt(np.mean(e ** 2)), e.max(), n_o.mean()))
     assert np.sqrt(np.mean(e ** 2)) < 2e-2
+    # the production walk: its own kernels (split traversal + evaluation), and in one-target-per-wave mode the reference's set
+    eng.set_walk_mode(pkg.WALK_GROUP)
+    eng.gravity_tree()
+    acc_g, _, cost_g = eng.get_accel()
+    st = eng.stats()
+    eng.close()
+    eg = rel_err(acc_g[idx], d_o)
+    print("BAM wiring, group walk: tree vs direct rms %.2e max %.2e, %.1f interactions/particle (split kernels: %d launches)" %
+          (np.sqrt(np.mean(eg ** 2)), eg.max(), cost_g.mean(), int(st.reserved[5])))
+    assert st.reserved[5] >= 1
+    assert np.all(cost_g >= n_o) and np.sqrt(np.mean(eg ** 2)) <= 1.05 * np.sqrt(np.mean(e ** 2))
+    active = (np.random.default_rng(5).uniform(size=n) < 0.3).astype(np.uint8)
+    sel = np.nonzero(active)[0]
+    cfg.walk_mode = pkg.WALK_GROUP
+    eng = _engine(pkg, cfg, pos, mass, typ, tuning={"walk_spread": 64, "walk_nleaf": 0, "walk_root": 1, "walk_sg": 1}, active=active)
+    eng.compute_accelerations(pm_step=False)
+    acc1, _, cost1 = eng.get_accel()
+    eng.close()
+    err1 = np.abs(acc1[sel] - a_o[sel]).max() / np.abs(a_o).max()
+    print("BAM wiring, group-walk kernels with one target per wave: max force diff to the oracle %.1e" % err1)
+    assert err1 < 1e-10
 
 
 def test_bad_type_on_device_is_rejected(pkg):
