@@ -40,7 +40,7 @@ EXPORTS = [
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
-HOST_EXPORTS = ["ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
+HOST_EXPORTS = ["ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
                 "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
                 "ngravs_host_pm_seconds", "ngravs_host_toptree_init", "ngravs_host_toptree_from_children", "ngravs_host_toptree_adapt",
                 "ngravs_host_toptree_free", "ngravs_host_import_request"]

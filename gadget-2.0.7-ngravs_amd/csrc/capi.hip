@@ -1227,6 +1227,14 @@ extern "C" int ngravs_dd_get_toptree(ngravs_ctx *c, int32_t *nnode, const int32_
   return NGRAVS_OK;
 }
 
+extern "C" int ngravs_host_toptree_borrow(ngravs_ctx *c, ngravs_toptree *view)
+{
+  if(!c || !view)
+    return NGRAVS_ERR_ARG;
+  *view = c->top.h;
+  return NGRAVS_OK;
+}
+
 extern "C" int ngravs_dd_leaf_sums(ngravs_ctx *c, void **dev_sums, int64_t *count)
 {
   if(!c || !c->have_particles || !c->extent_override || !dev_sums || !count)

@@ -166,6 +166,26 @@ static int tt_finish(ngravs_toptree *t)
   return 0;
 }
 
+/* a copy of a finished tree (all tables), e.g. of the view ngravs_host_toptree_borrow() lends */
+static int tt_clone(const ngravs_toptree *src, ngravs_toptree *out)
+{
+  CHECK(tt_alloc(out, src->nnode));
+  memcpy(out->child, src->child, sizeof(int32_t) * (size_t)src->nnode);
+  memcpy(out->level, src->level, sizeof(int32_t) * (size_t)src->nnode);
+  memcpy(out->leaf, src->leaf, sizeof(int32_t) * (size_t)src->nnode);
+  memcpy(out->xyz, src->xyz, sizeof(int32_t) * 3 * (size_t)src->nnode);
+  out->nleaf = src->nleaf;
+  out->depth = src->depth;
+  out->node_of_leaf = malloc(sizeof(int32_t) * (size_t)(src->nleaf > 0 ? src->nleaf : 1));
+  if(!out->node_of_leaf)
+    {
+      ngravs_host_toptree_free(out);
+      return NGRAVS_ERR_NOMEM;
+    }
+  memcpy(out->node_of_leaf, src->node_of_leaf, sizeof(int32_t) * (size_t)src->nleaf);
+  return 0;
+}
+
 int ngravs_host_toptree_from_children(ngravs_toptree *t, const int32_t *child, int32_t nnode)
 {
   int rc;
@@ -244,6 +264,19 @@ int ngravs_host_toptree_adapt(const ngravs_toptree *t, const double *leaf_count,
       free(cnt);
       return rc;
     }
+  {
+    /* the steady state: no leaf to split, no subtree to merge -- the tree stays (out->nnode = 0 says so; nothing is built) */
+    int violated = t->child[0] < 0;
+    for(i = 1; i < t->nnode && !violated; i++)
+      if(t->child[i] < 0 ? (cnt[i] > thresh && t->level[i] < max_level) : !(cnt[i] > thresh && t->level[i] < max_level))
+        violated = 1;
+    if(!violated)
+      {
+        free(cnt);
+        memset(out, 0, sizeof(*out));
+        return 0;
+      }
+  }
   cap = (int64_t)t->nnode + 64;
   for(i = 0; i < t->nnode; i++)
     if(t->child[i] < 0 && cnt[i] > thresh)
@@ -337,38 +370,44 @@ int ngravs_host_toptree_adapt(const ngravs_toptree *t, const double *leaf_count,
  *  each (whether a B is feasible is a greedy sweep; B is found by bisection on the real line), then the greedy cut for that B,
  *  every task keeping at least one leaf.
  * ========================================================================================================================= */
-static int cut_sweep(const double *count, const double *work, int64_t n, int ntask, double B, double max_load, int32_t *owner)
+/* prefix sums pw[i] = work of leaves [0, i), pc[i] = count of leaves [0, i): a task that starts at leaf `first` takes the longest
+ * run with work <= B and count <= max_load (both prefix sums are monotone: one binary search), at least one leaf, and leaves one
+ * leaf for every later task */
+static int cut_sweep(const double *pw, const double *pc, int64_t n, int ntask, double B, double max_load, int32_t *owner)
 {
-  int64_t i = 0;
+  int64_t i = 0, k;
   int t;
   for(t = 0; t < ntask; t++)
     {
-      double w = 0, c = 0;
-      const int64_t must_leave = ntask - 1 - t;   /* leaves the later tasks need (one each) */
-      const int64_t first = i;
-      while(i < n - must_leave)
-        {
-          if(i > first && (w + work[i] > B || c + count[i] > max_load))
-            break;
-          if(i == first && count[i] > max_load)
-            return -1;   /* one leaf alone breaks the memory bound */
-          w += work[i];
-          c += count[i];
-          if(owner)
-            owner[i] = t;
-          i++;
-        }
-      if(i == first)
+      const int64_t limit = n - (ntask - 1 - t);   /* exclusive end this task may reach */
+      int64_t lo = i, hi = limit;                  /* largest e in [i, limit] with the run [i, e) within both bounds */
+      if(i >= limit)
         return -1;
+      if(pc[i + 1] - pc[i] > max_load)
+        return -1;   /* one leaf alone breaks the memory bound */
+      while(lo < hi)
+        {
+          const int64_t mid = (lo + hi + 1) >> 1;
+          if(pw[mid] - pw[i] <= B && pc[mid] - pc[i] <= max_load)
+            lo = mid;
+          else
+            hi = mid - 1;
+        }
+      if(lo == i)
+        lo = i + 1;   /* a task takes at least one leaf (the caller's B is never below the heaviest leaf, up to rounding) */
+      if(owner)
+        for(k = i; k < lo; k++)
+          owner[k] = t;
+      i = lo;
     }
   return i == n ? 0 : -1;
 }
 
 int ngravs_host_split(const double *count, const double *work, int64_t nleaf, int ntask, double max_load, int32_t *owner)
 {
-  double lo = 0, hi = 0, wmax = 0;
+  double lo = 0, hi = 0, wmax = 0, *pw, *pc;
   int64_t i;
-  int it;
+  int it, rc;
   if(!count || !owner || ntask < 1 || nleaf < ntask)
     return -1;
   if(!work)
@@ -381,28 +420,39 @@ int ngravs_host_split(const double *count, const double *work, int64_t nleaf, in
         owner[i] = 0;
       return 0;
     }
+  pw = malloc(sizeof(double) * 2 * (size_t)(nleaf + 1));
+  if(!pw)
+    return -1;
+  pc = pw + nleaf + 1;
+  pw[0] = pc[0] = 0;
   for(i = 0; i < nleaf; i++)
     {
-      hi += work[i];
+      pw[i + 1] = pw[i] + work[i];
+      pc[i + 1] = pc[i] + count[i];
       if(work[i] > wmax)
         wmax = work[i];
     }
-  hi = hi * (1.0 + 1e-12) + 1e-300;
-  if(cut_sweep(count, work, nleaf, ntask, hi, max_load, NULL))
-    return -1;   /* the memory bound alone cannot be met */
-  lo = fmax(wmax, hi / ntask) * (1.0 - 1e-12);
-  if(cut_sweep(count, work, nleaf, ntask, lo, max_load, NULL) == 0)
+  hi = pw[nleaf] * (1.0 + 1e-12) + 1e-300;
+  if(cut_sweep(pw, pc, nleaf, ntask, hi, max_load, NULL))
+    {
+      free(pw);
+      return -1;   /* the memory bound alone cannot be met */
+    }
+  lo = fmax(wmax, pw[nleaf] / ntask) * (1.0 - 1e-12);
+  if(cut_sweep(pw, pc, nleaf, ntask, lo, max_load, NULL) == 0)
     hi = lo;
   else
     for(it = 0; it < 64 && hi - lo > 1e-13 * hi; it++)
       {
         const double mid = 0.5 * (lo + hi);
-        if(cut_sweep(count, work, nleaf, ntask, mid, max_load, NULL) == 0)
+        if(cut_sweep(pw, pc, nleaf, ntask, mid, max_load, NULL) == 0)
           hi = mid;
         else
           lo = mid;
       }
-  return cut_sweep(count, work, nleaf, ntask, hi, max_load, owner);
+  rc = cut_sweep(pw, pc, nleaf, ntask, hi, max_load, owner);
+  free(pw);
+  return rc;
 }
 
 /* =========================================================================================================================
@@ -763,11 +813,10 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double lea
    * with about the threshold */
   if(!rc)
     {
-      const int32_t *child = NULL;
-      int32_t nn = 0;
-      rc = ngravs_dd_get_toptree(ctx, &nn, &child);
-      if(!rc && nn > 0)
-        rc = ngravs_host_toptree_from_children(&tree, child, nn);
+      ngravs_toptree view;
+      rc = ngravs_host_toptree_borrow(ctx, &view);   /* the library's finished copy of the last tree: levels, coordinates, leaf numbers */
+      if(!rc && view.nnode > 0)
+        rc = tt_clone(&view, &tree);
       else if(!rc)
         {
           const double guess = n_own * W, lm = leaf_max > 0 ? leaf_max : fmin(NGRAVS_TOPLEAF_MAX, guess / (20.0 * W));
@@ -822,7 +871,7 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double lea
           rc = unknown;
           break;
         }
-      if(unknown == 0 && next.nnode == tree.nnode)
+      if(unknown == 0 && (next.nnode == 0 || next.nnode == tree.nnode))
         {
           ngravs_host_toptree_free(&next);
           break;   /* the tree obeys the rule and is the one these sums were taken for */

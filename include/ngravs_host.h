@@ -129,9 +129,13 @@ int ngravs_host_toptree_from_children(ngravs_toptree *t, const int32_t *child, i
 /* One round of domain_topsplit (domain.c:1060-1138) on a tree whose leaf counts are known: a leaf with more than `thresh`
  * particles is split (below level max_level; the root always is), a split node that holds <= thresh particles becomes a leaf
  * again.  leaf_count: global particle count per leaf of `t`.  out: the new tree.  Returns the number of leaves of `out` whose
- * counts are not known from `t` (0 and the same node count: the tree obeys the rule and did not change), or a negative status. */
+ * counts are not known from `t`, or a negative status.  If nothing violates the rule the tree stays: returns 0 with
+ * out->nnode == 0 (nothing is built -- the steady state costs one pass over the node counts). */
 int ngravs_host_toptree_adapt(const ngravs_toptree *t, const double *leaf_count, double thresh, int max_level, ngravs_toptree *out);
 void ngravs_host_toptree_free(ngravs_toptree *t);
+/* the tree the context holds (ngravs_dd_set_toptree), with all its tables, as a VIEW: the pointers belong to the library and stay
+ * valid until the next ngravs_dd_set_toptree(); nnode 0: none yet.  Do not free. */
+int ngravs_host_toptree_borrow(ngravs_ctx *ctx, ngravs_toptree *view);
 /* The cut alone: owner[leaf] for the leaves in curve order from the global count and work per leaf: contiguous segments,
  * the largest work sum of a task as small as the memory bound count <= max_load allows.  Returns 0, or -1 if no cut respects
  * max_load. */

@@ -100,7 +100,7 @@ def build_toptree(lib, key21, thresh, start_level=1, max_level=18):
         unknown = lib.ngravs_host_toptree_adapt(C.byref(t), cnt.ctypes.data, float(thresh), max_level, C.byref(nxt))
         assert unknown >= 0
         rounds += 1
-        if unknown == 0 and nxt.nnode == t.nnode:
+        if unknown == 0 and nxt.nnode in (0, t.nnode):
             lib.ngravs_host_toptree_free(C.byref(nxt))
             return t, cnt, rounds
         lib.ngravs_host_toptree_free(C.byref(t))

@@ -77,7 +77,7 @@ def _worker(rank, world, port, out_dir, name):
         unknown = L.ngravs_host_toptree_adapt(C.byref(t), cnt.ctypes.data, thresh, 18, C.byref(nxt))
         assert unknown >= 0
         rounds += 1
-        if unknown == 0 and nxt.nnode == t.nnode:
+        if unknown == 0 and nxt.nnode in (0, t.nnode):
             L.ngravs_host_toptree_free(C.byref(nxt))
             break
         L.ngravs_host_toptree_free(C.byref(t))
