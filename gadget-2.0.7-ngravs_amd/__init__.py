@@ -34,7 +34,7 @@ EXPORTS = [
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum", "ngravs_direct_sum_targets",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
-    "ngravs_dd_get_toptree", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
+    "ngravs_dd_get_toptree", "ngravs_dd_peano_order", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
     "ngravs_dd_pack_leaves", "ngravs_dd_set_top", "ngravs_dd_recv_buffer", "ngravs_dd_apply_migration", "ngravs_dd_set_halo",
     "ngravs_dd_set_ids", "ngravs_dd_get_ids",
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",

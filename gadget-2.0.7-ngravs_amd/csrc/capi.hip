@@ -1193,6 +1193,16 @@ extern "C" int ngravs_dd_local_extent(ngravs_ctx *c, double lo[3], double hi[3])
   return dd_local_extent(c, lo, hi);
 }
 
+extern "C" int ngravs_dd_peano_order(ngravs_ctx *c, int force)
+{
+  if(!c || !c->have_particles)
+    return NGRAVS_ERR_STATE;
+  (void)hipSetDevice(c->cfg.device);
+  if(int rc = park_grav_pm(c))   // GravPM leaves the old order first: it moves with the rows as a caller-order column
+    return rc;
+  return dd_peano_order_own(c, force);
+}
+
 extern "C" int ngravs_dd_set_extent(ngravs_ctx *c, const double lo[3], const double hi[3])
 {
   if(!c)

@@ -159,6 +159,8 @@ struct PmSlab
   long long edesc_off = 0;                 // stage 3: where the extended-brick plane descriptors start in desc
   DevBuf<double> brick, slab, tbuf, ebrick, fmesh, send, recv;
   DevBuf<long long> desc;
+  std::vector<long long> hdesc[2];         // host copies of the descriptor tables in flight (upload_desc)
+  int hdesc_turn = 0;
   void *plan2f = nullptr, *plan2i = nullptr, *plan1 = nullptr;
   int plan_N = 0, plan_nx = 0, plan_ny = 0;
   double bytes_sent[4] = {0, 0, 0, 0};     // payload of the last step's four exchanges (this task, bytes)
@@ -277,6 +279,7 @@ int dd_target_bounds(ngravs_ctx *c, double out[2]);
 int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec);
 int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *present);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_peano_order_own(ngravs_ctx *c, int force);
 int dd_fill_ids(ngravs_ctx *c);
 int dd_record_doubles(const ngravs_ctx *c, int what);
 // ---- kernels_tree.hip

@@ -161,14 +161,24 @@ __global__ void k_keys(const double *__restrict__ pos, long long n, double cx, d
 }
 
 // gather the caller-order columns into Peano order
+// jumps (optional): how many rows (of every 64th block) are NOT next to the row before them in caller order (more than 64 rows apart): the measure of how
+// far the caller-order columns are from Peano order -- every such row is a scattered read here and in every pass that visits the
+// rows in Peano order (dd_peano_order_own puts the columns in order when most reads have become jumps)
 __global__ void k_gather(const unsigned int *__restrict__ idx, long long n, const double2 *__restrict__ rec,
                          double4 *__restrict__ s_pm, unsigned char *__restrict__ s_type,
-                         double *__restrict__ s_oldacc, unsigned char *__restrict__ s_active)
+                         double *__restrict__ s_oldacc, unsigned char *__restrict__ s_active, int *__restrict__ jumps = nullptr)
 {
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
     return;
   const long long j = idx[i];
+  if(jumps && (blockIdx.x & 63) == 0)   // a sample: every 64th block (the counter is one word for the whole grid)
+    {
+      const long long jp = i > 0 ? (long long)idx[i - 1] : j, d = j - jp;
+      const unsigned long long jm = __builtin_amdgcn_ballot_w64(d > 64 || d < -64);
+      if(jm && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+        atomicAdd(jumps, (int)__popcll(jm));
+    }
   const double2 a = rec[3 * j + 0], b = rec[3 * j + 1], d = rec[3 * j + 2];
   double4 v;
   v.x = a.x;
@@ -261,8 +271,9 @@ int dom_keys_and_sort(ngravs_ctx *c)
   if(full)
     HIP_TRY(c, hipcub::DeviceRadixSort::SortPairs(c->sort_tmp.p, tmp_bytes, c->in_key.p, c->s_key.p, c->idx_iota.p,
                                                   c->s_idx.p, (int)n, 0, 3 * TREE_BITS, c->stream));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters.p + 14, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(k_gather, dim3(nb), dim3(bs), 0, c->stream, c->s_idx.p, n, c->in_rec.p, c->s_pm.p, c->s_type.p,
-                     c->s_oldacc.p, c->s_active.p);
+                     c->s_oldacc.p, c->s_active.p, c->d_counters.p + 14);
   HIP_TRY(c, hipGetLastError());
   return NGRAVS_OK;
 }
@@ -860,9 +871,13 @@ __global__ void k_dd_bounds(const double *__restrict__ oldacc, const int *__rest
     }
   if((threadIdx.x & 63) == 0)
     {
-      // doubles >= 0 order like their bit patterns
-      atomicMin((unsigned long long *)&out[0], (unsigned long long)__double_as_longlong(a));
-      atomicMin((unsigned long long *)&out[1], (unsigned long long)__double_as_longlong(h));
+      // doubles >= 0 order like their bit patterns; an atomic only where the wave lowers the bound (the two words are shared by
+      // the whole grid: unconditional atomics queue up there)
+      const unsigned long long ua = (unsigned long long)__double_as_longlong(a), uh = (unsigned long long)__double_as_longlong(h);
+      if(ua < __atomic_load_n((unsigned long long *)&out[0], __ATOMIC_RELAXED))
+        atomicMin((unsigned long long *)&out[0], ua);
+      if(uh < __atomic_load_n((unsigned long long *)&out[1], __ATOMIC_RELAXED))
+        atomicMin((unsigned long long *)&out[1], uh);
     }
 }
 
@@ -875,7 +890,7 @@ int dd_target_bounds(ngravs_ctx *c, double out[2])
   WalkParams wp;
   make_walk_params(c, &wp);
   if(c->n_local > 0)
-    hipLaunchKernelGGL(k_dd_bounds, dim3(512), dim3(256), 0, c->stream, c->in_oldacc.p, c->in_type.p, c->in_active.p, (long long)c->n_local,
+    hipLaunchKernelGGL(k_dd_bounds, dim3(2048), dim3(256), 0, c->stream, c->in_oldacc.p, c->in_type.p, c->in_active.p, (long long)c->n_local,
                        wp, c->red_tmp.p);
   HIP_TRY(c, hipMemcpyAsync(out, c->red_tmp.p, sizeof(big), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1025,6 +1040,103 @@ int dd_apply_migration(ngravs_ctx *c, const void *dev_records, int64_t nrec)
   c->own_order_nlocal = -1;   // rows moved: the old order no longer names them
   c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
   return NGRAVS_OK;
+}
+
+// ---- peano_hilbert_order() of the own rows (peano.c:36-90, reorder_particles :261-312) -------------------------------------------
+// The reference sorts P[] itself along the curve at the end of every decomposition, so that whatever visits particles in tree
+// order reads memory in order.  The caller-order columns here are the library's own copy in the library-driven decomposition
+// (rows are named by ID, ngravs_get_ids): when most of the last gather's reads were jumps they are put into the Peano order of
+// that decomposition, once -- afterwards the order only drifts with the particles, and the per-leaf sums, the key pass and the
+// gather of the following steps read coalesced.
+struct OwnRow
+{
+  unsigned int nl;
+  __device__ bool operator()(unsigned int row) const { return row < nl; }
+};
+
+__global__ void k_dd_reorder(const unsigned int *__restrict__ rows, long long nl, const double *__restrict__ pos,
+                             const double *__restrict__ mass, const int *__restrict__ type, const double *__restrict__ oldacc,
+                             const unsigned char *__restrict__ active, const long long *__restrict__ id, const double *__restrict__ cost,
+                             const double *__restrict__ pm, double *__restrict__ pos2, double *__restrict__ mass2, int *__restrict__ type2,
+                             double *__restrict__ oldacc2, unsigned char *__restrict__ active2, long long *__restrict__ id2,
+                             double *__restrict__ cost2, double *__restrict__ pm2)
+{
+  const long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(k >= nl)
+    return;
+  const long long i = rows[k];
+  pos2[3 * k + 0] = pos[3 * i + 0];
+  pos2[3 * k + 1] = pos[3 * i + 1];
+  pos2[3 * k + 2] = pos[3 * i + 2];
+  mass2[k] = mass[i];
+  type2[k] = type[i];
+  oldacc2[k] = oldacc[i];
+  active2[k] = active[i];
+  id2[k] = id[i];
+  cost2[k] = cost[i];
+  if(pm2)
+    for(int j = 0; j < 3; j++)
+      pm2[3 * k + j] = pm[3 * i + j];
+}
+
+// returns 1 if the rows were put in order, 0 if they were left (no order known, or close enough to it), < 0: status
+int dd_peano_order_own(ngravs_ctx *c, int force)
+{
+  const long long nl = c->n_local, len = c->own_order_len;
+  if(c->own_order_nlocal != nl || len < nl || !c->s_idx.p || nl < 1 || !c->in_id.p || !c->in_cost.p || !c->d_counters.p)
+    return 0;
+  int jumps = 0;
+  HIP_TRY(c, hipMemcpyAsync(&jumps, c->d_counters.p + 14, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if(!force && (long long)jumps * 64 * 8 < len)   // (every 64th block counts) fewer than 1 read in 8 leaves its neighbourhood: in order
+    return 0;
+  // the own rows in Peano order: s_idx without the imported copies (rows >= n_local)
+  if(c->idx_iota.ensure((size_t)len))
+    return NGRAVS_ERR_NOMEM;
+  size_t tmp_bytes = 0;
+  OwnRow own;
+  own.nl = (unsigned int)nl;
+  (void)hipcub::DeviceSelect::If(nullptr, tmp_bytes, c->s_idx.p, c->idx_iota.p, c->d_counters.p + 14, (int)len, own, c->stream);
+  if(c->sort_tmp.ensure(tmp_bytes))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipcub::DeviceSelect::If(c->sort_tmp.p, tmp_bytes, c->s_idx.p, c->idx_iota.p, c->d_counters.p + 14, (int)len, own, c->stream));
+  int nsel = 0;
+  HIP_TRY(c, hipMemcpyAsync(&nsel, c->d_counters.p + 14, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if(nsel != nl)
+    {
+      ngravs_report(c, NGRAVS_ERR_STATE, "peano order of the own rows: the stored order does not name every own row once");
+      return NGRAVS_ERR_STATE;
+    }
+  DevBuf<double> pos2, mass2, old2, cost2, pm2;
+  DevBuf<int> type2;
+  DevBuf<unsigned char> act2;
+  DevBuf<long long> id2;
+  const size_t cap = (size_t)nl + 64;
+  const bool with_pm = c->pm_parked && c->pm_orig.p;
+  if(pos2.ensure(3 * cap) || mass2.ensure(cap) || old2.ensure(cap) || type2.ensure(cap) || act2.ensure(cap) || id2.ensure(cap) ||
+     cost2.ensure(cap) || (with_pm && pm2.ensure(3 * cap)))
+    {
+      pos2.release(), mass2.release(), old2.release(), type2.release(), act2.release(), id2.release(), cost2.release(), pm2.release();
+      return NGRAVS_ERR_NOMEM;
+    }
+  hipLaunchKernelGGL(k_dd_reorder, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, c->stream, c->idx_iota.p, nl, c->in_pos.p, c->in_mass.p,
+                     c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, with_pm ? c->pm_orig.p : (const double *)nullptr,
+                     pos2.p, mass2.p, type2.p, old2.p, act2.p, id2.p, cost2.p, with_pm ? pm2.p : (double *)nullptr);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->in_pos.release(), c->in_mass.release(), c->in_oldacc.release(), c->in_type.release(), c->in_active.release(), c->in_id.release(),
+      c->in_cost.release();
+  c->in_pos = pos2, c->in_mass = mass2, c->in_oldacc = old2, c->in_type = type2, c->in_active = act2, c->in_id = id2, c->in_cost = cost2;
+  if(with_pm)
+    {
+      c->pm_orig.release();
+      c->pm_orig = pm2;
+    }
+  c->n = nl;                  // the imported copies of the last step are gone with the order that named them
+  c->own_order_nlocal = -1;   // the rows ARE in that order now
+  c->have_order = c->have_tree = c->have_acc = false;
+  return 1;
 }
 
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)

@@ -54,11 +54,30 @@ __global__ void k_cell_minmax(const double4 *__restrict__ s_pm, const unsigned c
           lo[j] = a < lo[j] ? a : lo[j];
           hi[j] = b > hi[j] ? b : hi[j];
         }
-      if((threadIdx.x & 63) == 0)
+    }
+  // one value per block and bound, and only where it moves the bound: the six words are shared by the whole grid
+  __shared__ int sl[4][3], sh[4][3];
+  const int w = threadIdx.x >> 6;
+  if((threadIdx.x & 63) == 0)
+    for(int j = 0; j < 3; j++)
+      {
+        sl[w][j] = lo[j];
+        sh[w][j] = hi[j];
+      }
+  __syncthreads();
+  if(threadIdx.x < 3)
+    {
+      const int j = threadIdx.x;
+      int a = sl[0][j], b = sh[0][j];
+      for(int q = 1; q < (int)(blockDim.x >> 6); q++)
         {
-          atomicMin(&out[j], lo[j]);
-          atomicMax(&out[3 + j], hi[j]);
+          a = sl[q][j] < a ? sl[q][j] : a;
+          b = sh[q][j] > b ? sh[q][j] : b;
         }
+      if(a < __atomic_load_n(&out[j], __ATOMIC_RELAXED))
+        atomicMin(&out[j], a);
+      if(b > __atomic_load_n(&out[3 + j], __ATOMIC_RELAXED))
+        atomicMax(&out[3 + j], b);
     }
 }
 
@@ -529,7 +548,7 @@ int pmslab_begin(ngravs_ctx *c, int rank, int world, int bbox[6])
   int h[6] = {1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
   HIP_TRY(c, hipMemcpyAsync(c->d_counters.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
   if(n > 0)
-    hipLaunchKernelGGL(k_cell_minmax, dim3(512), dim3(256), 0, c->stream, c->s_pm.p, c->s_active.p, n, to_slab, N, c->d_counters.p);
+    hipLaunchKernelGGL(k_cell_minmax, dim3(2048), dim3(256), 0, c->stream, c->s_pm.p, c->s_active.p, n, to_slab, N, c->d_counters.p);
   HIP_TRY(c, hipMemcpyAsync(h, c->d_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   for(int j = 0; j < 3; j++)
@@ -604,8 +623,12 @@ static int upload_desc(ngravs_ctx *c, const std::vector<long long> &h)
     return NGRAVS_ERR_NOMEM;
   if(!h.empty())
     {
-      HIP_TRY(c, hipMemcpyAsync(s.desc.p, h.data(), sizeof(long long) * h.size(), hipMemcpyHostToDevice, c->stream));
-      HIP_TRY(c, hipStreamSynchronize(c->stream));   // h is a local of the caller
+      // h is a local of the caller: the copy reads one of two host vectors that live in the context, used in turn -- every pack
+      // stage ends in a stream synchronisation, so a vector's last copy has completed when its turn comes again (no wait here:
+      // the table follows the kernels already queued, the kernels that read it follow the table)
+      std::vector<long long> &keep = s.hdesc[s.hdesc_turn ^= 1];
+      keep.assign(h.begin(), h.end());
+      HIP_TRY(c, hipMemcpyAsync(s.desc.p, keep.data(), sizeof(long long) * keep.size(), hipMemcpyHostToDevice, c->stream));
     }
   return NGRAVS_OK;
 }

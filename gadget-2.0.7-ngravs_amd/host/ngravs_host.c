@@ -758,7 +758,17 @@ static int leaf_sums_round(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_
 }
 
 /* domain_findExtent + domain_determineTopTree + domain_sumCost + the cut (domain.c:882-924, 933-1138, 823-877, 347-544) */
+static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info,
+                         int own_rows);
+
 int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info)
+{
+  return domain_owners(ctx, cm, leaf_max, paf, plan, info, 0);
+}
+
+/* own_rows: the rows are the library's (ngravs_host_domain_decomposition: named by ID) -- it may put them in Peano order first */
+static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max, double paf, ngravs_dd_plan *plan, ngravs_dd_info *info,
+                         int own_rows)
 {
   ngravs_config_t cfg;
   ngravs_toptree tree, next;
@@ -779,6 +789,11 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double lea
   info->seconds[0] = -wall_now();
   rc = ngravs_get_config(ctx, &cfg);
   cw = NGRAVS_TOP_CW(cfg.n_gravs > 0 ? cfg.n_gravs : 1);
+  if(!rc && own_rows)
+    {
+      rc = ngravs_dd_peano_order(ctx, 0);   /* peano_hilbert_order() of P[] (domain.c:146), when the rows have left that order */
+      rc = rc > 0 ? 0 : rc;
+    }
   if(!rc)
     rc = ngravs_dd_local_extent(ctx, lo, hi);
   if(!rc)
@@ -1147,7 +1162,7 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, dou
   int rc;
   if(!info)
     info = &local;
-  CHECK(ngravs_host_domain_owners(ctx, cm, leaf_max, paf, &plan, info));
+  CHECK(domain_owners(ctx, cm, leaf_max, paf, &plan, info, 1));
   rc = domain_halo(ctx, cm, &plan, 1, info);
   ngravs_host_plan_free(&plan);
   return status_of(rc);

@@ -301,6 +301,14 @@ int ngravs_direct_sum_targets(ngravs_ctx *ctx, const double *pos, const double *
 int64_t ngravs_dd_record_bytes(ngravs_ctx *ctx, int what);
 int64_t ngravs_dd_num_local(ngravs_ctx *ctx);
 int ngravs_dd_local_extent(ngravs_ctx *ctx, double lo[3], double hi[3]);             /* domain.c:894-905 */
+/* peano_hilbert_order() of P[] (domain.c:146, peano.c:36-90, reorder_particles :261-312) for the library's OWN copy of the
+ * columns: the rows of the own particles are put into the Peano order of the last local decomposition, so that the passes that
+ * visit particles in tree order (per-leaf sums, keys, gather, result scatter) read memory in order.  Only for callers that name
+ * rows by ID (ngravs_dd_get_ids) -- the host layer's whole-decomposition driver (ngravs_host.h) calls it; a host that owns the row order (gadget_glue.c:
+ * P[] is the reference's, already in this order) never does.  force = 0: only when more than 1 in 8 reads of the last gather
+ * left its neighbourhood (64 rows).  Call it at the start of a step: imported copies, order, tree and results of the last
+ * step are gone afterwards.  Returns 1 if rows moved, 0 if they were left, < 0: status. */
+int ngravs_dd_peano_order(ngravs_ctx *ctx, int force);
 int ngravs_dd_set_extent(ngravs_ctx *ctx, const double lo[3], const double hi[3]);   /* result of domain.c:906-907 */
 /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac as set by ngravs_dd_set_extent (before the local Peano order exists) */
 int ngravs_get_domain_extent(ngravs_ctx *ctx, double out[8]);
