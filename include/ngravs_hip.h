@@ -225,7 +225,9 @@ int64_t ngravs_force_treebuild(ngravs_ctx *ctx);
 /* The dynamic tree update between rebuilds (predict.c:79-91 node drift + force_update_len(), forcetree.c:1005-1122,
  * and the node kicks of timestep.c:331-344), done as a refit: every node's per-species mass and centre of mass are
  * recomputed bottom-up from the current particle positions (exact, where the reference extrapolates them with node
- * velocities), softening flags likewise, and a cell's side grows to enclose what its particles now reach. */
+ * velocities; for N_GRAVS > 1 the reference's kick of a node adds a particle's dv to the node velocities of every species,
+ * timestep.c:337-340 -- the refit does not follow that), softening flags likewise, and a cell's side grows to
+ * enclose what its particles now reach. */
 int ngravs_force_update_tree(ngravs_ctx *ctx);
 /* gravity_tree(): walk for all active targets, OldAcc update, xG (gravtree.c:102-341). */
 int ngravs_gravity_tree(ngravs_ctx *ctx);

@@ -716,12 +716,20 @@ double orc_law_eval(const ngravs_config_t *cfg, int which, int id, double a3, do
  *   force_update_len -> force_update_node_len_local (forcetree.c:1005-1085): a particle that left its father's cell
  *       enlarges it to len = 2 max_k |Pos_k - center_k|, and the enlargement is handed up the father chain,
  *       len_p = 2 |center_p.x - center_no.x| + len_no while 0.999999 * that exceeds len_p.
- * (The node kicks of timestep.c:331-344 are not restated: they add a kicked particle's dv m/M to the node velocities of ALL
- * species -- a quirk that only matters for N_GRAVS > 1 -- and a pure drift never calls them.)
+ * Node kicks (timestep.c:331-344): when a particle is kicked by dv while the tree is kept, every ancestor's velocity of EVERY
+ * species k with mass gets dv * m / M_k -- for N_GRAVS = 1 exactly what keeps vs the mass-weighted mean velocity; for
+ * N_GRAVS > 1 the reference adds the kick of a particle to the node velocities of the species it does not belong to as well
+ * (restated as written).  orc_tree_drift_kicked: vs from the velocities the tree was built with, then the kicks dv, then the drift.
  * newpos = the drifted positions (the caller drifts the particles, as move_particles does); vel, dt the velocities and the
  * drift interval used for it.  The tree then refers to newpos.
  * ------------------------------------------------------------------------------------------ */
+void orc_tree_drift_kicked(orc_tree *t, const ngravs_config_t *cfg, const double *newpos, const double *vel, const double *dv, double dt);
 void orc_tree_drift(orc_tree *t, const ngravs_config_t *cfg, const double *newpos, const double *vel, double dt)
+{
+  orc_tree_drift_kicked(t, cfg, newpos, vel, NULL, dt);
+}
+
+void orc_tree_drift_kicked(orc_tree *t, const ngravs_config_t *cfg, const double *newpos, const double *vel, const double *dv, double dt)
 {
   const int ng = t->ng;
   const int64_t nn = t->numnodes;
@@ -736,11 +744,26 @@ void orc_tree_drift(orc_tree *t, const ngravs_config_t *cfg, const double *newpo
             vs[(a * 3 + j) * ng + g] += t->mass[i] * vel[3 * i + j];
         }
     }
+  for(int64_t a = 0; a < nn; a++)   /* force_update_node_recursive: vs = sum(m v) / M per species (forcetree.c:617-619, 674-676, 695-697) */
+    for(int g = 0; g < ng; g++)
+      if(t->nmass[a * ng + g] > 0)
+        for(int j = 0; j < 3; j++)
+          vs[(a * 3 + j) * ng + g] /= t->nmass[a * ng + g];
+  if(dv)
+    for(int64_t i = 0; i < t->n; i++)   /* timestep.c:331-344 */
+      for(int no = t->pfather[i]; no >= 0; no = t->father[no - t->maxpart])
+        {
+          const int64_t a = no - t->maxpart;
+          for(int j = 0; j < 3; j++)
+            for(int k = 0; k < ng; k++)
+              if(t->nmass[a * ng + k] > 0)
+                vs[(a * 3 + j) * ng + k] += dv[3 * i + j] * t->mass[i] / t->nmass[a * ng + k];
+        }
   for(int64_t a = 0; a < nn; a++)
     for(int g = 0; g < ng; g++)
       if(t->nmass[a * ng + g] > 0)
         for(int j = 0; j < 3; j++)
-          t->s[(a * 3 + j) * ng + g] += vs[(a * 3 + j) * ng + g] / t->nmass[a * ng + g] * dt;   /* predict.c:83-86 */
+          t->s[(a * 3 + j) * ng + g] += vs[(a * 3 + j) * ng + g] * dt;   /* predict.c:83-86 */
   free(vs);
   t->pos = newpos;
   for(int64_t i = 0; i < t->n; i++)   /* force_update_node_len_local, forcetree.c:1043-1085 */

@@ -109,6 +109,13 @@ class Tree:
         lib().orc_tree_drift.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         lib().orc_tree_drift(self.h, C.byref(self.cfg), _p(self.pos), _p(self._vel), C.c_double(dt))
 
+    def drift_kicked(self, newpos, vel, dv, dt):
+        """the same after node kicks (timestep.c:331-344): node velocities from `vel` (the build), every particle kicked by dv"""
+        self.pos = _f64(newpos)
+        self._vel, self._dv = _f64(vel), _f64(dv)
+        lib().orc_tree_drift_kicked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        lib().orc_tree_drift_kicked(self.h, C.byref(self.cfg), _p(self.pos), _p(self._vel), _p(self._dv), C.c_double(dt))
+
     @property
     def numnodes(self):
         return int(lib().orc_tree_numnodes(self.h))

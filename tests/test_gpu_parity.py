@@ -841,6 +841,64 @@ def test_dynamic_tree_update_against_the_reference_semantics(pkg, O, ng, wiring)
     assert np.median(err) < 1e-13 and np.quantile(err, 0.99) < 1e-10 and err.max() < 1e-2
 
 
+@pytest.mark.parametrize("ng", [1, 2])
+def test_node_kicks_against_the_refit(pkg, O, ng):
+    """The node kicks of timestep.c:331-344: a particle kicked by dv while the tree is kept adds dv m / M_k to the velocity of every
+    ancestor (restated in the oracle, orc_tree_drift_kicked), so that the following node drift (predict.c:79-91) moves the centres
+    of mass with the NEW velocities.  The library keeps no node velocities: it refits from the drifted particles.  N_GRAVS = 1: the
+    kicked node velocity is the mass-weighted mean of the kicked particle velocities, the drifted centre of mass is the exact one,
+    and the reference walk on the refit tree reproduces the oracle's walk on its kicked + drifted tree -- equal counts, forces to
+    rounding.  N_GRAVS = 2: the reference adds a particle's kick to the node velocities of BOTH species (the loop over k at
+    timestep.c:337-340 does not look at the particle's own species), its drifted centres of mass are then NOT those of the
+    drifted particles; the refit keeps the exact ones.  The test measures that reference quirk (documented deviation,
+    DESIGN 8) and checks that without kicks of the foreign species the two agree again."""
+    n = 30000
+    pos, mass, typ = pkg.ic.plummer_sphere(n, seed=5)
+    typ = (1 + (np.arange(n) % ng)).astype(np.int32)
+    rng = np.random.default_rng(8)
+    vel = 0.4 * rng.standard_normal((n, 3))
+    dv = 0.2 * rng.standard_normal((n, 3))
+    dt = 0.05
+    cfg = pkg.make_config(n_gravs=ng, G=1.0, theta=0.5, softening=[0.01] * 6, type_to_grav=pkg.ic.default_type_to_grav(ng),
+                          wiring="newton", walk_mode=pkg.WALK_STRICT)
+
+    def both(dv_):
+        pos2 = pos + (vel + dv_) * dt
+        T = O.Tree(cfg, pos, mass, typ, O.domain_extent(pos))
+        T.drift_kicked(pos2, vel, dv_, dt)
+        a_o, n_o = T.walk()
+        a_o, _ = O.finish(cfg, a_o)
+        T.close()
+        eng = _engine(pkg, cfg, pos, mass, typ)
+        eng.compute_accelerations(pm_step=False)
+        eng.update_particles(pos2, mass, typ)
+        eng.gravity_tree()
+        acc, _, cost = eng.get_accel()
+        eng.close()
+        same = cost.astype(np.int64) == n_o.astype(np.int64)
+        err = np.linalg.norm(acc - a_o, axis=1) / np.linalg.norm(a_o, axis=1)
+        return same, err
+
+    same, err = both(dv)
+    print("kicked + drifted tree, N_GRAVS=%d: counts equal for %.3f %%, |da|/|a| median %.1e, 99 %% %.1e, max %.1e"
+          % (ng, 100.0 * same.mean(), np.median(err), np.quantile(err, 0.99), err.max()))
+    if ng == 1:
+        assert same.mean() > 0.999
+        assert np.median(err) < 1e-13 and np.quantile(err, 0.99) < 1e-10 and err.max() < 1e-2
+    else:
+        # the reference's cross-species kicks displace its node centres of mass: visible, small (a monopole position error of
+        # |dv| dt m_other / M_k inside cells the walk accepted)
+        assert np.median(err) > 1e-9 and np.quantile(err, 0.99) < 5e-2
+        dv1 = dv.copy()
+        dv1[typ != 1] = 0.0                                     # kicks of ONE species: the other species' node velocities still move
+        _, err1 = both(dv1)
+        dv0 = np.zeros_like(dv)
+        same0, err0 = both(dv0)                                 # no kicks: the pure drift, identical again
+        print("   kicks of species 0 only: median %.1e; no kicks: counts equal %.3f %%, median %.1e" % (np.median(err1), 100.0 * same0.mean(), np.median(err0)))
+        assert np.median(err1) > 1e-10
+        assert same0.mean() > 0.999 and np.median(err0) < 1e-13
+
+
 def test_dynamic_tree_update_refit(pkg, O):
     """ngravs_update_particles + ngravs_force_update_tree (the drifted tree of TreeDomainUpdateFrequency > 0):
     (a) unchanged positions: the refit tree gives bit-identical forces to the freshly built one;
