@@ -403,7 +403,8 @@ def main():
                                     args.wiring, "tree-only" if treeonly else "TreePM PMGRID=%d" % pmgrid, args.walk),
                        "particles": n, "n_gravs": args.ngravs, "pmgrid": pmgrid, "walk": args.walk,
                        "mesh_cells_per_particle": cells_per_particle,   # the short-range sphere holds ~ 1/this: ia_per_particle scales with it
-                       "backend": (eng.backend if domain else (dist.get_backend() if world > 1 else None)),
+                       "backend": ((eng.backend + ("; " + eng.comm_note if getattr(eng, "comm_note", "") else "")) if domain
+                                   else (dist.get_backend() if world > 1 else None)),
                        "world_size_reported_by_backend": (eng.comm.world_reported if domain else (dist.get_world_size() if world > 1 else 1)),
                        "parallelism": ("work-weighted Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, x-slab decomposed PM (4 plane exchanges)" % world)
                        if domain else ("walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world),

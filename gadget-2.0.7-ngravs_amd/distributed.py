@@ -75,6 +75,11 @@ class RcclComm:
         self.c = Comm()
         L.ngravs_rccl_fill(self._h, C.byref(self.c))
         self.world_reported = int(L.ngravs_rccl_world(self._h))
+        L.ngravs_rccl_selftest.argtypes = [C.c_void_p]
+
+    def selftest(self):
+        """every collective of the vtable once with known answers (ngravs_rccl_selftest); collective.  Returns "" or what differed"""
+        return "" if self._L.ngravs_rccl_selftest(self._h) == 0 else (self.last_error() or "self test failed")
 
     def stats(self):
         calls, sec, byt = C.c_int64(0), C.c_double(0), C.c_double(0)
@@ -214,6 +219,20 @@ class DistributedEngine(Engine):
         if comm is None:
             comm = "rccl" if dist.get_backend(group) == "nccl" else "torch"
         self.comm = RcclComm(dev, group) if comm == "rccl" else TorchComm(dev, group)
+        self.comm_note = ""
+        if comm == "rccl":
+            # the C communicator proves itself once; if it does not on ANY task, all tasks fall back together to the process group
+            # (the same collectives through torch.distributed) and say so -- never a silent switch, never a hang inside a step
+            why = self.comm.selftest()
+            bad = torch.tensor([1 if why else 0], dtype=torch.int32, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+            if int(bad.item()):
+                import sys
+                print("ngravs: libngravs_rccl.so self test failed on task %d (%s): falling back to torch.distributed collectives"
+                      % (self.comm.rank, why or "on another task"), file=sys.stderr)
+                self.comm.close()
+                self.comm = TorchComm(dev, group)
+                self.comm_note = "fallback: libngravs_rccl self test failed (%s)" % (why or "on another task")
         self.rank, self.world, self.backend = self.comm.rank, self.comm.size, self.comm.backend
         if self.world > 64:
             raise NgravsError("at most 64 tasks")

@@ -226,6 +226,11 @@ static void ensure_ctx(void)
 	printf("ngravs-hip: ncclCommInitRank failed on task %d (one task per GPU)\n", ThisTask);
 	endrun(1072);
       }
+    if(ngravs_rccl_selftest(Rccl))   /* every collective once with known answers: a fabric problem ends the run here, with a reason */
+      {
+        printf("ngravs glue: task %d: RCCL self test: %s\n", ThisTask, ngravs_rccl_last_error(Rccl));
+        endrun(1056);
+      }
     ngravs_rccl_fill(Rccl, &Comm);
   }
 #else

@@ -420,6 +420,11 @@ static int rccl_one_task(void)
   int i, k;
   if(ngravs_rccl_unique_id(id) || ngravs_rccl_create(id, 0, 1, 0, &r))
     return 40;
+  if(ngravs_rccl_selftest(r))
+    {
+      printf("RCCL self test: %s\n", ngravs_rccl_last_error(r));
+      return 48;
+    }
   ngravs_rccl_fill(r, &cm);
   if(ngravs_rccl_world(r) != 1 || !cm.device_buffers || !cm.allreduce_dev)
     return 41;

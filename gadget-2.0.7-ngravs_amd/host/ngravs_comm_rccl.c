@@ -126,17 +126,17 @@ static int rccl_allgather(void *user, const void *send, void *recv, int64_t byte
 {
   ngravs_rccl *r = user;
   const double t0 = now_s();
-  const size_t b = (size_t)(bytes > 0 ? bytes : 0), all = b * (size_t)r->size;
+  const size_t b = (size_t)(bytes > 0 ? bytes : 0), all = b * (size_t)r->size, off = (b + 255) & ~(size_t)255;   /* gathered blocks start aligned */
   char *d;
   if(b == 0)
     return 0;
   HIPOK(r, hipSetDevice(r->device));
-  if(need_scratch(r, b + all))
+  if(need_scratch(r, off + all))
     return 1;
   d = r->scratch;
   HIPOK(r, hipMemcpyAsync(d, send, b, hipMemcpyHostToDevice, r->stream));
-  NCCLOK(r, ncclAllGather(d, d + b, b, ncclInt8, r->comm, r->stream));
-  HIPOK(r, hipMemcpyAsync(recv, d + b, all, hipMemcpyDeviceToHost, r->stream));
+  NCCLOK(r, ncclAllGather(d, d + off, b, ncclInt8, r->comm, r->stream));
+  HIPOK(r, hipMemcpyAsync(recv, d + off, all, hipMemcpyDeviceToHost, r->stream));
   HIPOK(r, hipStreamSynchronize(r->stream));
   account(r, t0, (double)all);
   return 0;
@@ -275,6 +275,90 @@ int ngravs_rccl_world(ngravs_rccl *r)
   if(!r || ncclCommCount(r->comm, &n) != ncclSuccess)
     return -1;
   return n;
+}
+
+/* Every collective of the vtable once, with known answers: a reduction, a gather and an all-to-all-v with unequal and empty
+ * blocks (block r -> p: (r + 2 p) mod 5 words of value 64 r + p; none when (r + p) mod 7 == 3).  Collective; 0 = all as
+ * expected on this task.  A host calls it once after ngravs_rccl_create() -- what it costs is three small collectives -- so
+ * that a fabric or bootstrap problem shows as an error message before the first step, not as a hang inside one. */
+static int64_t st_words(int from, int to) { return (from + to) % 7 == 3 ? 0 : (from + 2 * to) % 5; }
+
+int ngravs_rccl_selftest(ngravs_rccl *r)
+{
+  int64_t sum[2], *hs = NULL, *hr = NULL, sb[64], sd[64], rb[64], rd[64], ns = 0, nr = 0, k;
+  unsigned char *g = NULL, mine[3];
+  void *ds = NULL, *dr = NULL;
+  int p, rc = 1;
+  if(!r || r->size > 64)
+    return 1;
+  sum[0] = r->rank + 1;
+  sum[1] = -(int64_t)r->rank;
+  if(rccl_allreduce(r, sum, 1, NGRAVS_T_I64, NGRAVS_OP_SUM) || rccl_allreduce(r, sum + 1, 1, NGRAVS_T_I64, NGRAVS_OP_MIN))
+    return 1;
+  if(sum[0] != (int64_t)r->size * (r->size + 1) / 2 || sum[1] != -(int64_t)(r->size - 1))
+    {
+      snprintf(r->err, sizeof(r->err), "self test: all-reduce gave %lld / %lld", (long long)sum[0], (long long)sum[1]);
+      return 1;
+    }
+  g = malloc(3 * (size_t)r->size);
+  if(!g)
+    return 1;
+  mine[0] = (unsigned char)r->rank;
+  mine[1] = (unsigned char)(r->rank ^ 0x5a);
+  mine[2] = 7;
+  if(rccl_allgather(r, mine, g, 3))
+    goto done;
+  for(p = 0; p < r->size; p++)
+    if(g[3 * p] != (unsigned char)p || g[3 * p + 1] != (unsigned char)(p ^ 0x5a) || g[3 * p + 2] != 7)
+      {
+        snprintf(r->err, sizeof(r->err), "self test: all-gather block %d is wrong", p);
+        goto done;
+      }
+  for(p = 0; p < r->size; p++)
+    {
+      sb[p] = 8 * st_words(r->rank, p);
+      rb[p] = 8 * st_words(p, r->rank);
+      sd[p] = 8 * ns;
+      rd[p] = 8 * nr;
+      ns += st_words(r->rank, p);
+      nr += st_words(p, r->rank);
+    }
+  hs = malloc(8 * (size_t)(ns + 1));
+  hr = calloc((size_t)(nr + 1), 8);
+  if(!hs || !hr || hipMalloc(&ds, 8 * (size_t)(ns + 1)) != hipSuccess || hipMalloc(&dr, 8 * (size_t)(nr + 1)) != hipSuccess)
+    goto done;
+  for(p = 0, k = 0; p < r->size; p++)
+    {
+      int64_t q;
+      for(q = 0; q < st_words(r->rank, p); q++)
+        hs[k++] = 64 * r->rank + p;
+    }
+  if(hipMemcpy(ds, hs, 8 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dr, 0xff, 8 * (size_t)(nr + 1)) != hipSuccess)
+    goto done;
+  if(rccl_alltoallv(r, ds, sb, sd, dr, rb, rd))
+    goto done;
+  if(hipMemcpy(hr, dr, 8 * (size_t)nr, hipMemcpyDeviceToHost) != hipSuccess)
+    goto done;
+  for(p = 0, k = 0; p < r->size; p++)
+    {
+      int64_t q;
+      for(q = 0; q < st_words(p, r->rank); q++)
+        if(hr[k++] != 64 * p + r->rank)
+          {
+            snprintf(r->err, sizeof(r->err), "self test: all-to-all-v block from task %d is wrong", p);
+            goto done;
+          }
+    }
+  rc = 0;
+done:
+  free(g);
+  free(hs);
+  free(hr);
+  if(ds)
+    (void)hipFree(ds);
+  if(dr)
+    (void)hipFree(dr);
+  return rc;
 }
 
 int ngravs_rccl_barrier(ngravs_rccl *r)

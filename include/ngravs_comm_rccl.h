@@ -42,6 +42,10 @@ void ngravs_rccl_stats(ngravs_rccl *r, int64_t *calls, double *seconds, double *
 const char *ngravs_rccl_last_error(ngravs_rccl *r);
 /* the world size RCCL itself reports (ncclCommCount) */
 int ngravs_rccl_world(ngravs_rccl *r);
+/* every callback of the vtable once with known answers (reductions, a gather, an all-to-all-v with unequal and empty blocks);
+ * collective over all tasks, 0 = all as expected on this task, else ngravs_rccl_last_error() says what differed.  Call it once
+ * after ngravs_rccl_create(): a bootstrap or fabric problem then shows before the first step instead of inside it. */
+int ngravs_rccl_selftest(ngravs_rccl *r);
 /* barrier (an all-reduce of one int) -- convenience for hosts without another communicator */
 int ngravs_rccl_barrier(ngravs_rccl *r);
 
