@@ -2,6 +2,7 @@
 x-slab decomposed PM (four plane exchanges, no mesh all-reduce), all driven by the C host layer (host/ngravs_host.c) through
 torch.distributed -- with 3 ranks sharing the one GPU of the box over gloo.  Merged results must reproduce the single-task
 engine and keep the accuracy of the Ewald golden."""
+import ctypes as C
 import os
 import sys
 
@@ -246,6 +247,75 @@ def test_one_task_over_rccl(pkg, tmp_path):
     print("one task over RCCL vs the single-task engine: max |da|/|a| = %.2e" % err.max())
     assert np.array_equal(cost, c1)
     assert err.max() < 1e-10
+
+
+def _order_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos, mass, typ, old, cfg = _strict_case(pkg, "c4")
+    cfg.err_tol_theta = 0.5                                 # Barnes-Hut criterion: the walk does not depend on the last step's OldAcc
+    n = len(pos)
+    L = pkg.lib()
+    L.ngravs_dd_peano_order.argtypes = [C.c_void_p, C.c_int]
+    eng = dd.DistributedEngine(cfg)
+    ids = np.arange(n)[::-1].copy()                         # rows in an order that has nothing to do with the curve
+    eng.set_particles(pos[ids], mass[ids], typ[ids], old_acc=old[ids], ids=ids)
+    before = L.ngravs_dd_peano_order(eng._h, 1)             # no decomposition yet: no order to put the rows in
+    eng.compute_accelerations(pm_step=True)
+    a1, o1, c1, p1 = eng.get_accel(want_pm=True)
+    ids1 = eng.local_ids()
+    ord1 = eng.order()
+    eng.compute_accelerations(pm_step=False)                # the decomposition of this step finds the rows far from Peano order
+    a2, o2, c2, p2 = eng.get_accel(want_pm=True)
+    ids2 = eng.local_ids()
+    ord2 = eng.order()
+    again = L.ngravs_dd_peano_order(eng._h, 0)              # in order now: left alone
+    forced = L.ngravs_dd_peano_order(eng._h, 1)             # forced: rows rewritten (to the same places)
+    ids3 = eng.local_ids()
+    eng.compute_accelerations(pm_step=False)
+    a3, o3, c3, p3 = eng.get_accel(want_pm=True)
+    ids4 = eng.local_ids()
+    np.savez(os.path.join(out_dir, "o.npz"), before=before, again=again, forced=forced, ids1=ids1, ids2=ids2, ids3=ids3, ids4=ids4, ord1=ord1,
+             ord2=ord2, a1=a1, a2=a2, a3=a3, c1=c1, c2=c2, c3=c3, p1=p1, p2=p2, p3=p3, o2=o2, o3=o3)
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_own_rows_are_put_in_peano_order(pkg, tmp_path):
+    """ngravs_dd_peano_order(): the library-driven decomposition keeps ITS copy of the particle columns in Peano order, as
+    peano_hilbert_order() keeps the reference's P[] (domain.c:146, peano.c:36-90).  Rows handed over in reverse index order: the
+    first decomposition works on them as they are, the second finds the gather jumping and reorders -- rows, IDs, OldAcc, GravCost
+    and the parked GravPM move together (a step WITHOUT PM force follows: its OldAcc needs the PM step's GravPM), the results by ID
+    are those of the first step's tree walk, and the sorted order of the working set is then the row order."""
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_order_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    d = np.load(os.path.join(str(tmp_path), "o.npz"))
+    n = len(d["ids1"])
+    assert d["before"] == 0 and d["again"] == 0 and d["forced"] == 1
+    assert np.array_equal(d["ids1"], np.arange(n)[::-1])                       # step 1: the caller's rows
+    assert not np.array_equal(d["ord1"], np.arange(n))
+    assert np.array_equal(np.sort(d["ids2"]), np.arange(n)) and not np.array_equal(d["ids2"], d["ids1"])
+    assert np.array_equal(d["ord2"], np.arange(n))                             # step 2: row order == Peano order
+    assert np.array_equal(d["ids2"], d["ids1"][d["ord1"]])                     # ... the order step 1 had found
+    assert np.array_equal(d["ids3"], d["ids2"]) and np.array_equal(d["ids4"], d["ids2"])
+    by1 = np.argsort(d["ids1"])
+    by2 = np.argsort(d["ids2"])
+    # tree force and cost of the same particles on the same tree (same positions): identical; GravPM carried through the reorder
+    assert np.array_equal(d["c2"][by2], d["c1"][by1]) and np.array_equal(d["c3"][by2], d["c1"][by1])
+    assert np.abs(d["a2"][by2] - d["a1"][by1]).max() <= 1e-13 * np.abs(d["a1"]).max()
+    assert np.array_equal(d["p2"][by2], d["p1"][by1]) and np.array_equal(d["p3"][by2], d["p1"][by1])
+    assert np.array_equal(d["a3"], d["a2"]) and np.array_equal(d["o3"], d["o2"])
+    print("rows reordered once: %d of %d rows changed place; forces by ID equal, GravPM carried" % ((d["ids2"] != d["ids1"]).sum(), n))
 
 
 def test_three_rank_domain_decomposition(pkg, tmp_path):
