@@ -681,6 +681,7 @@ __device__ __forceinline__ double wave_max(double v)
 #endif
 #define GW2_MAXWAVES 16      // evaluation kernel: 4 waves per SIMD (128 VGPRs), 5 KB of LDS each beside the tables
 #define GW3_TBLOCK 256       // traversal kernel: 4 groups per workgroup
+#define GW3_RING 1024        // traversal kernel: LIFO positions mirrored in LDS per wave (a round pushes at most 512)
 
 template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT, int MODE>
 __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES : GW_MAXWAVES) * 64) void k_walk_group2(
@@ -697,6 +698,8 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
   // units (g_first, g_cnt, the group index are unit indices), MODE 2 over groups.
   constexpr int ES = GW2_ES;   // entries per force-loop trip (independent instruction streams)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int ring_s[MODE == 1 ? (GW3_TBLOCK / 64) * GW3_RING : 1];   // traversal kernel: LDS mirror of each wave's LIFO top
+  int *const ring = ring_s + (MODE == 1 ? (threadIdx.x >> 6) * GW3_RING : 0);
   // LDS: [tables (if TAB_LDS)] [exp table 32] [per wave: chunk pool 64 x (double4 pos/mass, double h, uchar species)]
   double *tab_s = reinterpret_cast<double *>(smem);
   const int ntabs = wp.ntab_lds + wp.exp_tab;   // distinct short-range tables [+ the exp(-ym r_bin) table]
@@ -1137,6 +1140,10 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           bad |= n_items[g] < 0;
         }
       auto STK = [&](int i) -> int & { return stack[i]; };
+      // Traversal kernel: the top of the LIFO is mirrored in LDS (a ring of GW3_RING positions per wave, written through): a round
+      // then starts from an LDS read instead of a global round trip for the 64 node indices it pops -- one of the dependent memory
+      // stages of a round.  ring_lo: positions >= ring_lo are intact in the ring (a push at q overwrites the slot of q - GW3_RING).
+      int ring_lo = 0;
       if(MODE == 2)
         sp = 0;
       else
@@ -1203,13 +1210,20 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                           c1 = i1 == q ? cidx[1][q] : c1;
                           c2 = i2 == q ? cidx[2][q] : c2;
                         }
-                      STK(lane) = tv.ltab[((size_t)c0 * nc + c1) * nc + c2];
+                      const int v0 = tv.ltab[((size_t)c0 * nc + c1) * nc + c2];
+                      STK(lane) = v0;
+                      if constexpr(MODE == 1)
+                        ring[lane] = v0;
                     }
                   sp = total;
                 }
             }
           if(from_root && lane == 0)
-            STK(0) = 0;
+            {
+              STK(0) = 0;
+              if constexpr(MODE == 1)
+                ring[0] = 0;
+            }
         }
       wave_sync();
       bool overflow = false, stk_overflow = false;   // a list or the LIFO is full
@@ -1629,7 +1643,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           sp -= nb;
           st_nodes += nb;
           st_batches++;
-          const int my = lane < nb ? STK(sp + lane) : -1;
+          int my = -1;
+          if(MODE == 1 && sp >= ring_lo)
+            my = lane < nb ? ring[(sp + lane) & (GW3_RING - 1)] : -1;
+          else
+            my = lane < nb ? STK(sp + lane) : -1;
           wave_sync();
           // decision: 0 drop, 1 accept (monopoles), 2 open (children), 3 open as a leaf (all particles of the range)
           int dec = 0;
@@ -1823,12 +1841,16 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       const int val = isn ? it : -2 - it;
                       if(isn || isp)
                         rbase[off] = val;
+                      if constexpr(MODE == 1)
+                        if(isn)
+                          ring[on & (GW3_RING - 1)] = val;
                       on += isn ? 1 : 0;
                       op0 += p0 ? 1 : 0;
                       op1 += p1 ? 1 : 0;
                       op2 += p2 ? 1 : 0;
                     }
                   sp += tn;
+                  ring_lo = sp - GW3_RING > ring_lo ? sp - GW3_RING : ring_lo;
                   n_items[0] += (int)((tot >> 10) & 1023u);
                   if(NG > 1)
                     n_items[NG > 1 ? 1 : 0] += (int)((tot >> 20) & 1023u);
