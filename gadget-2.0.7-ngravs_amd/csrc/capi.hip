@@ -533,8 +533,23 @@ static double ev_ms(ngravs_ctx *c);
 
 static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool keep_tree)
 {
-  if(!c || !p || p->n <= 0 || !p->pos || !p->mass || !p->type)
+  if(!c || !p || p->n < 0 || (p->n > 0 && (!p->pos || !p->mass || !p->type)) || (p->n == 0 && keep_tree))
     return NGRAVS_ERR_ARG;
+  if(p->n == 0)
+    {
+      // a task without particles (NumPart = 0): legal with several tasks -- it still owns mesh slabs, takes part in every
+      // collective and may receive particles in the next migration.  Nothing to upload.
+      (void)hipSetDevice(c->cfg.device);
+      c->n = c->n_local = 0;
+      c->own_order_nlocal = -1;
+      c->sort_low = 35;
+      c->all_active = true;
+      c->have_particles = true;
+      c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
+      c->top.on = false;
+      c->pm_parked = false;
+      return NGRAVS_OK;
+    }
   if(keep_tree && (!c->have_order || !c->have_tree || p->n != c->n || c->n_local != c->n))
     {
       ngravs_report(c, NGRAVS_ERR_STATE, "ngravs_update_particles: needs a built tree over the same particles (no halo copies)");
@@ -753,6 +768,16 @@ static int domain_decomposition_impl(ngravs_ctx *c, bool keep_pm)
   // visits active own rows only)
   c->have_pm = c->pm_parked;
   c->pm_parked = false;
+  if(c->n == 0)
+    {
+      // a task without particles and without imported copies: an empty order
+      c->own_order_nlocal = -1;
+      c->shard_first = c->shard_count = 0;
+      c->have_order = true;
+      c->have_tree = c->tree_stale = c->have_pm = false;
+      c->stats.t_domain = c->stats.t_peano = 0;
+      return NGRAVS_OK;
+    }
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   int rc = dom_find_extent(c);
   if(rc)
@@ -808,6 +833,14 @@ extern "C" int64_t ngravs_force_treebuild(ngravs_ctx *c)
   if(!c || !c->have_order)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  if(c->n == 0)   // nothing to build a tree of (a task without particles): no nodes, nothing will walk it
+    {
+      c->nnodes = 0;
+      c->have_tree = true;
+      c->tree_refit = false;
+      c->stats.t_treebuild = 0;
+      return 0;
+    }
   if(hipEventRecord(c->ev0, c->stream) != hipSuccess)
     return NGRAVS_ERR_NO_DEVICE;
   int rc = tree_build(c);
@@ -859,6 +892,15 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
     return rc;
   if((rc = ensure_table(c)))
     return rc;
+  if(c->n_local == 0)   // no targets on this task
+    {
+      c->stats.t_treewalk = 0;
+      c->stats.walk_kernel_ms = 0;
+      c->stats.interactions = 0;
+      c->stats.n_active = 0;
+      c->have_acc = true;
+      return NGRAVS_OK;
+    }
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   if((rc = walk_run(c)))
     return rc;
@@ -991,6 +1033,8 @@ extern "C" int ngravs_get_accel(ngravs_ctx *c, double *grav_accel, int64_t accel
   // the working set is own rows [0, n_local) followed by imported copies; ONLY the own rows are the caller's (its arrays hold
   // NumPart = ngravs_dd_num_local() rows -- the imports of a multi-task step never reach them)
   const int64_t n = c->n, nl = c->n_local;
+  if(nl == 0)   // a task without own particles: no rows to deliver
+    return NGRAVS_OK;
   if(c->out_tmp.ensure(3 * n) || c->out_tmpf.ensure(n))
     return NGRAVS_ERR_NOMEM;
   // in_active is the caller-order flag column of the last hand-over
@@ -1343,6 +1387,8 @@ extern "C" int ngravs_dd_set_ids(ngravs_ctx *c, const int64_t *ids, int on_devic
   if(!c || !c->have_particles || !ids)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  if(c->n_local == 0)
+    return NGRAVS_OK;
   HIP_TRY(c, hipMemcpyAsync(c->in_id.p, ids, sizeof(long long) * c->n_local, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                             c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1354,6 +1400,8 @@ extern "C" int ngravs_dd_get_ids(ngravs_ctx *c, int64_t *ids, int on_device)
   if(!c || !c->have_particles || !ids)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  if(c->n_local == 0)
+    return NGRAVS_OK;
   return download_strided(c, c->in_id.p, sizeof(long long), 1, c->n_local, ids, sizeof(long long), on_device);
 }
 

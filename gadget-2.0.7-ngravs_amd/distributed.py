@@ -13,7 +13,7 @@ that vtable:
   TorchComm  rehearsal: torch.distributed "gloo" through host copies (several tasks on one GPU, or no RCCL).
 
 Collectives per step in the steady state (DistributedEngine.info.collectives, .pm_bytes):
-  all-reduce   MIN of extent + target bounds (9 f64); SUM of the per-leaf sums (NGRAVS_TOP_CW doubles per top leaf)
+  all-reduce   MIN of extent + target bounds + status + largest own count (10 f64); SUM of the per-leaf sums (NGRAVS_TOP_CW doubles per top leaf)
   all-gather   migration counts + import requests (one call); PM bricks' bounding boxes (7 i32)
   all-to-all-v imported leaves (56-byte records), the four mesh exchanges of the slab PM; migrating particles only when any move
 """

@@ -772,7 +772,7 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
 {
   ngravs_config_t cfg;
   ngravs_toptree tree, next;
-  double lo[3], hi[3], bounds[2] = {1e300, 1e300}, e[9], total = 0, wtot = 0, wmax = 0, cmax = 0, *sums = NULL, *lcount = NULL, *lwork,
+  double lo[3], hi[3], bounds[2] = {1e300, 1e300}, e[10], total = 0, wtot = 0, wmax = 0, cmax = 0, *sums = NULL, *lcount = NULL, *lwork,
          *twork = NULL, thresh, n_own;
   int32_t *owner = NULL, i;
   int r, k, q, cw, rc = 0, W, round;
@@ -808,8 +808,9 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
   e[6] = bounds[0];
   e[7] = bounds[1];
   e[8] = rc ? -1.0 : 0.0;
+  e[9] = -n_own;   /* -> the largest particle count of a task: what the first guess of the top tree is sized with, THE SAME on every task */
   {
-    const int rcc = cm->allreduce(cm->user, e, 9, NGRAVS_T_F64, NGRAVS_OP_MIN);
+    const int rcc = cm->allreduce(cm->user, e, 10, NGRAVS_T_F64, NGRAVS_OP_MIN);
     info->collectives++;
     if(rcc)
       return status_of(rcc);
@@ -834,7 +835,9 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
         rc = tt_clone(&view, &tree);
       else if(!rc)
         {
-          const double guess = n_own * W, lm = leaf_max > 0 ? leaf_max : fmin(NGRAVS_TOPLEAF_MAX, guess / (20.0 * W));
+          /* (sized from all-reduced numbers only: a guess from the own count would give tasks with different counts different
+           * trees, and the all-reduce of the leaf sums that follows different lengths) */
+          const double guess = -e[9] * W, lm = leaf_max > 0 ? leaf_max : fmin(NGRAVS_TOPLEAF_MAX, guess / (20.0 * W));
           int lvl = 1;
           while(lvl < 6 && guess / (double)(1ll << (3 * lvl)) > lm)
             lvl++;

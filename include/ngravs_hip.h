@@ -131,7 +131,7 @@ typedef struct {
  * PMGRID), SoA callers pass sizeof(element).  `on_device` != 0 means the pointers are HIP device
  * pointers (zero-copy hand-over; no PCIe traffic inside the call). */
 typedef struct {
-  int64_t n;                 /* NumPart                                               */
+  int64_t n;                 /* NumPart; 0 is legal (a task without particles in a multi-task run: pointers may be NULL) */
   const double *pos;         /* Pos[3]          */  int64_t pos_stride;
   const double *mass;        /* Mass            */  int64_t mass_stride;
   const int32_t *type;       /* Type            */  int64_t type_stride;

@@ -249,6 +249,89 @@ def test_one_task_over_rccl(pkg, tmp_path):
     assert err.max() < 1e-10
 
 
+def _degenerate_case(pkg, name):
+    rng = np.random.default_rng(5)
+    if name == "two":              # two particles, three tasks: one task owns nothing at all, before and after the decomposition
+        n, L = 2, 1.0
+        pos = np.array([[0.2, 0.3, 0.4], [0.7, 0.1, 0.9]])
+    elif name == "tiny":           # fewer particles than top leaves: most leaves are empty, tasks own a handful of particles
+        n, L = 90, 1.0
+        pos = rng.random((n, 3)) * L
+    elif name == "clump":          # nearly all particles inside one small cell + a few far away: the top tree goes deep, one task gets the clump
+        n, L = 6000, 1.0
+        pos = 0.5 + 0.004 * rng.standard_normal((n, 3))
+        pos[:40] = rng.random((40, 3))
+        pos = np.mod(pos, L)
+    else:                          # "slab": everything in a thin sheet: the cut leaves some tasks with very little
+        n, L = 5000, 1.0
+        pos = rng.random((n, 3)) * L
+        pos[:, 0] = 0.25 + 0.002 * rng.random(n)
+    mass = np.full(n, 1.0 / n)
+    typ = (1 + (np.arange(n) % 2)).astype(np.int32)
+    eps = 0.002
+    cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=16, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                          type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    return pos, mass, typ, cfg
+
+
+def _degenerate_worker(rank, world, port, out_dir, name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos, mass, typ, cfg = _degenerate_case(pkg, name)
+    n = len(pos)
+    mine = np.arange(n) if rank == 0 else np.zeros(0, dtype=np.int64)      # one task holds everything, the others start EMPTY
+    eng = dd.DistributedEngine(cfg, leaf_max=40.0)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], ids=mine)
+    out = {}
+    for step in range(2):                                                   # the second step: cut weighted by GravCost, rows reordered
+        eng.compute_accelerations(pm_step=True)
+        a, o, c, p = eng.get_accel(want_pm=True)
+        out.update({"ids%d" % step: eng.local_ids(), "acc%d" % step: a, "pm%d" % step: p, "cost%d" % step: c})
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), **out)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["two", "tiny", "clump", "slab"])
+def test_three_rank_degenerate_sets(pkg, tmp_path, name):
+    """Edge cases of the multi-task path: tasks that start with NO particles, fewer particles than top leaves, a clump that one
+    task has to take whole (the top tree refines down to it), a thin sheet (tasks with almost nothing after the cut).  Theta
+    criterion, reference walk: total force and interaction counts of the single task, on both steps."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 29300 + (os.getpid() % 2000)
+    mp.spawn(_degenerate_worker, args=(world, port, str(tmp_path), name), nprocs=world, join=True)
+    pos, mass, typ, cfg = _degenerate_case(pkg, name)
+    n = len(pos)
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ)
+    eng.compute_accelerations(pm_step=True)
+    a1, _, c1, p1 = eng.get_accel(want_pm=True)
+    eng.close()
+    for step in range(2):
+        acc, cost, pm, seen, own = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3)), np.zeros(n, dtype=np.int64), []
+        for r in range(world):
+            d = np.load(os.path.join(str(tmp_path), "g%d.npz" % r))
+            ids = d["ids%d" % step]
+            acc[ids], cost[ids], pm[ids] = d["acc%d" % step], d["cost%d" % step], d["pm%d" % step]
+            seen[ids] += 1
+            own.append(len(ids))
+        assert np.all(seen == 1)
+        tot1, tot = a1 + p1, acc + pm
+        err = np.linalg.norm(tot - tot1, axis=1) / np.linalg.norm(tot1, axis=1).max()
+        print("%s step %d: tasks own %s particles; counts equal: %s; max |d(a+pm)| / max|a| = %.1e" %
+              (name, step, own, np.array_equal(cost, c1), err.max()))
+        assert np.array_equal(cost, c1)
+        assert err.max() < 1e-10
+
+
 def _order_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
