@@ -251,13 +251,13 @@ def test_one_task_over_rccl(pkg, tmp_path):
 
 def _degenerate_case(pkg, name):
     rng = np.random.default_rng(5)
-    if name == "two":              # two particles, three tasks: one task owns nothing at all, before and after the decomposition
+    if name.startswith("two"):     # two particles, three tasks: one task owns nothing at all, before and after the decomposition
         n, L = 2, 1.0
         pos = np.array([[0.2, 0.3, 0.4], [0.7, 0.1, 0.9]])
-    elif name == "tiny":           # fewer particles than top leaves: most leaves are empty, tasks own a handful of particles
+    elif name.startswith("tiny"):  # fewer particles than top leaves: most leaves are empty, tasks own a handful of particles
         n, L = 90, 1.0
         pos = rng.random((n, 3)) * L
-    elif name == "clump":          # nearly all particles inside one small cell + a few far away: the top tree goes deep, one task gets the clump
+    elif name.startswith("clump"): # nearly all particles inside one small cell + a few far away: the top tree goes deep, one task gets the clump
         n, L = 6000, 1.0
         pos = 0.5 + 0.004 * rng.standard_normal((n, 3))
         pos[:40] = rng.random((40, 3))
@@ -269,8 +269,12 @@ def _degenerate_case(pkg, name):
     mass = np.full(n, 1.0 / n)
     typ = (1 + (np.arange(n) % 2)).astype(np.int32)
     eps = 0.002
-    cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=16, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
-                          type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    if name.endswith("_tree"):     # the same sets without a mesh and without periodicity: tree-only
+        cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[eps] * 6, type_to_grav=pkg.ic.default_type_to_grav(2),
+                              wiring="newton", walk_mode=pkg.WALK_STRICT)
+    else:
+        cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=16, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
     return pos, mass, typ, cfg
 
 
@@ -292,14 +296,15 @@ def _degenerate_worker(rank, world, port, out_dir, name):
     out = {}
     for step in range(2):                                                   # the second step: cut weighted by GravCost, rows reordered
         eng.compute_accelerations(pm_step=True)
-        a, o, c, p = eng.get_accel(want_pm=True)
+        a, o, c = eng.get_accel()[:3]
+        p = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a)
         out.update({"ids%d" % step: eng.local_ids(), "acc%d" % step: a, "pm%d" % step: p, "cost%d" % step: c})
     np.savez(os.path.join(out_dir, "g%d.npz" % rank), **out)
     eng.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["two", "tiny", "clump", "slab"])
+@pytest.mark.parametrize("name", ["two", "tiny", "clump", "slab", "two_tree", "clump_tree"])
 def test_three_rank_degenerate_sets(pkg, tmp_path, name):
     """Edge cases of the multi-task path: tasks that start with NO particles, fewer particles than top leaves, a clump that one
     task has to take whole (the top tree refines down to it), a thin sheet (tasks with almost nothing after the cut).  Theta
@@ -313,7 +318,8 @@ def test_three_rank_degenerate_sets(pkg, tmp_path, name):
     eng = pkg.Engine(cfg)
     eng.set_particles(pos, mass, typ)
     eng.compute_accelerations(pm_step=True)
-    a1, _, c1, p1 = eng.get_accel(want_pm=True)
+    a1, _, c1 = eng.get_accel()[:3]
+    p1 = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a1)
     eng.close()
     for step in range(2):
         acc, cost, pm, seen, own = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 3)), np.zeros(n, dtype=np.int64), []
