@@ -338,6 +338,72 @@ def test_three_rank_degenerate_sets(pkg, tmp_path, name):
         assert err.max() < 1e-10
 
 
+def _active_worker(rank, world, port, out_dir, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos, mass, typ, old, cfg = _strict_case(pkg, "c4")
+    cfg.walk_mode = pkg.WALK_GROUP if mode == "group" else pkg.WALK_STRICT
+    n = len(pos)
+    active = (np.arange(n) % 7 == 3).astype(np.uint8)       # Ti_endstep == Ti_Current for one particle in seven
+    mine = np.arange(rank, n, world)
+    eng = dd.DistributedEngine(cfg)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], old_acc=old[mine], ids=mine, active=active[mine])
+    eng.compute_accelerations(pm_step=True)
+    a, o, c, p = eng.get_accel(want_pm=True)
+    np.savez(os.path.join(out_dir, "a%d.npz" % rank), ids=eng.local_ids(), acc=a, old=o, cost=c, pm=p)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["strict", "group"])
+def test_three_rank_sparse_active_set(pkg, tmp_path, mode):
+    """Individual timesteps on several tasks: only one particle in seven is active (gravtree.c:102-130 walks only
+    Ti_endstep == Ti_Current); the flags migrate with the particles.  Active rows: the single task's force (reference walk:
+    identical counts, 1e-10; group walk: as two valid groupings agree); inactive rows: not walked -- zero force and cost, their
+    OldAcc kept; GravPM for every particle (pm_periodic.c:716-763 updates all)."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 29100 + (os.getpid() % 2000)
+    mp.spawn(_active_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
+    pos, mass, typ, old, cfg = _strict_case(pkg, "c4")
+    cfg.walk_mode = pkg.WALK_GROUP if mode == "group" else pkg.WALK_STRICT
+    n = len(pos)
+    active = (np.arange(n) % 7 == 3).astype(np.uint8)
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=old, active=active)
+    eng.compute_accelerations(pm_step=True)
+    a1, o1, c1, p1 = eng.get_accel(want_pm=True)
+    eng.close()
+    acc, oa, cost, pm, seen = np.zeros((n, 3)), np.zeros(n), np.zeros(n), np.zeros((n, 3)), np.zeros(n, dtype=np.int64)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "a%d.npz" % r))
+        acc[d["ids"]], oa[d["ids"]], cost[d["ids"]], pm[d["ids"]] = d["acc"], d["old"], d["cost"], d["pm"]
+        seen[d["ids"]] += 1
+    assert np.all(seen == 1)
+    act = active.astype(bool)
+    assert np.all(acc[~act] == 0) and np.all(cost[~act] == 0) and np.all(a1[~act] == 0)
+    assert np.array_equal(oa[~act], old[~act])
+    err = np.linalg.norm(acc[act] - a1[act], axis=1) / np.linalg.norm(a1[act] + p1[act], axis=1)
+    epm = np.abs(pm - p1).max() / np.abs(p1).max()
+    print("%s walk, %d of %d particles active on 3 tasks: |da|/|a+pm| median %.1e max %.1e; counts equal: %s; GravPM %.1e" %
+          (mode, act.sum(), n, np.median(err), err.max(), np.array_equal(cost[act], c1[act]), epm))
+    assert epm < 1e-10
+    if mode == "strict":
+        assert np.array_equal(cost[act], c1[act]) and err.max() < 1e-10
+        assert np.abs(oa[act] - o1[act]).max() <= 1e-10 * o1[act].max()
+    else:
+        # groups are stretches of 64 consecutive ACTIVE own particles: seven times as wide as a full group, and cut differently on
+        # 3 tasks -- two valid walks of the same criterion, each within ErrTolForceAcc of the truth (measured p99 3.7e-3, max 1.1e-2)
+        assert np.median(err) < 1e-10 and np.quantile(err, 0.99) < 1e-2 and err.max() < 5e-2
+
+
 def _order_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
