@@ -135,6 +135,13 @@ def _strict_case(pkg, case):
         cfg = pkg.make_config(n_gravs=3, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
                               type_to_grav=pkg.ic.default_type_to_grav(3), wiring="c4", walk_mode=pkg.WALK_STRICT)
         return pos, mass, typ, np.zeros(n), cfg
+    if case == "c3":               # BASELINE's config 3 in small: N_GRAVS=1 (Newton), TreePM
+        n, L = 30000, 1.0
+        pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=1, seed=57)
+        eps = L / (40 * n ** (1 / 3))
+        cfg = pkg.make_config(n_gravs=1, periodic=1, pmgrid=32, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(1), wiring="newton", walk_mode=pkg.WALK_STRICT)
+        return pos, mass, typ, np.zeros(n), cfg
     if case == "periodic":         # periodic tree-only: nearest-image tree force + the lattice-correction walk (forcetree.c:2077-2455)
         n, L = 16000, 1.0
         pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=2, seed=77)
@@ -221,6 +228,32 @@ def test_three_rank_forces_do_not_depend_on_the_task_count(pkg, tmp_path, case):
               (moved, eo3, np.abs(p3 - p1).max() / np.abs(p1).max()))
         assert moved > n // 2
         assert np.array_equal(c3, c1) and eo3 < 1e-10 and np.abs(p3 - p1).max() / np.abs(p1).max() < 1e-10
+
+
+@pytest.mark.parametrize("case,world", [("c4", 2), ("c4", 5), ("c3", 3), ("plummer", 5)])
+def test_other_task_counts(pkg, tmp_path, case, world):
+    """The same invariant with 2 and 5 tasks (uneven mesh slabs: PMGRID 32 over 5 tasks; a cut into 5 of a centrally
+    concentrated set) and for N_GRAVS = 1: reference walk, forces and interaction counts of the single task."""
+    import torch.multiprocessing as mp
+    port = 28700 + (os.getpid() % 2000)
+    mp.spawn(_strict_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    pos, mass, typ, old, cfg = _strict_case(pkg, case)
+    n = len(pos)
+    acc, cost, seen, own = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.int64), []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "s%d.npz" % r))
+        acc[d["ids"]], cost[d["ids"]] = d["acc"], d["cost"]
+        seen[d["ids"]] += 1
+        own.append("%d+%d" % (d["halo"][1], d["halo"][0]))
+    assert np.all(seen == 1)
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ, old_acc=old)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    a1, _, c1 = eng.get_accel()
+    eng.close()
+    err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1, axis=1)
+    print("%s on %d tasks (own+imported %s): max |da|/|a| = %.2e, counts equal: %s" % (case, world, " ".join(own), err.max(), np.array_equal(cost, c1)))
+    assert np.array_equal(cost, c1) and err.max() < 1e-10
 
 
 def test_one_task_over_rccl(pkg, tmp_path):
