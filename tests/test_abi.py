@@ -21,6 +21,21 @@ def test_exports_the_c_host_layer(pkg, have_lib):
         assert hasattr(have_lib, name), name
 
 
+def test_exports_the_rccl_communicator(pkg, have_lib):
+    """libngravs_rccl.so (host/ngravs_comm_rccl.c) defines every function include/ngravs_comm_rccl.h declares (checked with nm: no
+    RCCL call without a GPU), and it links against librccl, not against torch"""
+    import subprocess
+    hdr = open(os.path.join(os.path.dirname(pkg.__file__), "..", "include", "ngravs_comm_rccl.h")).read()
+    declared = set(re.findall(r"\b(ngravs_rccl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(pkg.RCCL_EXPORTS)
+    assert os.path.exists(pkg.RCCL_LIB_PATH), "libngravs_rccl.so not built (__graft_entry__.build())"
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.RCCL_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert declared <= defined, declared - defined
+    und = subprocess.run(["nm", "-D", "--undefined-only", pkg.RCCL_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "ncclAllReduce" in und and "ncclSend" in und and "ncclRecv" in und and "ncclCommInitRank" in und
+
+
 def test_host_split_balances_work_within_the_memory_bound(pkg, have_lib):
     """ngravs_host_split does the job of domain_findSplit + domain_shiftSplit (reference domain.c:347-544): contiguous runs of
     top leaves, every task gets leaves, the particle count of a task stays below max_load, and under that bound the largest work
