@@ -302,12 +302,15 @@ def _degenerate_case(pkg, name):
     mass = np.full(n, 1.0 / n)
     typ = (1 + (np.arange(n) % 2)).astype(np.int32)
     eps = 0.002
+    group = name.endswith("_group")   # the production walk on the same sets
     if name.endswith("_tree"):     # the same sets without a mesh and without periodicity: tree-only
         cfg = pkg.make_config(n_gravs=2, G=1.0, theta=0.5, softening=[eps] * 6, type_to_grav=pkg.ic.default_type_to_grav(2),
                               wiring="newton", walk_mode=pkg.WALK_STRICT)
     else:
         cfg = pkg.make_config(n_gravs=2, periodic=1, pmgrid=16, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
                               type_to_grav=pkg.ic.default_type_to_grav(2), wiring="c4", walk_mode=pkg.WALK_STRICT)
+    if group:
+        cfg.walk_mode = pkg.WALK_GROUP
     return pos, mass, typ, cfg
 
 
@@ -337,7 +340,7 @@ def _degenerate_worker(rank, world, port, out_dir, name):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["two", "tiny", "clump", "slab", "two_tree", "clump_tree"])
+@pytest.mark.parametrize("name", ["two", "tiny", "clump", "slab", "two_tree", "clump_tree", "two_group", "tiny_group", "clump_group"])
 def test_three_rank_degenerate_sets(pkg, tmp_path, name):
     """Edge cases of the multi-task path: tasks that start with NO particles, fewer particles than top leaves, a clump that one
     task has to take whole (the top tree refines down to it), a thin sheet (tasks with almost nothing after the cut).  Theta
@@ -367,8 +370,13 @@ def test_three_rank_degenerate_sets(pkg, tmp_path, name):
         err = np.linalg.norm(tot - tot1, axis=1) / np.linalg.norm(tot1, axis=1).max()
         print("%s step %d: tasks own %s particles; counts equal: %s; max |d(a+pm)| / max|a| = %.1e" %
               (name, step, own, np.array_equal(cost, c1), err.max()))
-        assert np.array_equal(cost, c1)
-        assert err.max() < 1e-10
+        if name.endswith("_group"):
+            # two valid groupings of the production walk (groups are stretches of a task's own particles): the same force within the
+            # walk's own accuracy
+            assert np.quantile(err, 0.99) < 2e-2 and err.max() < 0.2
+        else:
+            assert np.array_equal(cost, c1)
+            assert err.max() < 1e-10
 
 
 def _active_worker(rank, world, port, out_dir, mode):
