@@ -446,16 +446,19 @@ def test_three_rank_sparse_active_set(pkg, tmp_path, mode):
 
 
 def _soak_positions(pos0, L, step):
-    """deterministic drift: every particle moves ~ a mean spacing per step, some cross domain boundaries every step"""
+    """deterministic drift: every particle moves ~ a mean spacing per step, some cross domain boundaries every step.
+    L = 0: a non-periodic set (lengths of order 1, no wrap: the domain extent itself changes from step to step)"""
     rng = np.random.default_rng(1000 + step)
     n = len(pos0)
+    if L == 0:
+        return pos0 * (1.0 + 0.03 * step) + 0.05 * step * np.sin(3.0 * pos0[:, [1, 2, 0]] + 0.4 * step) + 0.01 * rng.standard_normal((n, 3))
     return np.mod(pos0 + L * (0.02 * step * np.sin(2 * np.pi * (pos0[:, [1, 2, 0]] / L + 0.13 * step)) + 0.004 * rng.standard_normal((n, 3))), L)
 
 
 NSOAK = 6
 
 
-def _soak_worker(rank, world, port, out_dir):
+def _soak_worker(rank, world, port, out_dir, case="c4"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -465,19 +468,21 @@ def _soak_worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     dd = importlib.import_module("ngravs_amd.distributed")
-    pos0, mass, typ, old0, cfg = _strict_case(pkg, "c4")
-    n, L = len(pos0), cfg.box_size
+    pos0, mass, typ, old0, cfg = _strict_case(pkg, case)
+    n, L = len(pos0), cfg.box_size if cfg.periodic else 0.0
     eng = dd.DistributedEngine(cfg, leaf_max=400.0)
     ids = np.arange(rank, n, world)
     old_all, pm_all = old0.copy(), np.zeros((n, 3))
     out = {}
     for step in range(NSOAK):
-        pm_step = step % 2 == 0
+        pm_step = step % 2 == 0 and bool(cfg.pmgrid)
         pos = _soak_positions(pos0, L, step)
         # the host's hand-over of its rows (the particles this task owned after the last step), with the OldAcc and GravPM it keeps
-        eng.set_particles(pos[ids], mass[ids], typ[ids], old_acc=old_all[ids], ids=ids, grav_pm=None if pm_step else pm_all[ids])
+        eng.set_particles(pos[ids], mass[ids], typ[ids], old_acc=old_all[ids], ids=ids,
+                          grav_pm=None if (pm_step or not cfg.pmgrid) else pm_all[ids])
         eng.compute_accelerations(pm_step=pm_step)
-        a, o, c, p = eng.get_accel(want_pm=True)
+        a, o, c = eng.get_accel()[:3]
+        p = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a)
         ids = eng.local_ids()
         # every task needs OldAcc / GravPM only of the rows it will hand over next: its own
         old_all[ids], pm_all[ids] = o, p
@@ -488,25 +493,28 @@ def _soak_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_three_rank_soak_with_moving_particles(pkg, tmp_path):
-    """Six steps with particles that MOVE between the steps (the host hands its rows over again each step, with the OldAcc and
+@pytest.mark.parametrize("case", ["c4", "plummer", "periodic"])
+def test_three_rank_soak_with_moving_particles(pkg, tmp_path, case):
+    """(c4: TreePM; plummer: tree-only, non-periodic -- the domain extent changes every step; periodic: tree-only with the lattice walk.)
+    Six steps with particles that MOVE between the steps (the host hands its rows over again each step, with the OldAcc and
     GravPM it keeps; PM and non-PM steps alternate): particles migrate every step, the top tree adapts, rows get reordered, GravPM
     travels -- and every step's forces, OldAcc and interaction counts are the single task's (reference walk, relative criterion)."""
     import torch.multiprocessing as mp
     world = 3
     port = 28900 + (os.getpid() % 2000)
-    mp.spawn(_soak_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    pos0, mass, typ, old0, cfg = _strict_case(pkg, "c4")
-    n, L = len(pos0), cfg.box_size
+    mp.spawn(_soak_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    pos0, mass, typ, old0, cfg = _strict_case(pkg, case)
+    n, L = len(pos0), cfg.box_size if cfg.periodic else 0.0
     res = [np.load(os.path.join(str(tmp_path), "k%d.npz" % r)) for r in range(world)]
     eng = pkg.Engine(cfg)
     old_all, pm_all = old0.copy(), np.zeros((n, 3))
     for step in range(NSOAK):
-        pm_step = step % 2 == 0
+        pm_step = step % 2 == 0 and bool(cfg.pmgrid)
         pos = _soak_positions(pos0, L, step)
-        eng.set_particles(pos, mass, typ, old_acc=old_all, grav_pm=None if pm_step else pm_all)
+        eng.set_particles(pos, mass, typ, old_acc=old_all, grav_pm=None if (pm_step or not cfg.pmgrid) else pm_all)
         eng.compute_accelerations(pm_step=pm_step)
-        a1, o1, c1, p1 = eng.get_accel(want_pm=True)
+        a1, o1, c1 = eng.get_accel()[:3]
+        p1 = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a1)
         old_all, pm_all = o1.copy(), p1.copy()
         acc, oa, cost, pm, seen = np.zeros((n, 3)), np.zeros(n), np.zeros(n), np.zeros((n, 3)), np.zeros(n, dtype=np.int64)
         mig = 0
@@ -518,7 +526,7 @@ def test_three_rank_soak_with_moving_particles(pkg, tmp_path):
         assert np.all(seen == 1)
         err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1 + p1, axis=1)
         eo = np.abs(oa - o1).max() / o1.max()
-        epm = np.abs(pm - p1).max() / np.abs(p1).max()
+        epm = np.abs(pm - p1).max() / np.abs(p1).max() if cfg.pmgrid else 0.0
         print("step %d (%s): %d migrated, %d top leaves (%d counting rounds); counts equal: %s; |da| %.1e, OldAcc %.1e, GravPM %.1e" %
               (step, "PM" if pm_step else "no PM", mig, res[0]["info%d" % step][2], res[0]["info%d" % step][3], np.array_equal(cost, c1),
                err.max(), eo, epm))
