@@ -899,7 +899,9 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
       double cNg = 0, cYg = 0, cSg = 0;
       // BAM / NGRAVS_ACCUMULATOR laws (ngravs.c:495-668; tree-only, non-periodic wirings: this instantiation only): they depend on the
       // TARGET's mass and on the particle number behind the source, so the lane keeps its mass and the ids of its two laws
-      constexpr bool BAMCAP = !PM && !LATT && !YUK;
+      // (tree-only instantiations have no tables: their TAB_LDS slot selects the variant that carries the BAM laws -- compiled in
+      // unconditionally they cost the plain Newtonian tree-only walk 15 % of its evaluation kernel: registers, a runtime test per use)
+      constexpr bool BAMCAP = !PM && !LATT && !YUK && TAB_LDS;
       double pmassT = 1.0;
       int lawA = 0, lawS = 0;
       if constexpr(BAMCAP)
@@ -2573,6 +2575,8 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
         return yuk ? launch_group3_t<NG, true, true, TL, false>(c, wp) : launch_group3_t<NG, true, false, TL, false>(c, wp);
       if(c->cfg.periodic)
         return yuk ? launch_group3_t<NG, false, true, false, true>(c, wp) : launch_group3_t<NG, false, false, false, true>(c, wp);
+      if(!yuk && wp.bam)
+        return launch_group3_t<NG, false, false, true, false>(c, wp);   // the variant with the BAM laws
       return yuk ? launch_group3_t<NG, false, true, false, false>(c, wp) : launch_group3_t<NG, false, false, false, false>(c, wp);
     }
   if(pm)
@@ -2581,6 +2585,8 @@ static int launch_group(ngravs_ctx *c, const WalkParams &wp, bool allow_split, b
   if(c->cfg.periodic)
     return yuk ? launch_group2_t<NG, false, true, false, true>(c, wp, glist, nlist)
                : launch_group2_t<NG, false, false, false, true>(c, wp, glist, nlist);
+  if(!yuk && wp.bam)
+    return launch_group2_t<NG, false, false, true, false>(c, wp, glist, nlist);
   return yuk ? launch_group2_t<NG, false, true, false, false>(c, wp, glist, nlist)
              : launch_group2_t<NG, false, false, false, false>(c, wp, glist, nlist);
 }
