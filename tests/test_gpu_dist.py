@@ -379,6 +379,95 @@ def test_three_rank_degenerate_sets(pkg, tmp_path, name):
             assert err.max() < 1e-10
 
 
+def _random_case(pkg, seed):
+    """a random small configuration: particle number, species, mesh / periodicity, clustering, softening spread, top-leaf size"""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(800, 30000))
+    ng = int(rng.integers(1, 4))
+    kind = ["treepm", "tree", "periodic_tree"][seed % 3]
+    L = 1.0
+    pos = rng.random((n, 3))
+    if rng.random() < 0.6:                        # a dense region of random size and place
+        k = int(n * rng.uniform(0.1, 0.7))
+        pos[:k] = np.mod(rng.random(3) + rng.uniform(0.01, 0.2) * rng.standard_normal((k, 3)), 1.0)
+    pos = np.clip(pos, 0.0, 1.0 - 1e-12)
+    mass = rng.uniform(0.5, 1.5, n) / n
+    typ = (1 + rng.integers(0, ng, n)).astype(np.int32)
+    eps = 0.3 / n ** (1 / 3) / 10
+    soft = [eps * (1 + 0.5 * t) if rng.random() < 0.5 else eps for t in range(6)]
+    kw = dict(n_gravs=ng, G=1.0, theta=float(rng.uniform(0.3, 0.7)), softening=soft, type_to_grav=pkg.ic.default_type_to_grav(ng),
+              wiring="newton" if (ng == 1 or kind == "tree") else "c4", walk_mode=pkg.WALK_STRICT)
+    if kind == "treepm":
+        kw.update(periodic=1, pmgrid=int(rng.choice([16, 32])), box_size=L)
+    elif kind == "periodic_tree":
+        kw.update(periodic=1, pmgrid=0, box_size=L)
+    cfg = pkg.make_config(**kw)
+    leaf_max = float(rng.choice([20.0, 80.0, 300.0, 0.0]))
+    world = int(rng.choice([2, 3, 4]))
+    return pos, mass, typ, cfg, (leaf_max or None), world
+
+
+def _random_worker(rank, world, port, out_dir, seed):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos, mass, typ, cfg, leaf_max, _ = _random_case(pkg, seed)
+    n = len(pos)
+    cut = np.sort(np.random.default_rng(seed).choice(n + 1, world - 1))        # uneven (possibly empty) initial shares
+    lo, hi = ([0] + list(cut))[rank], (list(cut) + [n])[rank]
+    mine = np.arange(lo, hi)
+    eng = dd.DistributedEngine(cfg, leaf_max=leaf_max)
+    eng.set_particles(pos[mine], mass[mine], typ[mine], ids=mine)
+    out = {}
+    for step in range(2):
+        eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+        a, o, c = eng.get_accel()[:3]
+        p = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a)
+        out.update({"ids%d" % step: eng.local_ids(), "acc%d" % step: a + p, "cost%d" % step: c,
+                    "info%d" % step: np.array([eng.info.n_topleaves, eng.timings["halo"], eng.num_local()])})
+    np.savez(os.path.join(out_dir, "q%d.npz" % rank), **out)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("seed", list(range(9)))
+def test_random_configurations_on_several_tasks(pkg, tmp_path, seed):
+    """Differential test over random small configurations (particle number, 1-3 species, TreePM / tree-only / periodic tree-only,
+    clustering, unequal softenings, opening angle, top-leaf size, 2-4 tasks, uneven or empty initial shares): reference walk, the
+    single task's interaction counts and forces on two consecutive steps."""
+    import torch.multiprocessing as mp
+    pos, mass, typ, cfg, leaf_max, world = _random_case(pkg, seed)
+    n = len(pos)
+    port = 28500 + (os.getpid() % 2000)
+    mp.spawn(_random_worker, args=(world, port, str(tmp_path), seed), nprocs=world, join=True)
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos, mass, typ)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    a1, _, c1 = eng.get_accel()[:3]
+    p1 = eng.get_accel(want_pm=True)[3] if cfg.pmgrid else np.zeros_like(a1)
+    eng.close()
+    tot1 = a1 + p1
+    res = [np.load(os.path.join(str(tmp_path), "q%d.npz" % r)) for r in range(world)]
+    for step in range(2):
+        tot, cost, seen = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.int64)
+        for d in res:
+            ids = d["ids%d" % step]
+            tot[ids], cost[ids] = d["acc%d" % step], d["cost%d" % step]
+            seen[ids] += 1
+        assert np.all(seen == 1)
+        err = np.linalg.norm(tot - tot1, axis=1) / np.linalg.norm(tot1, axis=1).max()
+        print("seed %d step %d: n %d, N_GRAVS %d, pmgrid %d, periodic %d, %d tasks, %d top leaves, own %s, imported %s: counts equal %s, max |d| %.1e" %
+              (seed, step, n, cfg.n_gravs, cfg.pmgrid, cfg.periodic, world, res[0]["info%d" % step][0], [int(d["info%d" % step][2]) for d in res],
+               [int(d["info%d" % step][1]) for d in res], np.array_equal(cost, c1), err.max()))
+        assert np.array_equal(cost, c1) and err.max() < 1e-10
+
+
 def _active_worker(rank, world, port, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
