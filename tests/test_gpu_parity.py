@@ -135,6 +135,54 @@ def test_strict_treepm_and_pm(pkg, O, wiring, ng, pmgrid, n):
     eng.close()
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_configurations_against_the_oracle(pkg, O, seed):
+    """Differential test of the reference path (decomposition, keys, tree, reference walk, PM, OldAcc) against the oracle over random
+    small configurations: particle number, 1-3 species, wiring, TreePM (16-64 mesh) or tree-only, clustering, unequal softening
+    lengths, opening angle; both criteria.  Identical interaction counts, forces to rounding."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(500, 20000))
+    ng = int(rng.integers(1, 4))
+    pm = seed % 2 == 0
+    L = float(rng.choice([1.0, 1e4]))
+    pos = rng.random((n, 3))
+    if rng.random() < 0.6:
+        k = int(n * rng.uniform(0.1, 0.8))
+        pos[:k] = np.mod(rng.random(3) + rng.uniform(0.005, 0.2) * rng.standard_normal((k, 3)), 1.0)
+    pos = np.clip(pos, 0.0, 1.0 - 1e-12) * L
+    mass = rng.uniform(0.5, 1.5, n) / n
+    typ = (1 + rng.integers(0, ng, n)).astype(np.int32) if ng > 1 else rng.integers(0, 6, n).astype(np.int32)
+    eps = L / (40 * n ** (1 / 3))
+    soft = [eps * float(rng.choice([1.0, 1.0, 2.5])) for _ in range(6)]
+    wiring = "newton" if ng == 1 else str(rng.choice(["c4", "newton", "coloyuk", "yukawa_offdiag"] if (ng == 2 and pm) else ["c4", "newton"] if pm else ["newton"]))
+    kw = dict(n_gravs=ng, G=float(rng.choice([1.0, 43007.1])), theta=float(rng.uniform(0.3, 0.8)), softening=soft,
+              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=pkg.WALK_STRICT)
+    if pm:
+        kw.update(periodic=1, pmgrid=int(rng.choice([16, 32, 64])), box_size=L)
+    cfg = pkg.make_config(**kw)
+    eng, (acc, old, cost, gpm), (a_o, old_o, n_o, pm_o), T = _strict_vs_oracle(pkg, O, cfg, pos, mass, typ)
+    scale = np.abs(a_o).max()
+    e1 = np.abs(acc - a_o).max() / scale
+    epm = np.abs(gpm - pm_o).max() / np.abs(pm_o).max() if pm else 0.0
+    same1 = np.array_equal(cost.astype(np.int64), n_o)
+    eng.set_opening(0.0, 0.005)
+    eng.set_old_acc(old)
+    eng.gravity_tree()
+    acc2, _, cost2 = eng.get_accel()
+    cfg.err_tol_theta = 0.0
+    a2, n2 = T.walk(old_acc=old_o, table=O.shortrange_table(cfg)[0] if pm else None)
+    a2, _ = O.finish(cfg, a2, pm_o)
+    e2 = np.abs(acc2 - a2).max() / np.abs(a2).max()
+    same2 = np.mean(cost2.astype(np.int64) == n2)
+    eng.close()
+    T.close()
+    print("seed %d: n %d, N_GRAVS %d, %s, pmgrid %d, L %g, theta %.2f: theta pass |da| %.1e counts equal %s, GravPM %.1e; relative pass |da| %.1e, counts equal for %.4f"
+          % (seed, n, ng, wiring, cfg.pmgrid, L, cfg.err_tol_theta if False else kw["theta"], e1, same1, epm, e2, same2))
+    assert e1 < TOL and same1 and epm < TOL
+    assert np.allclose(old, old_o, rtol=1e-8)
+    assert e2 < 1e-8 and same2 > 0.999
+
+
 def test_group_walk_tree_only_accuracy(pkg, O):
     """group walk vs direct summation: no worse than the reference tree at the same ErrTolForceAcc"""
     n = 40000
