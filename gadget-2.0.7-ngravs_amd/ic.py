@@ -69,6 +69,7 @@ def read_gadget_format1(path):
     masstab = np.frombuffer(h, dtype="<f8", count=6, offset=24)
     time, redshift = struct.unpack_from("<dd", h, 72)
     boxsize = struct.unpack_from("<d", h, 72 + 16 + 8 + 24 + 8)[0]
+    num_files = struct.unpack_from("<i", h, 124)[0]
     n = int(npart.sum())
     pos = np.frombuffer(block(), dtype="<f4", count=3 * n).reshape(n, 3).astype(np.float64)
     vel = np.frombuffer(block(), dtype="<f4", count=3 * n).reshape(n, 3).astype(np.float64)
@@ -86,10 +87,10 @@ def read_gadget_format1(path):
                 k += npart[t]
             start += npart[t]
     return dict(pos=pos, vel=vel, ids=ids, mass=mass, type=ptype,
-                header=dict(npart=npart, mass=masstab, time=time, redshift=redshift, boxsize=boxsize))
+                header=dict(npart=npart, mass=masstab, time=time, redshift=redshift, boxsize=boxsize, num_files=num_files))
 
 
-def write_gadget_format1(path, pos, vel, ids, ptype, masstab, mass=None, time=0.0, boxsize=0.0):
+def write_gadget_format1(path, pos, vel, ids, ptype, masstab, mass=None, time=0.0, boxsize=0.0, num_files=1):
     """Snapshot/IC format 1 (reference io.c:672-996, header allvars.h:685-708): header, POS, VEL,
     ID and a MASS block for the types whose header mass is 0.  Particles are written grouped by type, fp32 on disk."""
     pos, vel = np.asarray(pos, dtype=np.float64), np.asarray(vel, dtype=np.float64)
@@ -103,7 +104,7 @@ def write_gadget_format1(path, pos, vel, ids, ptype, masstab, mass=None, time=0.
     struct.pack_into("<dd", hdr, 72, time, 0.0)
     struct.pack_into("<ii", hdr, 88, 0, 0)
     struct.pack_into("<6I", hdr, 96, *npart)
-    struct.pack_into("<ii", hdr, 120, 0, 1)
+    struct.pack_into("<ii", hdr, 120, 0, int(num_files))
     struct.pack_into("<d", hdr, 128, boxsize)
 
     def rec(f, payload):
