@@ -338,9 +338,8 @@ def main():
     if domain:
         # OldAcc of the own particles (first num_local rows of the working set) feeds the next pass
         nl = eng.num_local()
-        tot = nl + int(eng.timings.get("halo", 0))
-        tmp = torch.zeros(tot, dtype=torch.float64, device=dev)    # ngravs_set_old_acc reads the working set's rows; own rows first
-        eng.get_old_acc_device(tmp.data_ptr())                     # ... the library delivers exactly those
+        tmp = torch.zeros(max(nl, 1), dtype=torch.float64, device=dev)   # own rows: what the library delivers and what it reads back
+        eng.get_old_acc_device(tmp.data_ptr())
         eng._check(pkg.lib().ngravs_set_old_acc(eng._h, tmp.data_ptr(), 8, 1), "ngravs_set_old_acc")
     else:
         eng.get_old_acc_device(d_old.data_ptr())

@@ -717,7 +717,11 @@ extern "C" int ngravs_set_old_acc(ngravs_ctx *c, const double *old_acc, int64_t 
   if(!c || !c->have_particles || !old_acc)
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  int rc = upload_column_f64(c, old_acc, stride, 1, c->n, on_device, c->in_oldacc.p);
+  if(c->n_local == 0)
+    return NGRAVS_OK;
+  // the caller's rows are its OWN particles (NumPart = ngravs_dd_num_local()); imported copies of a multi-task working set are
+  // sources only, their OldAcc is never read
+  int rc = upload_column_f64(c, old_acc, stride, 1, c->n_local, on_device, c->in_oldacc.p);
   if(rc)
     return rc;
   if(c->have_order)

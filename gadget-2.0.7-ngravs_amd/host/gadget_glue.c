@@ -8,9 +8,11 @@
  * timestep.c, predict.c are untouched.
  *
  * This repository cannot build the reference (its headers need GSL and FFTW-2); tests/test_host_glue.py compiles this file
- * with -fsyntax-only -Wall -Werror against tests/glue_stub/ (declarations of exactly the globals and prototypes used here,
- * layouts from SURVEY.md 8(a')), and host/host_shim_test.c drives the same library calls and the same ngravs_host_*
- * helpers on the GPU, with two tasks.
+ * with -Wall -Wextra -Werror against tests/glue_stub/ (declarations of exactly the globals and prototypes used here, layouts
+ * from SURVEY.md 8(a')), checks with nm that it defines every symbol the link recipe needs, and RUNS it on the GPU with one
+ * task (tests/glue_stub/glue_driver.c: the reference's globals, one-task MPI and the call sequence of a first step and of a
+ * short-range step with a sparse active set; P[]'s results equal the library's, forcetest.txt is written);
+ * host/host_shim_test.c drives the same library calls and the same ngravs_host_* helpers with two tasks.
  *
  * One task (NTask == 1): P[] is handed over with byte strides, results come back in P[]'s order.
  * Several tasks: the cut of the Peano curve (work-weighted, domain.c:347-544) is found by ngravs_host_domain_owners();
@@ -526,6 +528,10 @@ void gravity_tree(void)
   if(All.ComovingIntegrationOn)	/* gravtree.c:50-51: new softening lengths for the new scale factor */
     set_softenings();
   must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
+  /* the walk reads P[].OldAcc as it is NOW (gravtree.c:334-335): the first step calls gravity_tree() twice (accel.c:44-52), the
+   * second time with the OldAcc the first call has just written -- the hand-over of the decomposition does not have it yet */
+  if(NumPart > 0)
+    must(ngravs_set_old_acc(Ctx, &P[0].OldAcc, sizeof(struct particle_data), 0), 1074);
   must(ngravs_gravity_tree(Ctx), 1063);
   /* only particles with Ti_endstep == Ti_Current are written (gravtree.c:318-341); inactive rows of P[] keep their values */
   must(ngravs_get_accel(Ctx, &P[0].GravAccel[0], sizeof(struct particle_data), NULL, 0, &P[0].OldAcc,

@@ -209,7 +209,8 @@ int ngravs_set_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
  * the sorted columns and the nodes are refreshed by ngravs_force_update_tree(), which ngravs_gravity_tree() and
  * ngravs_pmforce_periodic() call by themselves when needed.  NGRAVS_ERR_STATE without a built tree. */
 int ngravs_update_particles(ngravs_ctx *ctx, const ngravs_particles_t *p);
-/* Update OldAcc only (second pass of accel.c:48-52 without re-uploading positions). */
+/* Update OldAcc only (second pass of accel.c:48-52 without re-uploading positions): the caller's OWN rows (NumPart =
+ * ngravs_dd_num_local() of them; the imported copies of a multi-task working set are sources only and keep what they came with). */
 int ngravs_set_old_acc(ngravs_ctx *ctx, const double *old_acc, int64_t stride, int on_device);
 
 /* ---- the path ---------------------------------------------------------------------------- */
