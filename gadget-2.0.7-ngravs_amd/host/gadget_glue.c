@@ -9,9 +9,10 @@
  *
  * This repository cannot build the reference (its headers need GSL and FFTW-2); tests/test_host_glue.py compiles this file
  * with -Wall -Wextra -Werror against tests/glue_stub/ (declarations of exactly the globals and prototypes used here, layouts
- * from SURVEY.md 8(a')), checks with nm that it defines every symbol the link recipe needs, and RUNS it on the GPU with one
- * task (tests/glue_stub/glue_driver.c: the reference's globals, one-task MPI and the call sequence of a first step and of a
- * short-range step with a sparse active set; P[]'s results equal the library's, forcetest.txt is written);
+ * from SURVEY.md 8(a')), checks with nm that it defines every symbol the link recipe needs, and RUNS it on the GPU with 1, 2
+ * and 3 tasks (tests/glue_stub/glue_driver.c: the reference's globals, MPI as forked processes over shared memory and the call
+ * sequence of a first step and of a short-range step with a sparse active set; P[]'s results equal the library's,
+ * forcetest.txt is written);
  * host/host_shim_test.c drives the same library calls and the same ngravs_host_* helpers with two tasks.
  *
  * One task (NTask == 1): P[] is handed over with byte strides, results come back in P[]'s order.
@@ -210,6 +211,9 @@ static void ensure_ctx(void)
   cfg.rank = 0;
   cfg.world_size = 1;
   cfg.device = ThisTask;	/* one rank per GPU of the node */
+#ifdef NGRAVS_GLUE_DEVICE
+  cfg.device = NGRAVS_GLUE_DEVICE;	/* rehearsals: several tasks on one GPU */
+#endif
   if(ngravs_create(&cfg, &Ctx) != NGRAVS_OK)
     endrun(1053);
   ngravs_set_fatal_handler(Ctx, on_fatal);

@@ -6,7 +6,9 @@
  * main: reads a particle set + parameters written by tests/test_host_glue.py, fills P[] / All the way begrun()/init() would,
  * then runs the reference's own call sequence of one force computation (accel.c:24-58 via run.c): pm_init_periodic(),
  * domain_Decomposition(), pmforce_periodic() [PM step], gravity_tree(), gravity_forcetest() [FORCETEST]; a second, short-range
- * only step with a sparse active set follows (only Ti_endstep == Ti_Current rows may change).  P[]'s results go to a file.
+ * only step with a sparse active set follows (only Ti_endstep == Ti_Current rows may change).  P[]'s results go to one file per task
+ * (rows: GravAccel, GravPM, OldAcc, GravCost, ID; the dump of step 1 and, after it, of step 2 -- the particle number of a task
+ * may differ between the two).  -DGLUE_NTASK=2: two tasks (forked processes, MPI through shared memory).
  *
  *   gcc -DNGRAVS_BUILD_INSIDE_REFERENCE -DDOUBLEPRECISION -DUNEQUALSOFTENINGS [-DPERIODIC -DPMGRID=32 -DFORCETEST=0.02]
  *       -DYUKAWA_IMASS=60 -Itests/glue_stub -Iinclude host/gadget_glue.c tests/glue_stub/glue_driver.c -lngravs_hip -lm
@@ -16,6 +18,7 @@
 #include <string.h>
 #include <math.h>
 #include <time.h>
+#include <unistd.h>
 #include <mpi.h>
 #include "allvars.h"
 #include "proto.h"
@@ -54,9 +57,9 @@ double second(void)
 double timediff(double t0, double t1) { return t1 - t0; }
 void endrun(int code)
 {
-  printf("endrun(%d)\n", code);
+  printf("task %d: endrun(%d)\n", ThisTask, code);
   fflush(stdout);
-  exit(code ? (code & 127) | 1 : 0);
+  _exit(code ? (code & 127) | 1 : 0);   /* (a task that ends the run leaves the others in their barrier: the test's timeout ends them) */
 }
 double get_random_number(int id)   /* a fixed pseudo-random number per particle ID (system.c:26-40 draws from a table of 1000) */
 {
@@ -79,64 +82,268 @@ void do_box_wrapping(void)   /* predict.c:107-133 */
 }
 #endif
 
-/* ---- MPI with one task ----------------------------------------------------------------------------------------------------- */
+/* ---- MPI: GLUE_NTASK tasks as forked processes of this program, collectives through one shared mapping ---------------------------
+ * (every task copies what it contributes into its slot, a process-shared barrier, every task copies out what it is owed, a second
+ * barrier).  Point-to-point: the glue's all-to-all-v posts at most one Isend and one Irecv per peer and then waits for all -- the
+ * exchange happens in MPI_Waitall, which every task enters once per round.  With one task everything degenerates to copies. */
+#include <pthread.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+#ifndef GLUE_NTASK
+#define GLUE_NTASK 1
+#endif
+#define SLOT ((size_t)96 << 20)
+static struct shared
+{
+  pthread_barrier_t bar;
+  int failed;
+} *Sh;
+static char *Slots;
+static char *slot(int r) { return Slots + (size_t)r * SLOT; }
+static void sync_tasks(void)
+{
+  if(NTask > 1)
+    pthread_barrier_wait(&Sh->bar);
+}
 static size_t tsize(MPI_Datatype t) { return t == MPI_BYTE ? 1 : (t == MPI_INT ? 4 : 8); }
+static void need(size_t bytes)
+{
+  if(bytes > SLOT)
+    {
+      printf("glue driver: a message of %zu bytes does not fit the shared slot\n", bytes);
+      exit(3);
+    }
+}
+static void mpi_start(void)
+{
+  pthread_barrierattr_t at;
+  int r;
+  NTask = GLUE_NTASK;
+  Sh = mmap(NULL, sizeof(*Sh), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  Slots = mmap(NULL, SLOT * (size_t)NTask, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if(Sh == MAP_FAILED || Slots == MAP_FAILED)
+    exit(3);
+  pthread_barrierattr_init(&at);
+  pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);
+  pthread_barrier_init(&Sh->bar, &at, (unsigned)NTask);
+  fflush(stdout);
+  for(r = 1; r < NTask; r++)   /* before anything has touched the GPU */
+    if(fork() == 0)
+      {
+        ThisTask = r;
+        break;
+      }
+}
+static int mpi_finish(int rc)
+{
+  int r, st, bad = rc;
+  fflush(stdout);
+  if(ThisTask != 0)
+    _exit(rc);
+  for(r = 1; r < NTask; r++)
+    if(wait(&st) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0)
+      bad = bad ? bad : 9;
+  return bad;
+}
 int MPI_Allreduce(const void *s, void *r, int n, MPI_Datatype t, MPI_Op o, MPI_Comm c)
 {
-  (void)o;
+  const size_t b = tsize(t) * (size_t)n;
+  int q, k;
   (void)c;
-  if(s != MPI_IN_PLACE)
-    memcpy(r, s, tsize(t) * (size_t)n);
+  need(b);
+  memcpy(slot(ThisTask), s == MPI_IN_PLACE ? r : s, b);
+  sync_tasks();
+  for(k = 0; k < n; k++)
+    {
+      if(t == MPI_DOUBLE)
+        {
+          double v = ((double *)slot(0))[k];
+          for(q = 1; q < NTask; q++)
+            {
+              const double w = ((double *)slot(q))[k];
+              v = o == MPI_SUM ? v + w : (o == MPI_MIN ? (w < v ? w : v) : (w > v ? w : v));
+            }
+          ((double *)r)[k] = v;
+        }
+      else if(t == MPI_LONG_LONG)
+        {
+          long long v = ((long long *)slot(0))[k];
+          for(q = 1; q < NTask; q++)
+            {
+              const long long w = ((long long *)slot(q))[k];
+              v = o == MPI_SUM ? v + w : (o == MPI_MIN ? (w < v ? w : v) : (w > v ? w : v));
+            }
+          ((long long *)r)[k] = v;
+        }
+      else
+        {
+          int v = ((int *)slot(0))[k];
+          for(q = 1; q < NTask; q++)
+            {
+              const int w = ((int *)slot(q))[k];
+              v = o == MPI_SUM ? v + w : (o == MPI_MIN ? (w < v ? w : v) : (w > v ? w : v));
+            }
+          ((int *)r)[k] = v;
+        }
+    }
+  sync_tasks();
   return MPI_SUCCESS;
 }
-int MPI_Barrier(MPI_Comm c) { (void)c; return MPI_SUCCESS; }
+int MPI_Barrier(MPI_Comm c)
+{
+  (void)c;
+  sync_tasks();
+  return MPI_SUCCESS;
+}
 int MPI_Allgatherv(const void *s, int n, MPI_Datatype t, void *r, const int *cnt, const int *dsp, MPI_Datatype rt, MPI_Comm c)
 {
-  (void)cnt;
+  int q;
   (void)rt;
   (void)c;
-  memcpy((char *)r + tsize(t) * (size_t)dsp[0], s, tsize(t) * (size_t)n);
+  need(tsize(t) * (size_t)n);
+  memcpy(slot(ThisTask), s, tsize(t) * (size_t)n);
+  sync_tasks();
+  for(q = 0; q < NTask; q++)
+    memcpy((char *)r + tsize(t) * (size_t)dsp[q], slot(q), tsize(t) * (size_t)cnt[q]);
+  sync_tasks();
   return MPI_SUCCESS;
 }
-int MPI_Bcast(void *b, int n, MPI_Datatype t, int root, MPI_Comm c) { (void)b; (void)n; (void)t; (void)root; (void)c; return MPI_SUCCESS; }
+int MPI_Bcast(void *b, int n, MPI_Datatype t, int root, MPI_Comm c)
+{
+  (void)c;
+  need(tsize(t) * (size_t)n);
+  if(ThisTask == root)
+    memcpy(slot(root), b, tsize(t) * (size_t)n);
+  sync_tasks();
+  if(ThisTask != root)
+    memcpy(b, slot(root), tsize(t) * (size_t)n);
+  sync_tasks();
+  return MPI_SUCCESS;
+}
 int MPI_Allgather(const void *s, int n, MPI_Datatype t, void *r, int rn, MPI_Datatype rt, MPI_Comm c)
 {
+  int q;
   (void)rn;
   (void)rt;
   (void)c;
-  memcpy(r, s, tsize(t) * (size_t)n);
+  need(tsize(t) * (size_t)n);
+  memcpy(slot(ThisTask), s, tsize(t) * (size_t)n);
+  sync_tasks();
+  for(q = 0; q < NTask; q++)
+    memcpy((char *)r + tsize(t) * (size_t)n * (size_t)q, slot(q), tsize(t) * (size_t)n);
+  sync_tasks();
   return MPI_SUCCESS;
 }
 int MPI_Alltoall(const void *s, int n, MPI_Datatype t, void *r, int rn, MPI_Datatype rt, MPI_Comm c)
 {
-  return MPI_Allgather(s, n, t, r, rn, rt, c);
+  const size_t b = tsize(t) * (size_t)n;
+  int q;
+  (void)rn;
+  (void)rt;
+  (void)c;
+  need(b * (size_t)NTask);
+  memcpy(slot(ThisTask), s, b * (size_t)NTask);
+  sync_tasks();
+  for(q = 0; q < NTask; q++)
+    memcpy((char *)r + b * (size_t)q, slot(q) + b * (size_t)ThisTask, b);
+  sync_tasks();
+  return MPI_SUCCESS;
 }
 int MPI_Alltoallv(const void *s, const int *sc, const int *sd, MPI_Datatype t, void *r, const int *rc, const int *rd, MPI_Datatype rt, MPI_Comm c)
 {
-  (void)rc;
+  const size_t e = tsize(t), hdr = sizeof(int) * 64;
+  size_t end = 0;
+  int q;
   (void)rt;
   (void)c;
-  memcpy((char *)r + tsize(t) * (size_t)rd[0], (const char *)s + tsize(t) * (size_t)sd[0], tsize(t) * (size_t)sc[0]);
+  for(q = 0; q < NTask; q++)
+    if((size_t)(sd[q] + sc[q]) > end)
+      end = (size_t)(sd[q] + sc[q]);
+  need(hdr + e * end);
+  memcpy(slot(ThisTask), sd, sizeof(int) * (size_t)NTask);   /* where each peer's block starts in my send buffer */
+  if(end)
+    memcpy(slot(ThisTask) + hdr, s, e * end);
+  sync_tasks();
+  for(q = 0; q < NTask; q++)
+    if(rc[q] > 0)
+      memcpy((char *)r + e * (size_t)rd[q], slot(q) + hdr + e * (size_t)((int *)slot(q))[ThisTask], e * (size_t)rc[q]);
+  sync_tasks();
   return MPI_SUCCESS;
 }
-/* (never reached with one task: the glue's all-to-all-v over Isend/Irecv only runs inside ngravs_host_* with NTask > 1) */
-int MPI_Irecv(void *b, int n, MPI_Datatype t, int src, int tag, MPI_Comm c, MPI_Request *q) { (void)b; (void)n; (void)t; (void)src; (void)tag; (void)c; (void)q; return 1; }
-int MPI_Isend(const void *b, int n, MPI_Datatype t, int dst, int tag, MPI_Comm c, MPI_Request *q) { (void)b; (void)n; (void)t; (void)dst; (void)tag; (void)c; (void)q; return 1; }
-int MPI_Waitall(int n, MPI_Request *q, MPI_Status *s) { (void)n; (void)q; (void)s; return 1; }
+/* point-to-point of one round: at most one send and one receive per peer, completed together in MPI_Waitall */
+static struct pend
+{
+  const void *sbuf[64];
+  void *rbuf[64];
+  size_t sb[64], rb[64];
+} Pend;
+int MPI_Irecv(void *b, int n, MPI_Datatype t, int src, int tag, MPI_Comm c, MPI_Request *q)
+{
+  (void)tag;
+  (void)c;
+  Pend.rbuf[src] = b;
+  Pend.rb[src] = tsize(t) * (size_t)n;
+  *q = 0;
+  return MPI_SUCCESS;
+}
+int MPI_Isend(const void *b, int n, MPI_Datatype t, int dst, int tag, MPI_Comm c, MPI_Request *q)
+{
+  (void)tag;
+  (void)c;
+  Pend.sbuf[dst] = b;
+  Pend.sb[dst] = tsize(t) * (size_t)n;
+  *q = 0;
+  return MPI_SUCCESS;
+}
+int MPI_Waitall(int n, MPI_Request *q, MPI_Status *s)
+{
+  const size_t hdr = sizeof(size_t) * 128;
+  size_t *h = (size_t *)slot(ThisTask), off = 0;
+  int p, rc = MPI_SUCCESS;
+  (void)n;
+  (void)q;
+  (void)s;
+  for(p = 0; p < NTask; p++)   /* header: offset and length of the block for every peer */
+    {
+      h[2 * p] = off;
+      h[2 * p + 1] = Pend.sb[p];
+      off += Pend.sb[p];
+    }
+  need(hdr + off);
+  for(p = 0; p < NTask; p++)
+    if(Pend.sb[p])
+      memcpy(slot(ThisTask) + hdr + h[2 * p], Pend.sbuf[p], Pend.sb[p]);
+  sync_tasks();
+  for(p = 0; p < NTask; p++)
+    if(Pend.rb[p])
+      {
+        const size_t *hp = (const size_t *)slot(p);
+        if(hp[2 * ThisTask + 1] != Pend.rb[p])
+          rc = 1;   /* the peer sends another size than this task expects */
+        else
+          memcpy(Pend.rbuf[p], slot(p) + hdr + hp[2 * ThisTask], Pend.rb[p]);
+      }
+  sync_tasks();
+  memset(&Pend, 0, sizeof(Pend));
+  return rc;
+}
 
 /* ---- the run ----------------------------------------------------------------------------------------------------------------- */
 static void dump(FILE *f)
 {
+  const double np = (double)NumPart;
   int i;
+  fwrite(&np, sizeof(double), 1, f);
   for(i = 0; i < NumPart; i++)
     {
-      double row[8] = {P[i].GravAccel[0], P[i].GravAccel[1], P[i].GravAccel[2], 0, 0, 0, P[i].OldAcc, (double)P[i].GravCost};
+      double row[9] = {P[i].GravAccel[0], P[i].GravAccel[1], P[i].GravAccel[2], 0, 0, 0, P[i].OldAcc, (double)P[i].GravCost, (double)P[i].ID};
 #ifdef PMGRID
       row[3] = P[i].GravPM[0];
       row[4] = P[i].GravPM[1];
       row[5] = P[i].GravPM[2];
 #endif
-      fwrite(row, sizeof(double), 8, f);
+      fwrite(row, sizeof(double), 9, f);
     }
 }
 
@@ -144,12 +351,16 @@ int main(int argc, char **argv)
 {
   FILE *f;
   double hd[16];
-  int i, j, n;
-  if(argc < 3 || !(f = fopen(argv[1], "rb")))
+  char name[600];
+  int i, j, n, k = 0;
+  if(argc < 3)
     return 2;
-  /* header: n, G, BoxSize, ErrTolTheta, ErrTolForceAcc, softening[6] (ForceSoftening / 2.8 = the Plummer-equivalent lengths) */
+  mpi_start();                   /* GLUE_NTASK tasks from here on (forked before anything touches the GPU) */
+  if(!(f = fopen(argv[1], "rb")))
+    return mpi_finish(2);
+  /* header: n, G, BoxSize, ErrTolTheta, ErrTolForceAcc, softening[6] (the Plummer-equivalent lengths of the six types) */
   if(fread(hd, sizeof(double), 11, f) != 11)
-    return 3;
+    return mpi_finish(3);
   n = (int)hd[0];
   memset(&All, 0, sizeof(All));
   All.G = hd[1];
@@ -164,30 +375,33 @@ int main(int argc, char **argv)
   All.SofteningBndry = hd[10];
   All.TypeOfOpeningCriterion = 1;
   All.TotNumPart = n;
-  All.MaxPart = n + 16;
-  All.PartAllocFactor = 1.5;
+  All.PartAllocFactor = 1.6;
+  All.MaxPart = (int)(All.PartAllocFactor * n / NTask) + 16;
   All.TreeAllocFactor = 0.8;
   All.TreeDomainUpdateFrequency = 0.0;
   All.Time = 1.0;
   strcpy(All.OutputDir, argc > 3 ? argv[3] : "./");
   P = calloc((size_t)All.MaxPart, sizeof(*P));
-  NumPart = n;
-  for(i = 0; i < n; i++)
+  for(i = 0; i < n; i++)         /* task r starts with every NTask-th particle: an arbitrary distribution, as after read_ic() */
     {
       double row[5];
       if(fread(row, sizeof(double), 5, f) != 5)
-        return 4;
-      P[i].Pos[0] = row[0];
-      P[i].Pos[1] = row[1];
-      P[i].Pos[2] = row[2];
-      P[i].Mass = row[3];
-      P[i].Type = (int)row[4];
-      P[i].ID = (unsigned int)(i + 1);
-      P[i].Ti_endstep = 0;
+        return mpi_finish(4);
+      if(i % NTask != ThisTask)
+        continue;
+      P[k].Pos[0] = row[0];
+      P[k].Pos[1] = row[1];
+      P[k].Pos[2] = row[2];
+      P[k].Mass = row[3];
+      P[k].Type = (int)row[4];
+      P[k].ID = (unsigned int)(i + 1);
+      P[k].Ti_endstep = 0;
+      k++;
     }
+  NumPart = k;
   fclose(f);
-  /* init_grav_maps(): types 1..N_GRAVS -> species 0..N_GRAVS-1, the rest species 0, and the wiring of the bench's C4 case (ngravs_core.c:201-425): Newton inside a
-   * species, Newton + Yukawa ("coloyuk") across; for N_GRAVS = 1 plain Newton */
+  /* init_grav_maps(): types 1..N_GRAVS -> species 0..N_GRAVS-1, the rest species 0, and the wiring of the bench's C4 case
+   * (ngravs_core.c:201-425): Newton inside a species, Newton + Yukawa ("coloyuk") across; for N_GRAVS = 1 plain Newton */
   for(i = 0; i < 6; i++)
     TypeToGrav[i] = (i >= 1 && i <= N_GRAVS) ? i - 1 : 0;
   for(i = 0; i < N_GRAVS; i++)
@@ -208,9 +422,10 @@ int main(int argc, char **argv)
 #ifdef PERIODIC
   lattice_init();                /* begrun.c:48 (a no-op here: the tables are built on the device on first use) */
 #endif
-  f = fopen(argv[2], "wb");
+  snprintf(name, sizeof(name), "%s.%d", argv[2], ThisTask);
+  f = fopen(name, "wb");
   if(!f)
-    return 5;
+    return mpi_finish(5);
   /* step 1: every particle active, a PM step: compute_accelerations(0), accel.c:24-58 */
   All.Ti_Current = 0;
   All.PM_Ti_endstep = 0;
@@ -229,12 +444,13 @@ int main(int argc, char **argv)
   All.Ti_Current = 8;
   All.PM_Ti_endstep = 16;
   for(i = 0; i < NumPart; i++)
-    P[i].Ti_endstep = (i % 5 == 2) ? 8 : 16;
+    P[i].Ti_endstep = ((P[i].ID - 1) % 5 == 2) ? 8 : 16;
   All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart;   /* TreeDomainUpdateFrequency = 0: every step re-decomposes */
   domain_Decomposition();
   gravity_tree();
   dump(f);
   fclose(f);
-  printf("glue driver: %d particles, N_GRAVS %d, two steps done; TotNumOfForces %lld\n", NumPart, N_GRAVS, All.TotNumOfForces);
-  return 0;
+  printf("glue driver: task %d of %d holds %d particles, N_GRAVS %d, two steps done; TotNumOfForces %lld\n", ThisTask, NTask, NumPart, N_GRAVS,
+         All.TotNumOfForces);
+  return mpi_finish(0);
 }
