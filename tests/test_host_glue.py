@@ -103,10 +103,12 @@ def test_c_host_runs_on_gpu(pkg, have_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("opts", [["-DPERIODIC", "-DPMGRID=32", "-DFORCETEST=0.02"], [],
-                                  ["-DPERIODIC", "-DPMGRID=32", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"],
-                                  ["-DGLUE_NTASK=3", "-DNGRAVS_GLUE_DEVICE=0"]])
-def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
+@pytest.mark.parametrize("opts,ng", [(["-DPERIODIC", "-DPMGRID=32", "-DFORCETEST=0.02"], 2), ([], 2),
+                                     (["-DPERIODIC", "-DPMGRID=32", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"], 2),
+                                     (["-DGLUE_NTASK=3", "-DNGRAVS_GLUE_DEVICE=0"], 2),
+                                     (["-DPERIODIC", "-DPMGRID=32", "-DGLUE_NTASK=3", "-DNGRAVS_GLUE_DEVICE=0"], 3),
+                                     (["-DPERIODIC", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"], 2)])
+def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     """gadget_glue.c EXECUTED, not only compiled: built against the interface stubs together with tests/glue_stub/glue_driver.c (the
     reference's globals, MPI for 1-3 tasks as forked processes over shared memory, second / endrun / do_box_wrapping /
     get_random_number) it runs the reference's own call sequence of a first step -- pm_init_periodic, domain_Decomposition,
@@ -121,15 +123,16 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
     root = os.path.join(os.path.dirname(pkg.__file__), "..")
     pm = any(o.startswith("-DPMGRID") for o in opts)
     ntask = max([int(o.split("=")[1]) for o in opts if o.startswith("-DGLUE_NTASK")] + [1])
-    n, L, ng = 20000, 1.0, 2
-    if pm:
+    periodic = "-DPERIODIC" in opts
+    n, L = (20000 if pm or not periodic else 6000), 1.0      # (periodic tree-only: the lattice walk and its direct sum are the slow ones)
+    if periodic:
         pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=5)
     else:
         pos, mass, typ = pkg.ic.plummer_sphere(n, seed=5)
         typ = (1 + (np.arange(n) % ng)).astype(np.int32)
-    eps = (L / (40 * n ** (1 / 3))) if pm else 0.01
+    eps = (L / (40 * n ** (1 / 3))) if periodic else 0.01
     soft = [eps, eps, 1.5 * eps, eps, eps, eps]
-    hd = np.array([n, 1.0, L if pm else 0.0, 0.5, 0.005] + soft, dtype=np.float64)
+    hd = np.array([n, 1.0, L if periodic else 0.0, 0.5, 0.005] + soft, dtype=np.float64)
     rows = np.column_stack([pos, mass, typ.astype(np.float64)])
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(fin, "wb") as f:
@@ -162,7 +165,7 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
         assert at == len(raw)
     assert np.all(seen == 1)                                                # every particle on exactly one task, both steps
     # the same calls from the Python host (one task)
-    cfg = pkg.make_config(n_gravs=ng, periodic=1 if pm else 0, pmgrid=32 if pm else 0, box_size=L if pm else 0.0, G=1.0, theta=0.5,
+    cfg = pkg.make_config(n_gravs=ng, periodic=1 if periodic else 0, pmgrid=32 if pm else 0, box_size=L if periodic else 0.0, G=1.0, theta=0.5,
                           err_tol_force_acc=0.005, softening=soft, type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4",
                           walk_mode=pkg.WALK_GROUP, tree_alloc_factor=0.8)
     eng = pkg.Engine(cfg)
@@ -182,9 +185,10 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
     def same(x, y, tol=1e-12):   # GravPM is summed by atomics (order varies from run to run): rounding noise there and in what it enters
         return np.abs(x - y).max() <= tol * max(np.abs(y).max(), 1e-300)
 
-    def walks_agree(x, y, tot):  # two valid groupings of the production walk
+    def walks_agree(x, y, tot, loose=1.0):  # two valid groupings of the production walk (each within ErrTolForceAcc of the truth)
         e = np.linalg.norm(x - y, axis=1) / np.linalg.norm(tot, axis=1)
-        return np.median(e) < 1e-6 and np.quantile(e, 0.99) < 5e-3 and e.max() < 5e-2
+        print("   production walk on %d task(s) vs one: |da|/|a| median %.1e, 99 %% %.1e, max %.1e" % (ntask, np.median(e), np.quantile(e, 0.99), e.max()))
+        return np.median(e) < 1e-4 * loose and np.quantile(e, 0.99) < 5e-3 * loose and e.max() < 5e-2 * loose
     if ntask == 1:
         assert np.array_equal(s1[:, 0:3], a2) and same(s1[:, 3:6], p2) and same(s1[:, 6], o2)
         assert np.array_equal(s1[:, 7], c2.astype(np.float64))
@@ -203,7 +207,8 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
     if ntask == 1:
         assert same(s2[:, 0:3], a3) and same(s2[:, 6], o3) and np.mean(s2[:, 7] == c3.astype(np.float64)) > 0.999
     else:
-        assert walks_agree(s2[~idle, 0:3], a3[~idle], (a3 + p2)[~idle])
+        # (groups of 64 consecutive ACTIVE own particles are five times as wide, and cut differently on several tasks)
+        assert walks_agree(s2[~idle, 0:3], a3[~idle], (a3 + p2)[~idle], loose=4.0)
     assert np.array_equal(s2[:, 3:6], s1[:, 3:6])                          # GravPM untouched by the short-range step (it travels with P[])
     assert np.array_equal(s2[idle, 0:3], s1[idle, 0:3]) and np.array_equal(s2[idle, 6], s1[idle, 6])   # inactive rows keep their values
     assert np.array_equal(s2[idle, 7], s1[idle, 7])
@@ -211,11 +216,13 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts):
     if "-DFORCETEST=0.02" in opts:
         lines = [ln.split() for ln in open(str(tmp_path / "forcetest.txt"))]
         want = sum(1 for i in range(n) if ((((i + 1) * 2654435761) & 0xffffffff) ^ ((((i + 1) * 2654435761) & 0xffffffff) >> 15)) % 1000 < 20)
-        assert len(lines) == want and all(len(ln) == 16 for ln in lines)
+        # gravtree_forcetest.c:297-311: 16 columns with PMGRID (%.15e, tree and tree + PM), 13 without (%g, the tree force is the total)
+        ncol = 16 if pm else 13
+        assert len(lines) == want and all(len(ln) == ncol for ln in lines)
         t = np.array([[float(v) for v in ln] for ln in lines])
-        direct, total = t[:, 6:9], t[:, 12:15]
+        direct, total = t[:, 6:9], (t[:, 12:15] if pm else t[:, 9:12])
         err = np.linalg.norm(total - direct, axis=1) / np.linalg.norm(direct, axis=1)
-        ids = t[:, 15].astype(int) - 1
-        assert np.allclose(t[:, 9:12], s1[ids, 0:3], rtol=1e-14, atol=0)  # the GravAccel column is P[].GravAccel
+        ids = t[:, ncol - 1].astype(int) - 1
+        assert np.allclose(t[:, 9:12], s1[ids, 0:3], rtol=1e-14 if pm else 1e-5, atol=0)  # the GravAccel column is P[].GravAccel
         print("forcetest.txt: %d lines, tree+PM vs direct sum rms %.2e max %.2e" % (len(lines), np.sqrt(np.mean(err ** 2)), err.max()))
         assert np.sqrt(np.mean(err ** 2)) < 2e-2
