@@ -449,6 +449,24 @@ int main(int argc, char **argv)
   domain_Decomposition();
   gravity_tree();
   dump(f);
+  if(NTask == 1)
+    {
+      /* step 3 (one task): TreeDomainUpdateFrequency > 0 and few forces since the last decomposition -- domain.c:76 keeps
+       * decomposition and tree, the particles have drifted (move_particles, predict.c:36-104: no box wrapping between
+       * decompositions): the glue hands the drifted positions over and the library refits the tree */
+      All.TreeDomainUpdateFrequency = 1.0;
+      All.NumForcesSinceLastDomainDecomp = 0;
+      All.Ti_Current = 12;
+      for(i = 0; i < NumPart; i++)
+        {
+          P[i].Ti_endstep = ((P[i].ID - 1) % 3 == 1) ? 12 : 16;
+          for(j = 0; j < 3; j++)
+            P[i].Pos[j] += 1e-3 * (All.BoxSize > 0 ? All.BoxSize : 1.0) * sin(0.37 * (double)P[i].ID + 1.3 * j);
+        }
+      domain_Decomposition();
+      gravity_tree();
+      dump(f);
+    }
   fclose(f);
   printf("glue driver: task %d of %d holds %d particles, N_GRAVS %d, two steps done; TotNumOfForces %lld\n", ThisTask, NTask, NumPart, N_GRAVS,
          All.TotNumOfForces);

@@ -148,13 +148,14 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe, fin, fout, str(tmp_path) + "/"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    out = np.zeros((2, n, 8))
-    seen = np.zeros((2, n), dtype=np.int64)
+    nstep = 3 if ntask == 1 else 2
+    out = np.zeros((nstep, n, 8))
+    seen = np.zeros((nstep, n), dtype=np.int64)
     own = []
     for t in range(ntask):
         raw = np.fromfile(fout + ".%d" % t, dtype=np.float64)
         at = 0
-        for step in range(2):
+        for step in range(nstep):
             k = int(raw[at])
             blk = raw[at + 1: at + 1 + 9 * k].reshape(k, 9)
             at += 1 + 9 * k
@@ -201,6 +202,19 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     eng.compute_accelerations(pm_step=False)
     a3, o3, c3 = a2.copy(), o2.copy(), c2.copy()
     eng.get_accel(into=(a3, o3, c3))
+    if ntask == 1:
+        # step 3: the drifted tree (domain.c:76 keeps decomposition and tree; the glue hands drifted positions over, the library refits)
+        idn = np.arange(1, n + 1, dtype=np.float64)
+        pos3 = pos + 1e-3 * (L if periodic else 1.0) * np.sin(0.37 * idn[:, None] + 1.3 * np.arange(3)[None, :])
+        act3 = (np.arange(n) % 3 == 1).astype(np.uint8)
+        eng.update_particles(pos3, mass, typ, old_acc=o3, active=act3)
+        eng.gravity_tree()
+        a4, o4, c4 = a3.copy(), o3.copy(), c3.copy()
+        eng.get_accel(into=(a4, o4, c4))
+        s3 = out[2]
+        assert same(s3[:, 0:3], a4) and same(s3[:, 6], o4) and np.mean(s3[:, 7] == c4.astype(np.float64)) > 0.999
+        idle3 = act3 == 0
+        assert np.array_equal(s3[idle3, 0:3], out[1][idle3, 0:3]) and np.array_equal(s3[:, 3:6], out[0][:, 3:6])
     eng.close()
     s2 = out[1]
     idle = act == 0
