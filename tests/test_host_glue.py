@@ -107,7 +107,8 @@ def test_c_host_runs_on_gpu(pkg, have_lib):
                                      (["-DPERIODIC", "-DPMGRID=32", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"], 2),
                                      (["-DGLUE_NTASK=3", "-DNGRAVS_GLUE_DEVICE=0"], 2),
                                      (["-DPERIODIC", "-DPMGRID=32", "-DGLUE_NTASK=3", "-DNGRAVS_GLUE_DEVICE=0"], 3),
-                                     (["-DPERIODIC", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"], 2)])
+                                     (["-DPERIODIC", "-DFORCETEST=0.02", "-DGLUE_NTASK=2", "-DNGRAVS_GLUE_DEVICE=0"], 2),
+                                     (["-DPERIODIC", "-DPMGRID=32", "-DNGRAVS_WITH_RCCL"], 2)])
 def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     """gadget_glue.c EXECUTED, not only compiled: built against the interface stubs together with tests/glue_stub/glue_driver.c (the
     reference's globals, MPI for 1-3 tasks as forked processes over shared memory, second / endrun / do_box_wrapping /
@@ -118,7 +119,8 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     (GravPM, summed by atomics, and the OldAcc it enters to rounding).  Two / three tasks (P[] migrated by the glue with whole
     particle_data records, exchanges staged through host memory by the MPI vtable): every particle on exactly one task, GravPM of
     the single mesh to 1e-10, the production walk's force as two valid groupings agree.  Always: inactive rows keep their values;
-    forcetest.txt holds one line per tested particle (appended task by task) whose direct sum agrees with tree + PM."""
+    forcetest.txt holds one line per tested particle (appended task by task) whose direct sum agrees with tree + PM.  The last variant
+    builds the glue with -DNGRAVS_WITH_RCCL: its communicator is libngravs_rccl.so (created from an MPI_Bcast id, self-tested), one task."""
     import numpy as np
     root = os.path.join(os.path.dirname(pkg.__file__), "..")
     pm = any(o.startswith("-DPMGRID") for o in opts)
@@ -143,7 +145,7 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng):
     cmd = ["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-DNGRAVS_BUILD_INSIDE_REFERENCE", "-DDOUBLEPRECISION", "-DUNEQUALSOFTENINGS",
            "-DN_GRAVS=%d" % ng, "-DYUKAWA_IMASS=60"] + opts + ["-I" + os.path.join(root, "tests", "glue_stub"), "-I" + os.path.join(root, "include"),
            os.path.join(os.path.dirname(pkg.__file__), "host", "gadget_glue.c"), os.path.join(root, "tests", "glue_stub", "glue_driver.c"),
-           "-o", exe, "-L" + libdir, "-lngravs_hip", "-lm", "-lpthread", "-Wl,-rpath," + libdir]
+           "-o", exe, "-L" + libdir, "-lngravs_hip"] + (["-lngravs_rccl"] if "-DNGRAVS_WITH_RCCL" in opts else []) + ["-lm", "-lpthread", "-Wl,-rpath," + libdir]
     b = subprocess.run(cmd, capture_output=True, text=True)
     assert b.returncode == 0, b.stderr[-3000:]
     r = subprocess.run([exe, fin, fout, str(tmp_path) + "/"], capture_output=True, text=True, timeout=300)
