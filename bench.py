@@ -212,8 +212,8 @@ def self_launch(ngpus):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=26, help="log2 of the particle number (26 = the 64M headline)")
     ap.add_argument("--pmgrid", type=int, default=0, help="0 = 2 cells per particle (512 at 64M)")
     ap.add_argument("--ngravs", type=int, default=2)
