@@ -183,6 +183,56 @@ def test_random_configurations_against_the_oracle(pkg, O, seed):
     assert e2 < 1e-8 and same2 > 0.999
 
 
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_configurations_production_walk_accuracy(pkg, seed):
+    """The production (group) walk against the reference walk over random small configurations (species, wiring, TreePM / tree-only,
+    clustering, unequal softening lengths), both with the relative criterion, both measured against the direct sum of a sample
+    (gravtree_forcetest.c's truth: tree + PM against the periodic direct sum in a box): the production walk is not less accurate
+    than the reference walk on the same input."""
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(5000, 30000))
+    ng = int(rng.integers(1, 4))
+    pm = seed % 2 == 1
+    L = 1.0
+    pos = rng.random((n, 3))
+    if rng.random() < 0.7:
+        k = int(n * rng.uniform(0.1, 0.8))
+        pos[:k] = np.mod(rng.random(3) + rng.uniform(0.01, 0.2) * rng.standard_normal((k, 3)), 1.0)
+    pos = np.clip(pos, 0.0, 1.0 - 1e-12) * L
+    mass = rng.uniform(0.5, 1.5, n) / n
+    typ = (1 + rng.integers(0, ng, n)).astype(np.int32) if ng > 1 else rng.integers(0, 6, n).astype(np.int32)
+    eps = L / (40 * n ** (1 / 3))
+    soft = [eps * float(rng.choice([1.0, 1.0, 2.0])) for _ in range(6)]
+    wiring = "newton" if (ng == 1 or not pm) else str(rng.choice(["c4", "newton"]))
+    res = {}
+    for mode in (pkg.WALK_STRICT, pkg.WALK_GROUP):
+        kw = dict(n_gravs=ng, G=1.0, theta=0.5, softening=soft, type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=mode)
+        if pm:
+            kw.update(periodic=1, pmgrid=int(32 if n < 15000 else 64), box_size=L)
+        cfg = pkg.make_config(**kw)
+        eng = _engine(pkg, cfg, pos, mass, typ)
+        eng.compute_accelerations(pm_step=pm)
+        _, old, _ = eng.get_accel()
+        eng.set_old_acc(old)
+        eng.set_opening(0.0, 0.005)
+        eng.gravity_tree()
+        if pm:
+            a, _, c, p = eng.get_accel(want_pm=True)
+        else:
+            a, _, c = eng.get_accel()
+            p = 0.0
+        idx = np.arange(seed % 7, n, max(1, n // 600), dtype=np.int32)
+        if "truth" not in res:
+            res["truth"] = eng.direct_sum(idx)
+        e = rel_err((a + p)[idx], res["truth"])
+        res[mode] = (np.sqrt(np.mean(e ** 2)), e.max(), c.mean())
+        eng.close()
+    (rs, ms, cs), (rg, mg, cg) = res[pkg.WALK_STRICT], res[pkg.WALK_GROUP]
+    print("seed %d: n %d, N_GRAVS %d, %s, %s: reference walk rms %.2e max %.2e (%.0f ia) | production walk rms %.2e max %.2e (%.0f ia)"
+          % (seed, n, ng, wiring, "TreePM %d" % cfg.pmgrid if pm else "tree-only", rs, ms, cs, rg, mg, cg))
+    assert rg <= 1.1 * rs + 1e-4 and mg <= max(2.0 * ms, 0.03)
+
+
 def test_group_walk_tree_only_accuracy(pkg, O):
     """group walk vs direct summation: no worse than the reference tree at the same ErrTolForceAcc"""
     n = 40000
