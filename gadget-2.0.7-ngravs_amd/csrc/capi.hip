@@ -923,6 +923,14 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
   c->stats.interactions = h[0];
   c->stats.n_active = (int64_t)h[1];
   c->have_acc = true;
+  if(c->cfg.pmgrid && c->cfg.walk_mode == NGRAVS_WALK_GROUP && h[1] > 0 && c->cfg.box_size > 0)
+    {
+      // pairs per target against the uniform expectation: the cut sphere's volume times the mean density of ALL tasks' particles
+      const double reach = (c->cfg.group_reach > 0 ? c->cfg.group_reach : NGRAVS_GROUP_REACH) * c->asmth;
+      const double ntot = c->top.on && c->top.total_count > 0 ? c->top.total_count : (double)c->n;
+      const double L = c->cfg.box_size, expect = 4.18879020478639 * reach * reach * reach * ntot / (L * L * L);
+      c->walk_ia_ratio = expect > 0 ? (h[0] / h[1]) / expect : 0.0;
+    }
   if(c->shard_count > 0 && c->extent_override)   // the work weights only matter to a multi-task domain cut
     hipLaunchKernelGGL(k_cost_update, GRID1(c->shard_count), 0, c->stream, c->s_idx.p, c->s_active.p, c->r_nint.p,
                        (long long)c->shard_first, (long long)c->shard_count, c->in_cost.p);

@@ -135,6 +135,7 @@ struct Tuning
 #define TOP_CW(ng) (7 + 4 * (ng))   // doubles per node: count (leaf sums: work), particles per type [6], per species m, m x, m y, m z
 struct TopTree
 {
+  double total_count = 0;   // particles of all tasks (the root's count of the last ngravs_dd_set_top)
   bool on = false;                     // sums + presence are set: the next tree build forces the global top (ngravs_dd_set_top)
   double import_reach = 0;             // short-range reach (units of Asmth) the import decision was made for (walk mode at set_top)
   ngravs_toptree h = {0, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, nullptr};   // host copy: child, level, xyz, leaf numbers
@@ -238,6 +239,8 @@ struct ngravs_ctx
   bool walk_dense_tlist = false;  // ... and that list is the own rows of a multi-task working set, nearly all of them active
   int walk_spread = 0;        // > 1: every group of 64 targets is walked as `spread` sub-groups by the fused kernel
   int walk_sg = 1;            // split walk: groups per traversal unit (shared item lists) of the last launch
+  double walk_ia_ratio = 0;   // pairs per target of the last TreePM group walk / what a uniform box of the same mean density gives
+                              // (0: no such walk yet): > 1 in clustered sets, where smaller traversal units accept more cells
   bool all_active = true;     // the caller passed no active flags
   DevBuf<int> walk_ovf;       // split walk: groups left to the fused kernel (lists or LIFO outgrew their region)
   DevBuf<int> walk_counters;  // [1] overflow flag, [2] groups in walk_ovf, [3] of them by the LIFO, [8..15] per-XCD group counters, [16..23] 64-bit walk statistics

@@ -974,6 +974,7 @@ int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *pres
   HIP_TRY(c, hipMemcpyAsync(t.info.p, info.data(), (size_t)nn, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   t.on = true;
+  t.total_count = cnt.empty() ? 0.0 : (double)cnt[0];
   t.import_reach = c->cfg.walk_mode == NGRAVS_WALK_GROUP ? fmin(6.0, c->cfg.group_reach > 0 ? c->cfg.group_reach : NGRAVS_GROUP_REACH) : 6.0;
   c->have_tree = false;
   return NGRAVS_OK;

@@ -2458,6 +2458,14 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   // 1.7 x that of 64: lists and traversal work per target fall to ~0.4), 1 for tree-only walks (no cut: a wider box opens more
   // of the tree for every target) and for scattered (compacted / spread) targets
   int SG = (PM && (c->walk_ntargets < 0 || c->walk_dense_tlist)) ? 4 : 1;
+  // ... in a CLUSTERED set the last walk says so: it evaluated more pairs per target than a uniform box of the same mean density
+  // holds in the cut sphere (every source inside the sphere a particle: the uniform regime).  A smaller unit has a smaller box,
+  // accepts more cells as monopoles, and wins back more than its longer lists cost (2^20 particles, 60 % of them in one clump:
+  // 1857 / 1393 / 1079 pairs per target and 8.0 / 7.2 / 5.2 ms for units of 4 / 2 / 1 groups)
+  if(SG == 4 && c->walk_ia_ratio > 2.0)
+    SG = 1;
+  else if(SG == 4 && c->walk_ia_ratio > 1.4)
+    SG = 2;
   if(c->tune.walk_sg >= 1)
     SG = c->tune.walk_sg;
   if(SG != c->walk_sg)

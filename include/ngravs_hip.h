@@ -188,7 +188,7 @@ int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
  *   "walk_waves" n: waves per evaluation workgroup (<= 16)                         "walk_lcap" n: initial item-list capacity (>= 1024)
  *   "walk_root" 1: TreePM group walks start at the root, not at the start table   "walk_compact" 0: do not compact sparse active sets
  *   "walk_spread" S: lanes per target for compacted active sets (1..64, 0 = auto)  "walk_exact_reach" 1: fp64 reach test, no fp32 pre-test
- *   "walk_sg" n: groups of 64 targets per traversal unit = per shared item list (0 = auto: 4 with TreePM, else 1)
+ *   "walk_sg" n: groups of 64 targets per traversal unit = per shared item list (0 = auto: with TreePM 4, or 2 / 1 when the last walk evaluated more than 1.4 / 2 x the pairs per target of a uniform box -- a clustered set; else 1)
  *   "walk_nleaf" k: an opened node with <= k particles hands its particles over instead of its children (0..8, -1 = default 8)
  *   "pm_notile" 1: per-particle CIC deposit     "pm_fused_gather" 1: one-pass gradient+gather    "pm_tile_gather" 1: LDS-tiled gather
  *   "pm_tile8" 1: deposit tiles of 8 instead of 16 mesh cells    "tree_levelwise" 1: level-by-level tree build for single-task trees too
