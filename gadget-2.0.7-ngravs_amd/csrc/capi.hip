@@ -464,6 +464,10 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.walk_spread = (int)iv;
   else if(k == "walk_sg" && iv >= 0 && iv <= 16)
     t.walk_sg = (int)iv;
+  else if(k == "walk_ring" && iv >= 0 && iv <= 1)
+    t.walk_ring = (int)iv;
+  else if(k == "walk_ring_k" && iv >= 0 && iv <= 8)
+    t.walk_ring_k = (int)iv;
   else if(k == "walk_nleaf" && iv >= -1 && iv <= 8)
     t.walk_nleaf = (int)iv;
   else if(k == "walk_exact_reach")

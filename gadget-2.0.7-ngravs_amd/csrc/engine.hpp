@@ -124,7 +124,9 @@ struct Tuning
   int pm_notile = 0, pm_fused_gather = 0, pm_tile_gather = 0, pm_tile8 = 0;
   int sort_full = 0;        // Peano order by one radix sort on all 63 key bits (default: top 42 bits + fix-up of the rare ties)
   int tree_levelwise = 0;   // build the tree level by level (the multi-task path) also for single-task trees
-  int moments_octet = 0;    // moments pass with eight lanes per node (k_moments8; measured slower: 5.7 against 5.0 ms of build at C4)
+  int moments_octet = 0;
+  int walk_ring = 1;        // TreePM evaluation through the ring-pool kernel (kernels_eval.hip); 0: k_walk_group2<...,2>
+  int walk_ring_k = 0;      // ... with at most this many slots per wave (0: as many as fit, at most 8)    // moments pass with eight lanes per node (k_moments8; measured slower: 5.7 against 5.0 ms of build at C4)
 };
 
 // The global top of the tree for multi-task runs (force_exchange_pseudodata / force_treeupdate_pseudos, forcetree.c:766-996):
@@ -303,6 +305,10 @@ int walk_run(ngravs_ctx *c);
 int walk_finish(ngravs_ctx *c);
 int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc);
 int direct_run_targets(ngravs_ctx *c, const double4 *d_tpm, const int *d_ttype, int64_t nt, double *d_acc);
+// ---- kernels_eval.hip
+int eval_ring_slots(const WalkParams &wp, int waves);
+int launch_eval_ring(ngravs_ctx *c, const TreeView &tv, const WalkParams &wp, bool yuk, int nblk, int waves, int K, const int *region,
+                     const int *gcount, long long g0, long long nb, int lcap, int scap, int S, const int *tlist, int SG, long long t_count);
 // ---- kernels_pm.hip
 int pm_run(ngravs_ctx *c);
 int pm_deposit(ngravs_ctx *c);

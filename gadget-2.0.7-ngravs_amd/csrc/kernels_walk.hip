@@ -29,22 +29,10 @@
 // lowered to coefficients  a(r) = m [ cN/r^2 + cY exp(-r ym)(ym/r + 1/r^2) ]  (none, newtonian,
 // neg_newtonian, yukawa, coloyuk) and kernels are compiled per N_GRAVS and per "has Yukawa".
 #include "engine.hpp"
+#include "walk_device.hpp"
 #include <hipcub/hipcub.hpp>
 #include <type_traits>
 
-#define WAVE 64
-
-__device__ __forceinline__ double nearest(double x, double box, double boxhalf)
-{
-  return (x > boxhalf) ? (x - box) : ((x < -boxhalf) ? (x + box) : x);   // NEAREST, forcetree.c:43
-}
-// the minimum-image wrap in 3 instructions instead of 8 (mul, rndne, fma) for the group traversal's conservative box tests,
-// which only use |x|: identical to NEAREST for |x| < 1.5 box except within an ulp of |x| = box/2, where both images are
-// equally far
-__device__ __forceinline__ double nearest_abs(double x, double box, double invbox)
-{
-  return __builtin_fma(-__builtin_rint(x * invbox), box, x);
-}
 // ---------------------------------------------------------------------------------------------
 // force laws, reference formulation (strict walk, direct sum)
 // ---------------------------------------------------------------------------------------------
@@ -595,64 +583,6 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 // per wave: [NULL entry (double4)] [128 x double4 position/mass] [4 x 128 floats] [128 type bytes] -- 16-byte multiple
 #define GW2_WAVE_LDS (sizeof(double4) + (sizeof(double4) + 4 * sizeof(float) + 1) * 128)
 #define GW_NLEAF 8          // an opened node with <= NLEAF particles hands over its particles directly
-
-// exp(-x) for x >= 0:  x = (32 n + j) ln2/32 + f, |f| <= ln2/64;  exp(-x) = 2^-n * T[j] * P6(-f), T[j] = 2^(-j/32)
-// (32-entry table in LDS: one 256-byte bank row, so distinct entries never conflict).  ~1 ulp.
-__device__ __forceinline__ double exp_neg_fast(double x, const double *__restrict__ T)
-{
-  const double inv = 46.16624130844683;                                   // 32/ln2
-  const double hi = 0.02166084938653512, lo = 5.9631716539705866e-12;      // ln2/32 = hi + lo, hi has 21 trailing zero bits
-  double m = __builtin_rint(x * inv);
-  double f = __builtin_fma(-m, hi, x);                                     // exact for m < 2^21
-  f = __builtin_fma(-m, lo, f);
-  int mi = (int)m;
-  double t = T[mi & 31];
-  double y = -f;                                                           // |y| <= ln2/64
-  double pz = 1.0 / 720.0;
-  pz = __builtin_fma(pz, y, 1.0 / 120.0);
-  pz = __builtin_fma(pz, y, 1.0 / 24.0);
-  pz = __builtin_fma(pz, y, 1.0 / 6.0);
-  pz = __builtin_fma(pz, y, 0.5);
-  pz = __builtin_fma(pz, y, 1.0);
-  pz = __builtin_fma(pz, y, 1.0);
-  return ldexp(t * pz, -(mi >> 5));
-}
-
-// wave-level "any lane": the condition's lane mask is compared on the scalar unit (no vector select / compare round trip)
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-__device__ __forceinline__ void wave_sync()
-{
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ int lane_prefix(unsigned long long mask)   // # set bits below this lane
-{
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-}
-__device__ __forceinline__ double wave_min(double v)
-{
-  for(int off = 32; off > 0; off >>= 1)
-    {
-      double o = __shfl_xor(v, off);
-      v = o < v ? o : v;
-    }
-  return v;
-}
-// a wave-uniform double (every lane holds the same value) moved into SGPRs: frees two VGPRs per value that lives as long as the group
-__device__ __forceinline__ double wave_uniform(double v)
-{
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-  for(int off = 32; off > 0; off >>= 1)
-    {
-      double o = __shfl_xor(v, off);
-      v = o > v ? o : v;
-    }
-  return v;
-}
 
 // =============================================================================================
 //  group walk: traversal and force evaluation are separate phases per group (and, by default, separate kernels).
@@ -2520,6 +2450,20 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   auto kt = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 1>;
   auto ke = k_walk_group2<NG, PM, YUK, TAB_LDS, LATT, 2>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // TreePM lists with the tables in LDS go through the ring-pool evaluation kernel when at least 4 slots per wave fit
+  int ringK = 0, ring_waves = waves;
+  if constexpr(PM && TAB_LDS && !LATT)
+    if(c->tune.walk_ring)
+      {
+        ring_waves = GW2_MAXWAVES;
+        if(c->tune.walk_waves > 0 && c->tune.walk_waves < ring_waves)
+          ring_waves = c->tune.walk_waves;
+        ringK = eval_ring_slots(wp, ring_waves);
+        if(c->tune.walk_ring_k >= 4 && c->tune.walk_ring_k < ringK)
+          ringK = c->tune.walk_ring_k;
+        if(ringK)
+          waves = ring_waves;
+      }
   const size_t nbatches = (size_t)((nunits + batch - 1) / batch);
   while(c->ev_batch.size() < 3 * nbatches)
     {
@@ -2545,6 +2489,15 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
       long long nblk = ncu;
       if(nblk > (nb + waves - 1) / waves)
         nblk = (nb + waves - 1) / waves;
+      if(ringK)
+        {
+          // the evaluation kernel with the ring pool (kernels_eval.hip): same lists, same pairs, per-lane cursors
+          int rr = launch_eval_ring(c, tree_view(c), wp, YUK, (int)nblk, ring_waves, ringK, region, gcount, g0, nb, lcap, scap, S,
+                                    walk_tlist(c), SG, walk_tcount(c));
+          if(rr != NGRAVS_OK)
+            return rr;
+        }
+      else
       hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                          c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, (long long)c->shard_first,
                          walk_tcount(c), c->walk_counters.p, (int *)nullptr, c->walk_counters.p + 1, c->r_acc.p,

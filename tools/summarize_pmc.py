@@ -36,7 +36,7 @@ def main():
                     k = short(row["Kernel_Name"])
                     per_kernel[k][row["Counter_Name"]] += float(row["Counter_Value"])
                     ndisp[k].add(row["Dispatch_Id"])
-                    if "k_walk" in k:
+                    if "k_walk" in k or "k_eval" in k:
                         per_disp[(k, int(row["Dispatch_Id"]))][row["Counter_Name"]] += float(row["Counter_Value"])
                         dur[(k, int(row["Dispatch_Id"]))] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
         lines.append("== " + os.path.basename(d.rstrip("/")))
@@ -48,7 +48,7 @@ def main():
             v = dict(per_disp[(k, i)])
             v["dur_ms"] = round(dur[(k, i)], 3)
             lines.append("   %s dispatch %d: %s" % (k[:40], i, v))
-            if k.endswith("2>") or ", 2>" in k:
+            if k.endswith("2>") or ", 2>" in k or "k_eval_ring" in k:
                 for c in ("FETCH_SIZE", "WRITE_SIZE"):
                     if c in v:
                         traffic.setdefault(c, []).append(v[c] * 1024.0)
