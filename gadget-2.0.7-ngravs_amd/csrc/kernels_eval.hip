@@ -68,7 +68,168 @@ __device__ __forceinline__ void lds_st_d4(unsigned a, const double4 &v)
   ER_AS3(d2, a + 16u) = hi;
 }
 
-template <int NG, bool YUK>
+
+// ---- the trip loop in gfx950 assembly -----------------------------------------------------------------------------------------
+// One trip: every lane takes the lowest set bit j of its mask m (none: j = -1, the NULL entry), reads entry j of its slot q, clears
+// the bit, and -- if that was its last bit -- reads { next, nextmask[lane] } of its slot under an exec mask; then the pair interaction
+// of forcetree.c:1953-2032 in the formulation of k_walk_group2's force loop (one Newton step on v_rsq_f64, table bin = (int)(asmthfac r),
+// Yukawa factor E[bin] * P4(bin fraction), softened pairs and slots beyond the exact cut under wave-level branches).  The loop ends
+// when no lane is left on the slot `tail`.  Fixed temporaries v100-v125, s90-s95 (declared as clobbers):
+//   v[100:107] entry -> dx, dy, dz, mass    v[108:109] r2    v[110:111] 1/r    v[112:113] r2 + tiny -> r    v[114:123] scratch
+//   v124 j    v125 address of entry j - ER_ENT    s[90:91] lanes with a real entry    s[92:93] exec    s[94:95] scratch mask
+// A VALU instruction of this ISA takes ONE scalar operand: every scalar constant is used by an instruction of its own.
+#define ER_YUK_ET                                                                                                                  \
+  "v_fract_f64_e32 v[114:115], v[114:115]\n"                          /* fb: position inside the table bin                      */ \
+  "v_mul_f64 v[118:119], v[114:115], %[ec3]\n"                                                                                     \
+  "v_add_u32_e32 v123, %[etab], v122\n"                                                                                            \
+  "v_add_f64 v[118:119], v[118:119], -%[ec2]\n"                                                                                    \
+  "ds_read_b64 v[120:121], v123\n"                                    /* E[bin] = exp(-ym r_bin)                                 */ \
+  "v_add_u32_e32 v122, %[trow], v122\n"                                                                                            \
+  "v_fma_f64 v[118:119], v[118:119], v[114:115], %[ec1]\n"                                                                         \
+  "ds_read_b64 v[122:123], v122\n"                                    /* short-range table                                       */ \
+  "v_fma_f64 v[118:119], v[118:119], v[114:115], -%[ec0]\n"                                                                        \
+  "v_mul_f64 v[116:117], v[110:111], v[110:111]\n"                    /* 1/r^2                                                   */ \
+  "v_fma_f64 v[118:119], v[118:119], v[114:115], 1.0\n"               /* exp(-ym (r - r_bin)), degree 4                          */ \
+  "s_waitcnt lgkmcnt(1)\n"                                                                                                         \
+  "v_mul_f64 v[118:119], v[120:121], v[118:119]\n"                    /* exp(-ym r)                                              */ \
+  "v_mul_f64 v[118:119], %[cY], v[118:119]\n"                                                                                      \
+  "v_fma_f64 v[120:121], %[ym], v[110:111], v[116:117]\n"             /* ym/r + 1/r^2                                            */ \
+  "v_mul_f64 v[118:119], v[120:121], v[118:119]\n"                                                                                 \
+  "v_fmac_f64_e32 v[118:119], %[cN], v[116:117]\n"                    /* + cN/r^2                                                */
+#define ER_NOYUK                                                                                                                   \
+  "v_add_u32_e32 v122, %[trow], v122\n"                                                                                            \
+  "ds_read_b64 v[122:123], v122\n"                                                                                                 \
+  "v_mul_f64 v[116:117], v[110:111], v[110:111]\n"                                                                                 \
+  "v_mul_f64 v[118:119], %[cN], v[116:117]\n"
+#define ER_FST_OFF_ET "16640"   /* fsT behind the exp(-ym r_bin) table: NTAB * 8 + 32 * 8 */
+#define ER_FST_OFF_NOET "256"
+#define ER_TRIP_ASM(YUKSEG, FSTOFF)                                                                                                \
+  "s_mov_b32 %[ntr], 0\n"                                                                                                          \
+  "L_er_top_%=:\n"                                                                                                                 \
+  "v_cmp_eq_u32_e32 vcc, %[tail], %[q]\n"                                                                                          \
+  "s_cbranch_vccz L_er_done_%=\n"                                                                                                  \
+  "s_add_u32 %[ntr], %[ntr], 1\n"                                                                                                  \
+  "v_ffbl_b32_e32 v124, %[m]\n"                                       /* -1 for an empty mask: the NULL entry                    */ \
+  "v_add_co_u32_e64 v122, s[90:91], %[m], -1\n"                       /* carry <=> m != 0: the lanes with a real entry           */ \
+  "v_lshl_add_u32 v125, v124, 5, %[q]\n"                                                                                           \
+  "v_and_b32_e32 %[m], v122, %[m]\n"                                                                                               \
+  "v_cmp_eq_u32_e32 vcc, 0, %[m]\n"                                                                                                \
+  "s_and_saveexec_b64 s[92:93], vcc\n"                                /* lanes whose block is used up follow the link            */ \
+  "v_add_u32_e32 v122, %[q], %[lane4]\n"                                                                                           \
+  "ds_read_b32 %[q], %[q] offset:256\n"                                                                                            \
+  "ds_read_b32 %[m], v122\n"                                                                                                       \
+  "s_mov_b64 exec, s[92:93]\n"                                                                                                     \
+  "ds_read_b128 v[100:103], v125 offset:336\n"                                                                                     \
+  "ds_read_b128 v[104:107], v125 offset:352\n"                                                                                     \
+  "s_waitcnt lgkmcnt(1)\n"                                            /* (right whether or not the masked reads were counted)    */ \
+  "v_add_f64 v[100:101], v[100:101], -%[tpx]\n"                                                                                    \
+  "v_add_f64 v[102:103], v[102:103], -%[tpy]\n"                                                                                    \
+  "v_mul_f64 v[108:109], v[102:103], v[102:103]\n"                                                                                 \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                         \
+  "v_add_f64 v[104:105], v[104:105], -%[tpz]\n"                                                                                    \
+  "v_fmac_f64_e32 v[108:109], v[100:101], v[100:101]\n"                                                                            \
+  "v_fmac_f64_e32 v[108:109], v[104:105], v[104:105]\n"                                                                            \
+  "v_cmp_ngt_f64_e32 vcc, %[reach2], v[108:109]\n"                    /* !(r2 < reach2)                                          */ \
+  "s_and_b64 s[94:95], vcc, s[90:91]\n"                                                                                          \
+  "s_cmp_eq_u64 s[94:95], 0\n"                                                                                                   \
+  "s_cbranch_scc1 L_er_incut_%=\n"                                                                                                 \
+  "v_cndmask_b32_e64 v107, v107, 0, s[94:95]\n"                     /* rare: beyond the exact cut -- no mass, not counted      */ \
+  "v_cndmask_b32_e64 v106, v106, 0, s[94:95]\n"                                                                                  \
+  "v_cndmask_b32_e64 v122, 0, 1, s[94:95]\n"                                                                                     \
+  "v_sub_u32_e32 %[nint], %[nint], v122\n"                                                                                         \
+  "L_er_incut_%=:\n"                                                                                                               \
+  "v_add_f64 v[112:113], v[108:109], %[tiny]\n"                       /* self / coincident pairs stay finite                     */ \
+  "v_rsq_f64_e32 v[110:111], v[112:113]\n"                                                                                         \
+  "v_cmp_lt_f64_e64 s[94:95], v[108:109], %[h2max]\n"               /* closer than the largest softening length?               */ \
+  "v_mul_f64 v[114:115], v[112:113], v[110:111]\n"                    /* one Newton step: y += y/2 (1 - x y^2)                   */ \
+  "v_fma_f64 v[114:115], -v[114:115], v[110:111], 1.0\n"                                                                           \
+  "v_mul_f64 v[116:117], v[110:111], 0.5\n"                                                                                        \
+  "v_fma_f64 v[110:111], v[116:117], v[114:115], v[110:111]\n"        /* 1/r                                                     */ \
+  "v_mul_f64 v[112:113], v[112:113], v[110:111]\n"                    /* r                                                       */ \
+  "v_mul_f64 v[114:115], v[112:113], %[asmthfac]\n"                                                                                \
+  "v_cvt_i32_f64_e32 v122, v[114:115]\n"                              /* table bin (saturating conversion, then clamped)         */ \
+  "v_min_i32_e32 v122, 0x7ff, v122\n"                                                                                              \
+  "v_lshlrev_b32_e32 v122, 3, v122\n"                                                                                              \
+  YUKSEG                                                                                                                           \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                         \
+  "v_fma_f64 v[118:119], -%[utor2wpi], v[122:123], v[118:119]\n"      /* - long-range part                                       */ \
+  "v_mul_f64 v[118:119], v[106:107], v[118:119]\n"                                                                                 \
+  "v_mul_f64 v[118:119], v[110:111], v[118:119]\n"                    /* fac = f m / r                                           */ \
+  "s_cmp_lg_u64 s[94:95], 0\n"                                                                                                   \
+  "s_cbranch_scc1 L_er_soft_%=\n"                                                                                                  \
+  "L_er_acc_%=:\n"                                                                                                                 \
+  "v_fmac_f64_e32 %[ax], v[100:101], v[118:119]\n"                                                                                 \
+  "v_fmac_f64_e32 %[ay], v[102:103], v[118:119]\n"                                                                                 \
+  "v_fmac_f64_e32 %[az], v[104:105], v[118:119]\n"                                                                                 \
+  "s_branch L_er_top_%=\n"                                                                                                         \
+  /* ---- rare: a pair possibly inside the softening radius (forcetree.c:1415-1417, ngravs.c:420-434) */                          \
+  "L_er_soft_%=:\n"                                                                                                                \
+  "v_mul_i32_i24_e32 v122, 0xffffffe1, v124\n"                        /* type byte of entry j: [slot] + ER_TYPE + j = v125 - 31 j + 272 */ \
+  "v_add_u32_e32 v122, v125, v122\n"                                                                                               \
+  "ds_read_u8 v122, v122 offset:272\n"                                                                                             \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                         \
+  "v_lshl_add_u32 v122, v122, 3, %[etab]\n"                                                                                        \
+  "ds_read_b64 v[120:121], v122 offset:" FSTOFF "\n"                  /* softening length of the source's type                   */ \
+  "s_waitcnt lgkmcnt(0)\n"                                                                                                         \
+  "v_max_f64 v[120:121], v[120:121], %[hT]\n"                         /* h = max(target, source)                                 */ \
+  "v_rcp_f64_e32 v[122:123], v[120:121]\n"                                                                                         \
+  "v_cmp_lt_f64_e64 s[94:95], v[112:113], v[120:121]\n"             /* soft = r < h                                            */ \
+  "v_fma_f64 v[114:115], -v[120:121], v[122:123], 1.0\n"              /* 1/h: two Newton steps                                   */ \
+  "v_fma_f64 v[122:123], v[122:123], v[114:115], v[122:123]\n"                                                                     \
+  "v_fma_f64 v[114:115], -v[120:121], v[122:123], 1.0\n"                                                                           \
+  "v_fma_f64 v[122:123], v[122:123], v[114:115], v[122:123]\n"        /* h_inv                                                   */ \
+  "v_mul_f64 v[114:115], v[112:113], v[122:123]\n"                    /* u = r / h                                               */ \
+  "v_mul_f64 v[116:117], v[114:115], v[114:115]\n"                    /* u^2                                                     */ \
+  "v_ldexp_f64 v[120:121], v[114:115], 5\n"                           /* 32 u                                                    */ \
+  "s_mov_b32 s90, 0x33333333\n"                                                                                                    \
+  "s_mov_b32 s91, 0x40433333\n"                                       /* 38.4                                                    */ \
+  "v_add_f64 v[120:121], v[120:121], -s[90:91]\n"                                                                                  \
+  "s_mov_b32 s92, 0x55555611\n"                                                                                                    \
+  "s_mov_b32 s93, 0x40255555\n"                                       /* 10.666666666667                                         */ \
+  "v_fma_f64 v[120:121], v[116:117], v[120:121], s[92:93]\n"          /* u < 1/2: 10.67 + u^2 (32 u - 38.4)                      */ \
+  "v_mul_f64 v[108:109], v[116:117], v[114:115]\n"                    /* u^3 (r2 is no longer needed)                            */ \
+  "v_rcp_f64_e32 v[110:111], v[108:109]\n"                            /* 1/u^3 (1/r is no longer needed)                         */ \
+  "v_mul_f64 v[116:117], v[116:117], s[90:91]\n"                      /* 38.4 u^2                                                */ \
+  "v_fma_f64 v[112:113], -v[108:109], v[110:111], 1.0\n"                                                                           \
+  "v_fma_f64 v[110:111], v[110:111], v[112:113], v[110:111]\n"                                                                     \
+  "v_fma_f64 v[112:113], -v[108:109], v[110:111], 1.0\n"                                                                           \
+  "v_fma_f64 v[110:111], v[110:111], v[112:113], v[110:111]\n"                                                                     \
+  "s_mov_b32 s90, 0x555554f8\n"                                                                                                    \
+  "s_mov_b32 s91, 0x40355555\n"                                       /* 21.333333333333                                         */ \
+  "v_add_f64 v[116:117], v[116:117], s[90:91]\n"                      /* 21.33 + 38.4 u^2                                        */ \
+  "s_mov_b32 s90, 0\n"                                                                                                             \
+  "s_mov_b32 s91, 0xc0480000\n"                                       /* -48                                                     */ \
+  "v_fma_f64 v[116:117], v[114:115], s[90:91], v[116:117]\n"          /* - 48 u                                                  */ \
+  "v_fma_f64 v[116:117], -v[108:109], s[92:93], v[116:117]\n"         /* - 10.67 u^3                                             */ \
+  "s_mov_b32 s90, 0x11116ee4\n"                                                                                                    \
+  "s_mov_b32 s91, 0x3fb11111\n"                                       /* 0.066666666667                                          */ \
+  "v_fma_f64 v[116:117], -v[110:111], s[90:91], v[116:117]\n"         /* - 0.0667 / u^3                                          */ \
+  "v_cmp_gt_f64_e32 vcc, 0.5, v[114:115]\n"                           /* u < 1/2                                                 */ \
+  "v_cndmask_b32_e32 v116, v116, v120, vcc\n"                                                                                      \
+  "v_cndmask_b32_e32 v117, v117, v121, vcc\n"                                                                                      \
+  "v_mul_f64 v[120:121], %[cS], v[106:107]\n"                         /* cS m h_inv^3 v                                          */ \
+  "v_mul_f64 v[120:121], v[120:121], v[122:123]\n"                                                                                 \
+  "v_mul_f64 v[120:121], v[120:121], v[122:123]\n"                                                                                 \
+  "v_mul_f64 v[120:121], v[120:121], v[122:123]\n"                                                                                 \
+  "v_mul_f64 v[120:121], v[120:121], v[116:117]\n"                                                                                 \
+  "v_cndmask_b32_e64 v118, v118, v120, s[94:95]\n"                                                                               \
+  "v_cndmask_b32_e64 v119, v119, v121, s[94:95]\n"                                                                               \
+  "s_branch L_er_acc_%=\n"                                                                                                         \
+  "L_er_done_%=:\n"
+#define ER_TRIP_CLOBBERS                                                                                                            \
+  "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
+      "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "s90", "s91", "s92", "s93", "s94", "s95",   \
+      "vcc", "scc", "memory"
+
+// law coefficients of a [target species][source species] pair as the kernel keeps them in LDS (read once per list and lane)
+struct ErLaw
+{
+  double cN, cY, cS;
+  unsigned trow;   // LDS address of the pair's short-range table
+  unsigned pad;
+};
+
+template <int NG, bool YUK, bool ET>
 __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
     TreeView tv, const double4 *__restrict__ s_pm, const unsigned char *__restrict__ s_type,
     const unsigned char *__restrict__ s_active, const double *__restrict__ table, WalkParams wp, long long t_first,
@@ -76,43 +237,64 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
     const int *__restrict__ region_base, const int *__restrict__ gcount, long long g_first, long long g_cnt, int lcap, int scap,
     int S, const int *__restrict__ tlist, int SG, int K)
 {
+  // LDS: [tables][exp table 32][softening per type 8][law table NG x NG][per wave: K slots + terminal stub]
   double *tab_s = reinterpret_cast<double *>(er_smem);
   const int ntabs = wp.ntab_lds + wp.exp_tab;   // distinct short-range tables [+ the exp(-ym r_bin) table]
   const unsigned tab_bytes = (unsigned)(sizeof(double) * ntabs * NTAB);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double *expT = reinterpret_cast<double *>(er_smem + tab_bytes);
   double *fsT = expT + 32;   // softening length per particle type (8 entries; index 7 = NULL entry)
+  ErLaw *lawT = reinterpret_cast<ErLaw *>(fsT + 8);
+  const unsigned fixed_bytes = tab_bytes + 40u * (unsigned)sizeof(double) + (unsigned)(NG_MAX * NG_MAX * sizeof(ErLaw));
   const unsigned wave_bytes = (unsigned)K * ER_SLOT + ER_HEAD;
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char *)er_smem;   // LDS address of er_smem
-  const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + tab_bytes + 40u * (unsigned)sizeof(double) + (unsigned)wave * wave_bytes));
-  const unsigned slot0_q = wbase;                               // q of slot 0
+  const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + fixed_bytes + (unsigned)wave * wave_bytes));
   const unsigned term_q = wbase + (unsigned)K * ER_SLOT;          // q of the terminal stub (no entries: only its NULL entry is read)
+  bool usoft = true;  // all types share one softening length
+#pragma unroll
+  for(int q = 0; q < NGRAVS_NTYPES; q++)
+    usoft = usoft && wp.fsoft[q] == wp.fsoft[0];
   {
     if(threadIdx.x < 32)
       expT[threadIdx.x] = exp2(-(double)threadIdx.x / 32.0);
     if(threadIdx.x >= 32 && threadIdx.x < 40)
       fsT[threadIdx.x - 32] = threadIdx.x - 32 < NGRAVS_NTYPES ? wp.fsoft[threadIdx.x - 32] : 0.0;
+    if(threadIdx.x < NG * NG)
+      {
+        const int a = threadIdx.x / NG, b = threadIdx.x % NG;
+        ErLaw l;
+        l.cN = wp.cN[a][b];
+        l.cY = wp.cY[a][b];
+        l.cS = wp.cS[a][b];
+        l.trow = lds0 + (unsigned)(wp.tab_slot[a * NG + b] * NTAB * sizeof(double));
+        l.pad = 0;
+        lawT[threadIdx.x] = l;
+      }
     for(int t = threadIdx.x; t < ntabs * NTAB; t += blockDim.x)
       {
         const int u = t / NTAB;
         tab_s[t] = table[(size_t)(u < wp.ntab_lds ? wp.slot_src[u] : NG * NG) * NTAB + (t % NTAB)];
       }
-    // the constant parts of this wave's slots: NULL entries, their type bytes, the terminal stub
+    // the constant parts of this wave's slots: NULL entries, their type bytes, the terminal stub; the type bytes of the entries
+    // stay 0 when all particle types share one softening length
     if(lane <= K)
       {
-        const unsigned qs = slot0_q + (unsigned)lane * ER_SLOT;   // lane K: the terminal stub
+        const unsigned qs = wbase + (unsigned)lane * ER_SLOT;   // lane K: the terminal stub
         double4 z;
         z.x = z.y = z.z = 1e10;
         z.w = 0.0;
         lds_st_d4(qs + ER_NULL, z);
         lds_st_u8(qs + ER_TYPE - 1, 7);   // fsT[7] = 0: unsoftened
       }
+    if(lane < 8)
+      for(int k = 0; k < K; k++)
+        lds_st_u32(wbase + (unsigned)k * ER_SLOT + ER_TYPE + 4u * (unsigned)lane, 0u);
     lds_st_u32(term_q + ER_NM + 4 * lane, 0u);
     if(lane == 0)
       lds_st_u32(term_q + ER_NEXT, term_q);
     __syncthreads();
   }
-  const double *const etab = tab_s + (size_t)wp.ntab_lds * NTAB;
+  const unsigned etab_a = lds0 + (unsigned)(wp.ntab_lds * NTAB * sizeof(double));   // LDS address of the exp(-ym r_bin) table
   const int G = WAVE / S;
   const long long ngroups = g_cnt;
   unsigned lane_pat = ~0u;   // the pool entries of a block this lane evaluates (S lanes share a target: entry j goes to lane j mod S)
@@ -124,13 +306,9 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
     }
   const double invbox = wp.box > 0 ? 1.0 / wp.box : 0.0;
   double h2max = 0;   // square of the largest softening length of any particle type (wave-uniform)
-  bool usoft = true;  // all types share one softening length
 #pragma unroll
   for(int q = 0; q < NGRAVS_NTYPES; q++)
-    {
-      h2max = fmax(h2max, wp.fsoft[q] * wp.fsoft[q]);
-      usoft = usoft && wp.fsoft[q] == wp.fsoft[0];
-    }
+    h2max = fmax(h2max, wp.fsoft[q] * wp.fsoft[q]);
   h2max = wave_uniform(h2max);
   // XCD-aware group assignment (as k_walk_group2): the Peano order is cut into 8 contiguous segments, one per XCD (own L2); an
   // exhausted segment steals from the others.  Placement only affects speed.
@@ -142,7 +320,8 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
   unsigned long long acc_st[4] = {0, 0, 0, 0};
   const unsigned lane4 = 4u * (unsigned)lane;
   const int mh = lane >> 5;   // MFMA: k index this lane supplies = half of the wave
-  const int mrow = 16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3);   // A-operand row -> pool entry (see k_walk_group2)
+  // A-operand row of this lane -> pool entry (see k_walk_group2), as a byte offset into a slot
+  const unsigned mrow_off = ER_ENT + 32u * (unsigned)(16 * ((lane >> 2) & 1) + 4 * ((lane & 31) >> 3) + (lane & 3));
   typedef float f16v __attribute__((ext_vector_type(16)));
   const double BIG = 1e300;
   for(;;)
@@ -166,13 +345,7 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
       if(grp < 0)
         break;
       const long long ru = grp / SG;   // the unit's region in this batch
-      const int *lists[NG];
-      {
-        const int *base = region_base + (size_t)ru * ((size_t)NG * lcap + scap);
-#pragma unroll
-        for(int g = 0; g < NG; g++)
-          lists[g] = base + (size_t)g * lcap;
-      }
+      const int *const lbase = region_base + (size_t)ru * ((size_t)NG * lcap + scap);
       const long long grel = grp;
       grp += g_first;
       const long long tk = grp * G + lane / S;
@@ -193,8 +366,16 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
         }
       if(!__any(valid ? 1 : 0))
         continue;
-      double cNg = 0, cYg = 0, cSg = 0;
-      const double *trow = tab_s;
+      int n_items[NG];
+      bool bad = false;
+#pragma unroll
+      for(int g = 0; g < NG; g++)
+        {
+          n_items[g] = __builtin_amdgcn_readfirstlane(gcount[ru * NG + g]);
+          bad |= n_items[g] < 0;
+        }
+      if(bad)   // the traversal kernel overflowed this unit's region: the fused kernel redoes it
+        continue;
       // group bounding box (wave-uniform, SGPRs)
       const double lox = wave_min(valid ? px : BIG), hix = wave_max(valid ? px : -BIG);
       const double loy = wave_min(valid ? py : BIG), hiy = wave_max(valid ? py : -BIG);
@@ -206,9 +387,6 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
       const bool prewrap = __builtin_amdgcn_readfirstlane(
                                (int)(wp.periodic && (wp.boxhalf - bhmax) * (wp.boxhalf - bhmax) > wp.reach2 && (wp.boxhalf - bhmax) > 0)) != 0;
       const bool lanewrap = wp.periodic && !prewrap;
-      // the pool holds positions RELATIVE to the box centre (what the cull computes anyway) unless images are taken per pair
-      const bool relstore = !lanewrap;
-      const double tpx = relstore ? px - bcx : px, tpy = relstore ? py - bcy : py, tpz = relstore ? pz - bcz : pz;
       // a group whose whole region [box - reach, box + reach] lies inside the periodic box needs no image arithmetic at all
       bool nowrap = !wp.periodic;
       if(wp.periodic && wp.src_in_box)
@@ -221,7 +399,6 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
       // fp32 reach pre-test on the matrix cores (no per-pair wrapping): threshold widened by the worst-case rounding so that no
       // true hit is lost; the force loop re-tests in fp64.  Bound as in k_walk_group2: e and p are fp32 roundings of coordinates
       // relative to the box centre (<= bhmax + reach each), the evaluation makes <= 8 roundings of magnitudes <= 3 (2 bhmax + rl)^2
-      const bool fastmask = !lanewrap && !wp.exact_reach;
       float mB[2][3];
       {
         const float tfx = (float)(px - bcx), tfy = (float)(py - bcy), tfz = (float)(pz - bcz);
@@ -248,381 +425,358 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
       double ax = 0, ay = 0, az = 0;
       int nint = 0;
       int st_entries = 0, st_iters = 0;
-      int n_items[NG];
-      bool bad = false;
-#pragma unroll
-      for(int g = 0; g < NG; g++)
-        {
-          n_items[g] = __builtin_amdgcn_readfirstlane(gcount[ru * NG + g]);
-          bad |= n_items[g] < 0;
-        }
-      if(bad)   // the traversal kernel overflowed this unit's region: the fused kernel redoes it
-        continue;
 
-      // ---- one pool entry against this lane's target (forcetree.c:1953-2032), as k_walk_group2's evalN with one entry per trip
-      auto evalN = [&](auto lw_tag, auto et_tag, const double4 e, const unsigned tyaddr, const unsigned long long actm_) {
+      // ---- all lists of the group; LW: images per pair (the group's box is too wide to wrap the sources once per group)
+      auto run_lists = [&](auto lw_tag) {
         constexpr bool LW = decltype(lw_tag)::value;
-        constexpr bool ET = decltype(et_tag)::value;   // Yukawa factor through the table bins
-        auto is_act = [&]() -> bool {
-          unsigned long long am = actm_;
-          asm volatile("" : "+s"(am));
-          return ((am >> lane) & 1ull) != 0;
-        };
-        double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
-        if(LW)
+        const bool fastmask = !LW && !wp.exact_reach;
+        // the pool holds positions RELATIVE to the box centre (what the cull computes anyway) unless images are taken per pair
+        const double tpx = LW ? px : px - bcx, tpy = LW ? py : py - bcy, tpz = LW ? pz : pz - bcz;
+        for(int g = 0; g < NG; g++)
           {
-            dx = nearest(dx, wp.box, wp.boxhalf);
-            dy = nearest(dy, wp.box, wp.boxhalf);
-            dz = nearest(dz, wp.box, wp.boxhalf);
-          }
-        const double r2 = dx * dx + dy * dy + dz * dz;
-        double mw = e.w;
-        const unsigned long long fpos = actm_ & __builtin_amdgcn_ballot_w64(!(r2 < wp.reach2));
-        if(fpos != 0ull)                                                  // rare: beyond the exact cut
-          {
-            asm volatile("; beyond the exact cut" ::: "memory");          // keeps this a branch
-            double r2o = r2;
-            asm volatile("" : "+v"(r2o));
-            const bool out = is_act() && !(r2o < wp.reach2);
-            mw = out ? 0.0 : mw;
-            nint -= out ? 1 : 0;
-          }
-        // self / coincident pairs stay finite (d = 0 kills them)
-        const double q2 = r2 + 1e-290;
-        double ri = __builtin_amdgcn_rsq(q2);
-        ri = ri * (1.5 - 0.5 * q2 * ri * ri);                             // one Newton step: ~2^-51
-        const double rr = q2 * ri;                                        // sqrt(r2) to ~2^-51
-        const double ri2 = ri * ri;
-        double f = cNg * ri2;
-        const double xt = wp.asmthfac * rr;
-        int tab = (int)xt;                                                // saturating conversion, then clamped
-        tab = tab < NTAB - 1 ? tab : NTAB - 1;
-        if(YUK)
-          {
-            double ex;
-            if(ET)
-              {
-                // exp(-ym r) = E[tab] exp(-u), u = ub * (position inside the bin): degree-4 Taylor in the bin fraction, Estrin form
-                // (Horner with one scalar operand per instruction: the constant bus takes one)
-                const double fb = __builtin_amdgcn_fract(xt);
-                double pz_ = fb * wp.ec[3];
-                pz_ = pz_ - wp.ec[2];
-                pz_ = __builtin_fma(pz_, fb, wp.ec[1]);
-                pz_ = __builtin_fma(pz_, fb, -wp.ec[0]);
-                pz_ = __builtin_fma(pz_, fb, 1.0);
-                ex = etab[tab] * pz_;
-              }
-            else
-              ex = exp_neg_fast(rr * wp.ym, expT);
-            f += cYg * ex * (wp.ym * ri + ri2);
-          }
-        f -= wp.utor2wpi * trow[tab];
-        double fac = f * mw * ri;
-        if(wave_any(r2 < h2max))                                          // rare: possibly inside the softening radius
-          {
-            asm volatile("; softened pair" ::: "memory");
-            const double h = __builtin_fmax(hT, fsT[lds_u8(tyaddr)]);     // the pair's softening (forcetree.c:1415-1417)
-            const bool soft = rr < h;
-            double h_inv = 1 / h, u = rr * h_inv;
-            double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
-                                 : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
-            double fs = cSg * mw * h_inv * h_inv * h_inv * v;
-            fac = soft ? fs : fac;
-          }
-        ax = __builtin_fma(dx, fac, ax);
-        ay = __builtin_fma(dy, fac, ay);
-        az = __builtin_fma(dz, fac, az);
-      };
-
-      // ---- one source species' list through the ring -----------------------------------------------------------
-      auto phase2 = [&](const int g, const int *__restrict__ items, const int n_) {
-        const int n = __builtin_amdgcn_readfirstlane(n_);
-        wave_sync();
-        st_entries += n;
-        if(n == 0)
-          return;
-        cNg = wp.cN[tg][g];
-        cYg = wp.cY[tg][g];
-        cSg = wp.cS[tg][g];
-        trow = tab_s + (size_t)wp.tab_slot[tg * NG + g] * NTAB;
-        // quads of four consecutive items in a golden-ratio stride order (see k_walk_group2)
-        const int nq = (n + 3) >> 2;
-        const int nsuper = (nq + WAVE - 1) / WAVE, nchunks = 4 * nsuper;
-        const int M = nsuper * WAVE;
-        int s_ = (int)(0.6180339887498949 * M) | 1;
-        if(s_ >= M)
-          s_ = 1;
-        for(;;)
-          {
-            int a = nsuper, b = s_ % nsuper;
-            while(b)
-              {
-                int t = a % b;
-                a = b;
-                b = t;
-              }
-            if(a == 1)
-              break;
-            s_ += 2;
+            const int n = n_items[g < NG ? g : 0];
+            const int *__restrict__ items = lbase + (size_t)g * lcap;
+            wave_sync();
+            st_entries += n;
+            if(n == 0)
+              continue;
+            double cNg, cYg, cSg;
+            unsigned trow_a;
+            {
+              const ErLaw l = lawT[tg * NG + g];
+              cNg = l.cN;
+              cYg = l.cY;
+              cSg = l.cS;
+              trow_a = l.trow;
+            }
+            // quads of four consecutive items in a golden-ratio stride order (see k_walk_group2)
+            const int nq = (n + 3) >> 2;
+            const int nsuper = (nq + WAVE - 1) / WAVE, nchunks = 4 * nsuper;
+            const int M = nsuper * WAVE;
+            int s_ = (int)(0.6180339887498949 * M) | 1;
             if(s_ >= M)
+              s_ = 1;
+            for(;;)
               {
-                s_ = 1;
-                break;
+                int a = nsuper, b = s_ % nsuper;
+                while(b)
+                  {
+                    int t = a % b;
+                    a = b;
+                    b = t;
+                  }
+                if(a == 1)
+                  break;
+                s_ += 2;
+                if(s_ >= M)
+                  {
+                    s_ = 1;
+                    break;
+                  }
               }
-          }
-        const int step64 = (int)((64ll * s_) % M);
-        int slot = (int)(((long long)lane * s_) % M);
-        auto fetch_quad = [&](int sc, int4 &v, int &nvalid) {
-          v.x = v.y = v.z = v.w = 0;
-          nvalid = 0;
-          if(sc < nsuper && slot < nq)
-            {
-              v = reinterpret_cast<const int4 *>(items)[slot];
-              nvalid = n - 4 * slot;
-              nvalid = nvalid > 4 ? 4 : nvalid;
-            }
-          slot += step64;
-          slot = slot >= M ? slot - M : slot;
-        };
-        auto fetch_rec = [&](bool hv, int item, double4 &q, int &hs) {   // hs: softening TYPE of the source (fsT index)
-          if(hv)
-            {
-              const int k = -1 - item;   // monopole: node * NG + g
-              const bool isp = item >= 0;
-              const double4 *src = isp ? s_pm + item : tv.mom + k;
-              q = *src;
-              hs = 0;
-              if(!usoft)   // (one softening length for all types: no type / flag bytes, each of which would pull another cache line)
-                hs = isp ? (int)s_type[item] : ((tv.flags[k / NG] >> 2) & 7);
-            }
-        };
-        int4 qd;
-        int nv;
-        fetch_quad(0, qd, nv);
-        double4 q1;
-        q1.x = q1.y = q1.z = q1.w = 0;
-        int hs1 = 0;
-        bool have1 = nv > 0;
-        fetch_rec(have1, qd.x, q1, hs1);
-
-        // ring state (wave-uniform): blocks tail .. tail + nlive - 1 are complete and not yet left by every lane, the next entry
-        // goes to (wr_slot, wr_pos)
-        int wr_slot = 0, wr_pos = 0, tail_slot = 0, nlive = 0, cc = 0;
-        bool first = true, closed = false;
-        unsigned newest_q = term_q;
-        unsigned m = 0, q = term_q;   // this lane's cursor: parked on the terminal stub
-
-        // the reach masks of the block in slot sl (nfill entries) and its publication
-        auto build_block = [&](const int sl, const int nfill) {
-          const unsigned sq = slot0_q + (unsigned)sl * ER_SLOT;
-          unsigned word = 0;
-          if(fastmask)
-            {
-              const unsigned ea = sq + ER_ENT + 32u * (unsigned)mrow;
-              const double4 er = lds_d4(ea);
-              const float fx = (float)er.x, fy = (float)er.y, fz = (float)er.z;
-              const float e2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-              const float a0 = mh ? fy : fx, a1 = mh ? e2 : fz, a2 = mh ? 0.0f : 1.0f;
-              unsigned wt[2];
-#pragma unroll
-              for(int tb = 0; tb < 2; tb++)
+            const int step64 = (int)((64ll * s_) % M);
+            int slot = (int)(((long long)lane * s_) % M);
+            int4 qd = {0, 0, 0, 0};   // item quad of the current four chunks
+            int nv = 0;
+            // the record (and softening type) of chunk cc, requested one chunk ahead
+            double rx = 0, ry = 0, rz = 0, rw = 0;
+            int hs1 = 0;
+            auto fetch = [&](const int c_) {   // c_: chunk whose record is requested (wave-uniform)
+              const int bn = c_ & 3;
+              if(bn == 0)
                 {
-                  f16v acc;
-#pragma unroll
-                  for(int r = 0; r < 16; r++)
-                    acc[r] = 0.0f;
-                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, mB[tb][0], acc, 0, 0, 0);
-                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mB[tb][1], acc, 0, 0, 0);
-                  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, mB[tb][2], acc, 0, 0, 0);
-                  unsigned w_ = 0;
-#pragma unroll
-                  for(int r = 15; r >= 0; r--)
-                    w_ = __builtin_amdgcn_alignbit(w_, __float_as_uint(acc[r]), 31);
-                  wt[tb] = w_;
-                }
-              // lanes 32-63 of wt[0] <-> lanes 0-31 of wt[1]: afterwards [0] = this lane's target against entries 0-15, [1] = 16-31
-              const auto sw = __builtin_amdgcn_permlane32_swap(wt[0], wt[1], false, false);
-              word = sw[0] | (sw[1] << 16);
-            }
-          else
-            {
-              for(int b = 0; b < nfill; b++)
-                {
-                  const double4 e = lds_d4(sq + ER_ENT + 32u * (unsigned)b);
-                  double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
-                  if(lanewrap)
+                  qd.x = qd.y = qd.z = qd.w = 0;
+                  nv = 0;
+                  if((c_ >> 2) < nsuper && slot < nq)
                     {
-                      dx = nearest(dx, wp.box, wp.boxhalf);
-                      dy = nearest(dy, wp.box, wp.boxhalf);
-                      dz = nearest(dz, wp.box, wp.boxhalf);
+                      qd = reinterpret_cast<const int4 *>(items)[slot];
+                      nv = n - 4 * slot;
                     }
-                  const double r2 = dx * dx + dy * dy + dz * dz;
-                  word |= (r2 < wp.reach2) ? (1u << b) : 0u;
+                  slot += step64;
+                  slot = slot >= M ? slot - M : slot;
                 }
-            }
-          // entries beyond nfill are stale; lanes without a target take nothing; S lanes of a target share the entries
-          const unsigned okm = !valid ? 0u : (nfill >= 32 ? ~0u : ((1u << nfill) - 1u));
-          word &= okm & lane_pat;
-          nint += __popc(word);   // evalN takes the (rare) slots beyond the exact cut off again
-          if(first)
-            {
-              m = word;
-              q = sq;
-              first = false;
-            }
-          else
-            {
-              lds_st_u32(newest_q + ER_NM + lane4, word);
-              if(lane == 0)
-                lds_st_u32(newest_q + ER_NEXT, sq);
-            }
-          lds_st_u32(sq + ER_NM + lane4, 0u);
-          if(lane == 0)
-            lds_st_u32(sq + ER_NEXT, sq);
-          newest_q = sq;
-          wave_sync();
-        };
-
-        // trips until no lane is left on the slot tail_q.  Exists once per (per-pair wrap, table-bin exp) combination, chosen by
-        // scalar branches outside it; inside, the only control flow is the exec-masked cursor update and evalN's two rare branches.
-        auto trip_loop = [&](auto lw_tag, auto et_tag, const unsigned tail_q) {
-          for(;;)
-            {
-              if(__builtin_amdgcn_ballot_w64(q == tail_q) == 0ull)
-                break;
-              st_iters += (int)(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) >> 6);   // (+1, computed on the scalar unit)
-              int j;
-              asm("v_ffbl_b32 %0, %1" : "=v"(j) : "v"(m));   // an exhausted mask gives -1: the NULL entry in front of the slot
-              const unsigned a = q + ((unsigned)j << 5);
-              const double4 e = lds_d4(a + ER_ENT);
-              // (the entry's type byte is at q + ER_TYPE + j; written in terms of a and j, which the cursor update below leaves alone)
-              const unsigned tyaddr = a - 31u * (unsigned)j + ER_TYPE;
-              // m - 1 carries unless m is 0: the carry IS the mask of the lanes that hold a real entry this trip
-              unsigned long long actm_;
-              unsigned mm1;
-              asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(mm1), "=s"(actm_) : "v"(m));
-              // (an asm result counts as divergent; through readfirstlane the mask stays on the scalar unit)
-              const unsigned long long actm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(actm_ >> 32)) << 32) |
-                                              (unsigned)__builtin_amdgcn_readfirstlane((int)actm_);
-              m &= mm1;
-              if(m == 0u)   // this lane's bits of the block are used up: follow the link (or stay, if the next block is not there yet)
+              const int item = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
+              rw = 0.0;   // (no record: the cull drops massless entries)
+              if(c_ < nchunks && bn < nv)
                 {
-                  const unsigned qn = lds_u32(q + ER_NEXT);
-                  m = lds_u32(q + ER_NM + lane4);
-                  q = qn;
+                  const bool isp = item >= 0;
+                  const unsigned idx = isp ? (unsigned)item : ~(unsigned)item;   // monopole: node * NG + g = -1 - item
+                  const double4 *src = isp ? s_pm + idx : tv.mom + idx;
+                  const double4 r = *src;
+                  rx = r.x;
+                  ry = r.y;
+                  rz = r.z;
+                  rw = r.w;
+                  if(!usoft)   // (one softening length for all types: no type / flag bytes, each of which would pull another cache line)
+                    hs1 = isp ? (int)s_type[idx] : ((tv.flags[idx / NG] >> 2) & 7);
                 }
-              evalN(lw_tag, et_tag, e, tyaddr, actm);
-            }
-        };
+            };
+            fetch(0);
 
-        for(;;)
-          {
-            // ---- produce: cull chunks of 64 items into the ring while a whole chunk fits
-            while(cc < nchunks && K * 32 - (nlive * 32 + wr_pos) >= WAVE)
-              {
-                double4 qr = q1;
-                const int hs = hs1;
-                bool live = have1 && qr.w != 0.0;
-                double ex = qr.x - bcx, ey = qr.y - bcy, ez = qr.z - bcz;
-                if(!nowrap)
-                  {
-                    ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
-                    ey = nearest_abs(ey, wp.box, invbox);
-                    ez = nearest_abs(ez, wp.box, invbox);
-                  }
-                {
-                  // a source farther than the cut from the whole bounding box contributes to no target
-                  const double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
-                  live = live && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
-                }
-                if(relstore)
-                  {
-                    qr.x = ex;
-                    qr.y = ey;
-                    qr.z = ez;
-                  }
-                const unsigned long long lm = __ballot(live ? 1 : 0);
-                if(live)
-                  {
-                    const int L = wr_pos + lane_prefix(lm);
-                    int sl = wr_slot + (L >> 5);
-                    sl = sl >= K ? sl - K : sl;
-                    const unsigned sq = slot0_q + (unsigned)sl * ER_SLOT;
-                    lds_st_d4(sq + ER_ENT + 32u * (unsigned)(L & 31), qr);
-                    lds_st_u8(sq + ER_TYPE + (unsigned)(L & 31), (unsigned char)(hs & 7));
-                  }
-                int tot = wr_pos + __popcll(lm);
-                {
-                  // chunk cc+1: element (cc+1) & 3 of its quad
-                  const int bn = (cc + 1) & 3;
-                  if(bn == 0)
-                    fetch_quad((cc + 1) / 4, qd, nv);
-                  const int itn = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
-                  have1 = cc + 1 < nchunks && bn < nv;
-                  fetch_rec(have1, itn, q1, hs1);
-                }
-                wave_sync();
-                while(tot >= 32)
-                  {
-                    build_block(wr_slot, 32);
-                    wr_slot = wr_slot + 1 >= K ? 0 : wr_slot + 1;
-                    nlive++;
-                    tot -= 32;
-                  }
-                wr_pos = tot;
-                cc++;
-              }
-            if(cc >= nchunks && !closed)
-              {
-                if(wr_pos > 0)
-                  {
-                    build_block(wr_slot, wr_pos);
-                    wr_slot = wr_slot + 1 >= K ? 0 : wr_slot + 1;
-                    nlive++;
-                    wr_pos = 0;
-                  }
-                if(!first && lane == 0)
-                  lds_st_u32(newest_q + ER_NEXT, term_q);   // the list ends here
-                closed = true;
-                wave_sync();
-              }
-            if(nlive == 0)
-              break;
-            // ---- consume until every lane has left the oldest block
-            const unsigned tail_q = slot0_q + (unsigned)tail_slot * ER_SLOT;
-            if(lanewrap)
-              {
-                if(YUK && wp.exp_tab)
-                  trip_loop(std::true_type{}, std::true_type{}, tail_q);
-                else
-                  trip_loop(std::true_type{}, std::false_type{}, tail_q);
-              }
-            else
-              {
-                if(YUK && wp.exp_tab)
-                  trip_loop(std::false_type{}, std::true_type{}, tail_q);
-                else
-                  trip_loop(std::false_type{}, std::false_type{}, tail_q);
-              }
-            tail_slot = tail_slot + 1 >= K ? 0 : tail_slot + 1;
-            nlive--;
-          }
-        wave_sync();
-      };
+            // ring state (wave-uniform): blocks tail .. tail + nlive - 1 are complete and not yet left by every lane; wr_pos entries
+            // (up to 95: a partial block + one chunk) wait from slot wr_slot on
+            int wr_slot = 0, wr_pos = 0, tail_slot = 0, nlive = 0, cc = 0;
+            bool first = true, closed = false;
+            unsigned newest_q = term_q;
+            unsigned m = 0, q = term_q;   // this lane's cursor: parked on the terminal stub
 
-      for(int g = 0; g < NG; g++)
-        {
-          const int *lg = lists[0];
-          int ng_ = n_items[0];
+            for(;;)
+              {
+               for(;;)   // ---- produce until the ring is full (or the list is closed)
+                {
+                const bool flush = cc >= nchunks && !closed;
+                if(wr_pos >= 32 || (flush && wr_pos > 0))
+                  {
+                    // ---- the reach masks of the block in slot wr_slot (nfill entries) and its publication
+                    const int nfill = wr_pos < 32 ? wr_pos : 32;
+                    const unsigned sq = wbase + (unsigned)wr_slot * ER_SLOT;
+                    unsigned word = 0;
+                    if(fastmask)
+                      {
+                        const double4 er = lds_d4(sq + mrow_off);
+                        const float fx = (float)er.x, fy = (float)er.y, fz = (float)er.z;
+                        const float e2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                        const float a0 = mh ? fy : fx, a1 = mh ? e2 : fz, a2 = mh ? 0.0f : 1.0f;
+                        unsigned wt[2];
 #pragma unroll
-          for(int qq = 1; qq < NG; qq++)
-            if(qq == g)
-              {
-                lg = lists[qq];
-                ng_ = n_items[qq];
+                        for(int tb = 0; tb < 2; tb++)
+                          {
+                            f16v acc;
+#pragma unroll
+                            for(int r = 0; r < 16; r++)
+                              acc[r] = 0.0f;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, mB[tb][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mB[tb][1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, mB[tb][2], acc, 0, 0, 0);
+                            unsigned w_ = 0;
+#pragma unroll
+                            for(int r = 15; r >= 0; r--)
+                              w_ = __builtin_amdgcn_alignbit(w_, __float_as_uint(acc[r]), 31);
+                            wt[tb] = w_;
+                          }
+                        // lanes 32-63 of wt[0] <-> lanes 0-31 of wt[1]: afterwards [0] = this lane's target against entries 0-15, [1] = 16-31
+                        const auto sw = __builtin_amdgcn_permlane32_swap(wt[0], wt[1], false, false);
+                        word = sw[0] | (sw[1] << 16);
+                      }
+                    else
+                      {
+                        for(int b = 0; b < nfill; b++)
+                          {
+                            const double4 e = lds_d4(sq + ER_ENT + 32u * (unsigned)b);
+                            double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
+                            if(LW)
+                              {
+                                dx = nearest(dx, wp.box, wp.boxhalf);
+                                dy = nearest(dy, wp.box, wp.boxhalf);
+                                dz = nearest(dz, wp.box, wp.boxhalf);
+                              }
+                            const double r2 = dx * dx + dy * dy + dz * dz;
+                            word |= (r2 < wp.reach2) ? (1u << b) : 0u;
+                          }
+                      }
+                    // entries beyond nfill are stale; lanes without a target take nothing; S lanes of a target share the entries
+                    const unsigned okm = !valid ? 0u : (nfill >= 32 ? ~0u : ((1u << nfill) - 1u));
+                    word &= okm & lane_pat;
+                    nint += __popc(word);   // the force loop takes the (rare) slots beyond the exact cut off again
+                    if(first)
+                      {
+                        m = word;
+                        q = sq;
+                        first = false;
+                      }
+                    else
+                      {
+                        lds_st_u32(newest_q + ER_NM + lane4, word);
+                        if(lane == 0)
+                          lds_st_u32(newest_q + ER_NEXT, sq);
+                      }
+                    lds_st_u32(sq + ER_NM + lane4, 0u);
+                    if(lane == 0)
+                      lds_st_u32(sq + ER_NEXT, sq);
+                    newest_q = sq;
+                    wave_sync();
+                    wr_pos -= nfill;
+                    wr_slot = wr_slot + 1 >= K ? 0 : wr_slot + 1;
+                    nlive++;
+                    continue;
+                  }
+                if(flush)
+                  {
+                    if(!first && lane == 0)
+                      lds_st_u32(newest_q + ER_NEXT, term_q);   // the list ends here
+                    closed = true;
+                    wave_sync();
+                    continue;
+                  }
+                if(cc < nchunks && K * 32 - (nlive * 32 + wr_pos) >= WAVE)
+                  {
+                    // ---- produce: cull chunk cc (its record was requested one chunk ago) into the ring
+                    double ex = rx - bcx, ey = ry - bcy, ez = rz - bcz;
+                    if(!nowrap)
+                      {
+                        ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
+                        ey = nearest_abs(ey, wp.box, invbox);
+                        ez = nearest_abs(ez, wp.box, invbox);
+                      }
+                    // a source farther than the cut from the whole bounding box contributes to no target
+                    const double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
+                    const bool live = rw != 0.0 && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+                    const unsigned long long lm = __ballot(live ? 1 : 0);
+                    if(live)
+                      {
+                        const int L = wr_pos + lane_prefix(lm);   // < 160: at most three slots from wr_slot on
+                        const int s1 = wr_slot + 1 >= K ? wr_slot + 1 - K : wr_slot + 1, s2 = wr_slot + 2 >= K ? wr_slot + 2 - K : wr_slot + 2;
+                        const unsigned q0 = wbase + (unsigned)wr_slot * ER_SLOT, q1 = wbase + (unsigned)s1 * ER_SLOT,
+                                       q2 = wbase + (unsigned)s2 * ER_SLOT;
+                        const unsigned sq = L < 32 ? q0 : (L < 64 ? q1 : q2);
+                        const unsigned ea = sq + ER_ENT + 32u * (unsigned)(L & 31);
+                        typedef double d2 __attribute__((ext_vector_type(2)));
+                        d2 lo;
+                        lo.x = LW ? rx : ex;
+                        lo.y = LW ? ry : ey;
+                        ER_AS3(d2, ea) = lo;
+                        ER_AS3(double, ea + 16u) = LW ? rz : ez;
+                        ER_AS3(double, ea + 24u) = rw;
+                        if(!usoft)
+                          lds_st_u8(sq + ER_TYPE + (unsigned)(L & 31), (unsigned char)(hs1 & 7));
+                      }
+                    wr_pos += __popcll(lm);
+                    cc++;
+                    fetch(cc);
+                    wave_sync();
+                    continue;
+                  }
+                break;
+                }
+                if(nlive == 0)
+                  break;
+                // ---- consume: trips until no lane is left on the oldest block
+                {
+                  const unsigned tail_q = wbase + (unsigned)tail_slot * ER_SLOT;
+                  if constexpr(!LW && (ET || !YUK))
+                    {
+                      // The trip loop is written out in gfx950 assembly (ER_TRIP_ASM): left to the compiler, the loop-carried state
+                      // (cursor, accumulators) was copied between registers on every trip and around every call of the loop.
+                      int ntr;
+#define ER_TRIP_CALL(YUKSEG, FSTOFF)                                                                                              \
+  asm volatile(ER_TRIP_ASM(YUKSEG, FSTOFF)                                                                                         \
+               : [m] "+v"(m), [q] "+v"(q), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [nint] "+v"(nint), [ntr] "=&s"(ntr)           \
+               : [tpx] "v"(tpx), [tpy] "v"(tpy), [tpz] "v"(tpz), [cN] "v"(cNg), [cY] "v"(cYg), [cS] "v"(cSg), [hT] "v"(hT),          \
+                 [trow] "v"(trow_a), [lane4] "v"(lane4), [tail] "s"(tail_q), [reach2] "s"(wp.reach2), [tiny] "s"(1e-290),           \
+                 [asmthfac] "s"(wp.asmthfac), [ec0] "s"(wp.ec[0]), [ec1] "s"(wp.ec[1]), [ec2] "s"(wp.ec[2]), [ec3] "s"(wp.ec[3]),   \
+                 [utor2wpi] "s"(wp.utor2wpi), [ym] "s"(wp.ym), [h2max] "s"(h2max), [etab] "s"(etab_a)                              \
+               : ER_TRIP_CLOBBERS)
+                      if constexpr(YUK)
+                        ER_TRIP_CALL(ER_YUK_ET, ER_FST_OFF_ET);
+                      else
+                        ER_TRIP_CALL(ER_NOYUK, ER_FST_OFF_NOET);
+#undef ER_TRIP_CALL
+                      st_iters += ntr;
+                    }
+                  else
+                  for(;;)
+                    {
+                      if(__builtin_amdgcn_ballot_w64(q == tail_q) == 0ull)
+                        break;
+                      st_iters += (int)(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) >> 6);   // (+1, computed on the scalar unit)
+                      int j;
+                      asm("v_ffbl_b32 %0, %1" : "=v"(j) : "v"(m));   // an exhausted mask gives -1: the NULL entry in front of the slot
+                      const unsigned a = q + ((unsigned)j << 5);
+                      const double4 e = lds_d4(a + ER_ENT);
+                      // m - 1 carries unless m is 0: the carry IS the mask of the lanes that hold a real entry this trip
+                      unsigned long long actm_;
+                      unsigned mm1;
+                      asm("v_add_co_u32_e64 %0, %1, %2, -1" : "=v"(mm1), "=s"(actm_) : "v"(m));
+                      // (an asm result counts as divergent; through readfirstlane the mask stays on the scalar unit)
+                      const unsigned long long actm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(actm_ >> 32)) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readfirstlane((int)actm_);
+                      m &= mm1;
+                      if(m == 0u)   // this lane's bits of the block are used up: follow the link (or stay, if the next block is not there yet)
+                        {
+                          const unsigned qn = lds_u32(q + ER_NEXT);
+                          m = lds_u32(q + ER_NM + lane4);
+                          q = qn;
+                        }
+                      // ---- one pool entry against this lane's target (forcetree.c:1953-2032), as k_walk_group2's evalN
+                      double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
+                      if(LW)
+                        {
+                          dx = nearest(dx, wp.box, wp.boxhalf);
+                          dy = nearest(dy, wp.box, wp.boxhalf);
+                          dz = nearest(dz, wp.box, wp.boxhalf);
+                        }
+                      const double r2 = dx * dx + dy * dy + dz * dz;
+                      double mw = e.w;
+                      const unsigned long long fpos = actm & __builtin_amdgcn_ballot_w64(!(r2 < wp.reach2));
+                      if(fpos != 0ull)                                                  // rare: beyond the exact cut
+                        {
+                          asm volatile("; beyond the exact cut" ::: "memory");          // keeps this a branch
+                          double r2o = r2;
+                          asm volatile("" : "+v"(r2o));
+                          unsigned long long am = actm;
+                          asm volatile("" : "+s"(am));
+                          const bool out = ((am >> lane) & 1ull) != 0 && !(r2o < wp.reach2);
+                          mw = out ? 0.0 : mw;
+                          nint -= out ? 1 : 0;
+                        }
+                      // self / coincident pairs stay finite (d = 0 kills them)
+                      const double q2 = r2 + 1e-290;
+                      double ri = __builtin_amdgcn_rsq(q2);
+                      ri = ri * (1.5 - 0.5 * q2 * ri * ri);                             // one Newton step: ~2^-51
+                      const double rr = q2 * ri;                                        // sqrt(r2) to ~2^-51
+                      const double ri2 = ri * ri;
+                      double f = cNg * ri2;
+                      const double xt = wp.asmthfac * rr;
+                      int tab = (int)xt;                                                // saturating conversion, then clamped
+                      tab = tab < NTAB - 1 ? tab : NTAB - 1;
+                      if(YUK)
+                        {
+                          double ex_;
+                          if(ET)
+                            {
+                              // exp(-ym r) = E[tab] exp(-u), u = ub * (position inside the bin): degree-4 Taylor in the bin fraction
+                              // (Horner with one scalar operand per instruction: the constant bus takes one)
+                              const double fb = __builtin_amdgcn_fract(xt);
+                              double pz_ = fb * wp.ec[3];
+                              pz_ = pz_ - wp.ec[2];
+                              pz_ = __builtin_fma(pz_, fb, wp.ec[1]);
+                              pz_ = __builtin_fma(pz_, fb, -wp.ec[0]);
+                              pz_ = __builtin_fma(pz_, fb, 1.0);
+                              ex_ = ER_AS3(const double, etab_a + 8u * (unsigned)tab) * pz_;
+                            }
+                          else
+                            ex_ = exp_neg_fast(rr * wp.ym, expT);
+                          f += cYg * ex_ * (wp.ym * ri + ri2);
+                        }
+                      f -= wp.utor2wpi * ER_AS3(const double, trow_a + 8u * (unsigned)tab);
+                      double fac = f * mw * ri;
+                      if(wave_any(r2 < h2max))                                          // rare: possibly inside the softening radius
+                        {
+                          asm volatile("; softened pair" ::: "memory");
+                          // (the entry's type byte is at [slot] + ER_TYPE + j: in terms of a and j, which the cursor update left alone)
+                          const double h = __builtin_fmax(hT, fsT[lds_u8(a - 31u * (unsigned)j + ER_TYPE)]);   // forcetree.c:1415-1417
+                          const bool soft = rr < h;
+                          double h_inv = 1 / h, u = rr * h_inv;
+                          double v = (u < 0.5) ? (10.666666666667 + u * u * (32.0 * u - 38.4))
+                                               : (21.333333333333 - 48.0 * u + 38.4 * u * u - 10.666666666667 * u * u * u - 0.066666666667 / (u * u * u));
+                          double fs = cSg * mw * h_inv * h_inv * h_inv * v;
+                          fac = soft ? fs : fac;
+                        }
+                      ax = __builtin_fma(dx, fac, ax);
+                      ay = __builtin_fma(dy, fac, ay);
+                      az = __builtin_fma(dz, fac, az);
+                    }
+                  tail_slot = tail_slot + 1 >= K ? 0 : tail_slot + 1;
+                  nlive--;
+                }
               }
-          phase2(g, lg, ng_);
-        }
+            wave_sync();
+          }
+      };
+      if(lanewrap)
+        run_lists(std::true_type{});
+      else
+        run_lists(std::false_type{});
 
       {
         int st_nodes = 0, st_batches = 0;
@@ -666,10 +820,14 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+static size_t er_fixed_bytes(const WalkParams &wp)
+{
+  return sizeof(double) * (size_t)(wp.ntab_lds + wp.exp_tab) * NTAB + 40 * sizeof(double) + NG_MAX * NG_MAX * sizeof(ErLaw);
+}
 // How many ring slots fit beside the tables for `waves` waves (0: the ring kernel cannot run -- fewer than 4 slots)
 int eval_ring_slots(const WalkParams &wp, int waves)
 {
-  const size_t fixed = sizeof(double) * (size_t)(wp.ntab_lds + wp.exp_tab) * NTAB + 40 * sizeof(double);
+  const size_t fixed = er_fixed_bytes(wp);
   const size_t avail = 160 * 1024 - fixed;
   const long long per_wave = (long long)(avail / (size_t)waves);
   long long K = (per_wave - (long long)ER_HEAD) / (long long)ER_SLOT;
@@ -678,14 +836,14 @@ int eval_ring_slots(const WalkParams &wp, int waves)
   return K >= 4 ? (int)K : 0;
 }
 
-template <int NG, bool YUK>
+template <int NG, bool YUK, bool ET>
 static int launch_eval_ring_t(ngravs_ctx *c, const TreeView &tv, const WalkParams &wp, int nblk, int waves, int K, const int *region,
                               const int *gcount, long long g0, long long nb, int lcap, int scap, int S, const int *tlist, int SG,
                               long long t_count)
 {
-  const size_t fixed = sizeof(double) * (size_t)(wp.ntab_lds + wp.exp_tab) * NTAB + 40 * sizeof(double);
+  const size_t fixed = er_fixed_bytes(wp);
   const size_t lds = fixed + (size_t)waves * ((size_t)K * ER_SLOT + ER_HEAD);
-  auto ke = k_eval_ring<NG, YUK>;
+  auto ke = k_eval_ring<NG, YUK, ET>;
   HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void *>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(ke, dim3((unsigned)nblk), dim3(waves * 64), lds, c->stream, tv, c->s_pm.p, c->s_type.p, c->s_active.p, c->table.p, wp,
                      (long long)c->shard_first, t_count, c->walk_counters.p, c->r_acc.p, c->r_nint.p, region, gcount, g0, nb, lcap, scap,
@@ -696,16 +854,16 @@ static int launch_eval_ring_t(ngravs_ctx *c, const TreeView &tv, const WalkParam
 int launch_eval_ring(ngravs_ctx *c, const TreeView &tv, const WalkParams &wp, bool yuk, int nblk, int waves, int K, const int *region,
                      const int *gcount, long long g0, long long nb, int lcap, int scap, int S, const int *tlist, int SG, long long t_count)
 {
+#define ER_GO(NG_, Y_, E_) launch_eval_ring_t<NG_, Y_, E_>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count)
+  const bool et = yuk && wp.exp_tab;   // Yukawa factor through the table bins
   switch(c->cfg.n_gravs)
     {
     case 1:
-      return yuk ? launch_eval_ring_t<1, true>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count)
-                 : launch_eval_ring_t<1, false>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count);
+      return yuk ? (et ? ER_GO(1, true, true) : ER_GO(1, true, false)) : ER_GO(1, false, false);
     case 2:
-      return yuk ? launch_eval_ring_t<2, true>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count)
-                 : launch_eval_ring_t<2, false>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count);
+      return yuk ? (et ? ER_GO(2, true, true) : ER_GO(2, true, false)) : ER_GO(2, false, false);
     default:
-      return yuk ? launch_eval_ring_t<3, true>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count)
-                 : launch_eval_ring_t<3, false>(c, tv, wp, nblk, waves, K, region, gcount, g0, nb, lcap, scap, S, tlist, SG, t_count);
+      return yuk ? (et ? ER_GO(3, true, true) : ER_GO(3, true, false)) : ER_GO(3, false, false);
     }
+#undef ER_GO
 }
