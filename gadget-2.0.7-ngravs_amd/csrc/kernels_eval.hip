@@ -221,6 +221,59 @@ __device__ __forceinline__ void lds_st_d4(unsigned a, const double4 &v)
       "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "s90", "s91", "s92", "s93", "s94", "s95",   \
       "vcc", "scc", "memory"
 
+
+// ---- the cull of one chunk in assembly: 64 records (one per lane, massless when the lane has none) against the group's box, the
+// survivors compacted behind the wr_pos entries that wait from slot q0 on (q1, q2: the two slots that follow it in the ring).
+//   v[100:105] position relative to the box centre    v[106:111] distance to the box    v112 ring position    v113 slot    v114 address
+#define ER_CULL_WRAP                                                                                                                \
+  "v_mul_f64 v[106:107], v[100:101], %[invbox]\n"                     /* nearest image: x - box rint(x / box)                    */ \
+  "v_mul_f64 v[108:109], v[102:103], %[invbox]\n"                                                                                  \
+  "v_mul_f64 v[110:111], v[104:105], %[invbox]\n"                                                                                  \
+  "v_rndne_f64_e32 v[106:107], v[106:107]\n"                                                                                       \
+  "v_rndne_f64_e32 v[108:109], v[108:109]\n"                                                                                       \
+  "v_rndne_f64_e32 v[110:111], v[110:111]\n"                                                                                       \
+  "v_fma_f64 v[100:101], -v[106:107], %[box], v[100:101]\n"                                                                        \
+  "v_fma_f64 v[102:103], -v[108:109], %[box], v[102:103]\n"                                                                        \
+  "v_fma_f64 v[104:105], -v[110:111], %[box], v[104:105]\n"
+#define ER_CULL_ASM(WRAPSEG)                                                                                                        \
+  "v_add_f64 v[100:101], %[rx], -%[bcx]\n"                                                                                         \
+  "v_add_f64 v[102:103], %[ry], -%[bcy]\n"                                                                                         \
+  "v_add_f64 v[104:105], %[rz], -%[bcz]\n"                                                                                         \
+  WRAPSEG                                                                                                                          \
+  "v_add_f64 v[106:107], |v[100:101]|, -%[bhx]\n"                     /* a source farther than the cut from the whole box ...     */ \
+  "v_add_f64 v[108:109], |v[102:103]|, -%[bhy]\n"                                                                                  \
+  "v_add_f64 v[110:111], |v[104:105]|, -%[bhz]\n"                                                                                  \
+  "v_max_f64 v[106:107], v[106:107], 0\n"                                                                                          \
+  "v_max_f64 v[108:109], v[108:109], 0\n"                                                                                          \
+  "v_max_f64 v[110:111], v[110:111], 0\n"                                                                                          \
+  "v_mul_f64 v[106:107], v[106:107], v[106:107]\n"                                                                                 \
+  "v_fma_f64 v[106:107], v[108:109], v[108:109], v[106:107]\n"                                                                     \
+  "v_fma_f64 v[106:107], v[110:111], v[110:111], v[106:107]\n"                                                                     \
+  "v_cmp_gt_f64_e32 vcc, %[reach2], v[106:107]\n"                     /* ... contributes to no target                            */ \
+  "v_cmp_neq_f64_e64 s[90:91], 0, %[rw]\n"                            /* nor does a massless one (empty species of a node)       */ \
+  "s_and_b64 s[90:91], s[90:91], vcc\n"                                                                                            \
+  "s_bcnt1_i32_b64 %[cnt], s[90:91]\n"                                                                                             \
+  "v_mbcnt_lo_u32_b32 v112, s90, 0\n"                                                                                              \
+  "v_mbcnt_hi_u32_b32 v112, s91, v112\n"                                                                                           \
+  "v_add_u32_e32 v112, %[wrpos], v112\n"                              /* position among the waiting entries                      */ \
+  "s_and_saveexec_b64 s[92:93], s[90:91]\n"                                                                                        \
+  "v_cmp_gt_u32_e32 vcc, 32, v112\n"                                 /* (vcc is a scalar operand too: the slots go through VGPRs) */ \
+  "v_mov_b32_e32 v113, %[q0]\n"                                                                                                    \
+  "v_mov_b32_e32 v115, %[q1]\n"                                                                                                    \
+  "v_cndmask_b32_e32 v113, v115, v113, vcc\n"                                                                                      \
+  "v_cmp_gt_u32_e32 vcc, 64, v112\n"                                                                                               \
+  "v_mov_b32_e32 v115, %[q2]\n"                                                                                                    \
+  "v_cndmask_b32_e32 v113, v115, v113, vcc\n"                                                                                      \
+  "v_and_b32_e32 v114, 31, v112\n"                                                                                                 \
+  "v_lshl_add_u32 v114, v114, 5, v113\n"                                                                                           \
+  "ds_write_b128 v114, v[100:103] offset:336\n"                                                                                    \
+  "ds_write_b64 v114, v[104:105] offset:352\n"                                                                                     \
+  "ds_write_b64 v114, %[rw] offset:360\n"                                                                                          \
+  "s_mov_b64 exec, s[92:93]\n"
+#define ER_CULL_CLOBBERS                                                                                                            \
+  "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115",   \
+      "s90", "s91", "s92", "s93", "vcc", "scc", "memory"
+
 // law coefficients of a [target species][source species] pair as the kernel keeps them in LDS (read once per list and lane)
 struct ErLaw
 {
@@ -245,7 +298,7 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
   double *expT = reinterpret_cast<double *>(er_smem + tab_bytes);
   double *fsT = expT + 32;   // softening length per particle type (8 entries; index 7 = NULL entry)
   ErLaw *lawT = reinterpret_cast<ErLaw *>(fsT + 8);
-  const unsigned fixed_bytes = tab_bytes + 40u * (unsigned)sizeof(double) + (unsigned)(NG_MAX * NG_MAX * sizeof(ErLaw));
+  const unsigned fixed_bytes = tab_bytes + 40u * (unsigned)sizeof(double) + (unsigned)(NG * NG * sizeof(ErLaw));
   const unsigned wave_bytes = (unsigned)K * ER_SLOT + ER_HEAD;
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) unsigned char *)er_smem;   // LDS address of er_smem
   const unsigned wbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + fixed_bytes + (unsigned)wave * wave_bytes));
@@ -478,180 +531,53 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
             int slot = (int)(((long long)lane * s_) % M);
             int4 qd = {0, 0, 0, 0};   // item quad of the current four chunks
             int nv = 0;
-            // the record (and softening type) of chunk cc, requested one chunk ahead
-            double rx = 0, ry = 0, rz = 0, rw = 0;
-            int hs1 = 0;
-            auto fetch = [&](const int c_) {   // c_: chunk whose record is requested (wave-uniform)
-              const int bn = c_ & 3;
-              if(bn == 0)
-                {
-                  qd.x = qd.y = qd.z = qd.w = 0;
-                  nv = 0;
-                  if((c_ >> 2) < nsuper && slot < nq)
-                    {
-                      qd = reinterpret_cast<const int4 *>(items)[slot];
-                      nv = n - 4 * slot;
-                    }
-                  slot += step64;
-                  slot = slot >= M ? slot - M : slot;
-                }
-              const int item = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
-              rw = 0.0;   // (no record: the cull drops massless entries)
-              if(c_ < nchunks && bn < nv)
-                {
-                  const bool isp = item >= 0;
-                  const unsigned idx = isp ? (unsigned)item : ~(unsigned)item;   // monopole: node * NG + g = -1 - item
-                  const double4 *src = isp ? s_pm + idx : tv.mom + idx;
-                  const double4 r = *src;
-                  rx = r.x;
-                  ry = r.y;
-                  rz = r.z;
-                  rw = r.w;
-                  if(!usoft)   // (one softening length for all types: no type / flag bytes, each of which would pull another cache line)
-                    hs1 = isp ? (int)s_type[idx] : ((tv.flags[idx / NG] >> 2) & 7);
-                }
-            };
-            fetch(0);
-
             // ring state (wave-uniform): blocks tail .. tail + nlive - 1 are complete and not yet left by every lane; wr_pos entries
             // (up to 95: a partial block + one chunk) wait from slot wr_slot on
-            int wr_slot = 0, wr_pos = 0, tail_slot = 0, nlive = 0, cc = 0;
-            bool first = true, closed = false;
+            int wr_slot = 0, wr_pos = 0, tail_slot = 0, nlive = 0;
+            bool first = true;
             unsigned newest_q = term_q;
             unsigned m = 0, q = term_q;   // this lane's cursor: parked on the terminal stub
-
-            for(;;)
+            // One turn per chunk of 64 items: its records are requested, the oldest blocks are evaluated until the chunk fits into
+            // the ring (the requests are in flight meanwhile), the chunk is culled into the ring, the blocks it completes get their
+            // masks.  After the last chunk the ring is drained.
+            for(int cc = 0;; cc++)
               {
-               for(;;)   // ---- produce until the ring is full (or the list is closed)
-                {
-                const bool flush = cc >= nchunks && !closed;
-                if(wr_pos >= 32 || (flush && wr_pos > 0))
+                const bool have_chunk = cc < nchunks;
+                double rx = 0, ry = 0, rz = 0, rw = 0;   // the record of this lane's item (no item: massless, the cull drops it)
+                int hs1 = 0;
+                if(have_chunk)
                   {
-                    // ---- the reach masks of the block in slot wr_slot (nfill entries) and its publication
-                    const int nfill = wr_pos < 32 ? wr_pos : 32;
-                    const unsigned sq = wbase + (unsigned)wr_slot * ER_SLOT;
-                    unsigned word = 0;
-                    if(fastmask)
+                    const int bn = cc & 3;
+                    if(bn == 0)
                       {
-                        const double4 er = lds_d4(sq + mrow_off);
-                        const float fx = (float)er.x, fy = (float)er.y, fz = (float)er.z;
-                        const float e2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
-                        const float a0 = mh ? fy : fx, a1 = mh ? e2 : fz, a2 = mh ? 0.0f : 1.0f;
-                        unsigned wt[2];
-#pragma unroll
-                        for(int tb = 0; tb < 2; tb++)
+                        qd.x = qd.y = qd.z = qd.w = 0;
+                        nv = 0;
+                        if(slot < nq)
                           {
-                            f16v acc;
-#pragma unroll
-                            for(int r = 0; r < 16; r++)
-                              acc[r] = 0.0f;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, mB[tb][0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mB[tb][1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, mB[tb][2], acc, 0, 0, 0);
-                            unsigned w_ = 0;
-#pragma unroll
-                            for(int r = 15; r >= 0; r--)
-                              w_ = __builtin_amdgcn_alignbit(w_, __float_as_uint(acc[r]), 31);
-                            wt[tb] = w_;
+                            qd = reinterpret_cast<const int4 *>(items)[slot];
+                            nv = n - 4 * slot;
                           }
-                        // lanes 32-63 of wt[0] <-> lanes 0-31 of wt[1]: afterwards [0] = this lane's target against entries 0-15, [1] = 16-31
-                        const auto sw = __builtin_amdgcn_permlane32_swap(wt[0], wt[1], false, false);
-                        word = sw[0] | (sw[1] << 16);
+                        slot += step64;
+                        slot = slot >= M ? slot - M : slot;
                       }
-                    else
+                    const int item = bn == 0 ? qd.x : (bn == 1 ? qd.y : (bn == 2 ? qd.z : qd.w));
+                    if(bn < nv)
                       {
-                        for(int b = 0; b < nfill; b++)
-                          {
-                            const double4 e = lds_d4(sq + ER_ENT + 32u * (unsigned)b);
-                            double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
-                            if(LW)
-                              {
-                                dx = nearest(dx, wp.box, wp.boxhalf);
-                                dy = nearest(dy, wp.box, wp.boxhalf);
-                                dz = nearest(dz, wp.box, wp.boxhalf);
-                              }
-                            const double r2 = dx * dx + dy * dy + dz * dz;
-                            word |= (r2 < wp.reach2) ? (1u << b) : 0u;
-                          }
+                        const bool isp = item >= 0;
+                        const unsigned idx = isp ? (unsigned)item : ~(unsigned)item;   // monopole: node * NG + g = -1 - item
+                        const double4 *src = isp ? s_pm + idx : tv.mom + idx;
+                        const double4 r = *src;
+                        rx = r.x;
+                        ry = r.y;
+                        rz = r.z;
+                        rw = r.w;
+                        if(!usoft)   // (one softening length for all types: no type / flag bytes, each of which would pull another cache line)
+                          hs1 = isp ? (int)s_type[idx] : ((tv.flags[idx / NG] >> 2) & 7);
                       }
-                    // entries beyond nfill are stale; lanes without a target take nothing; S lanes of a target share the entries
-                    const unsigned okm = !valid ? 0u : (nfill >= 32 ? ~0u : ((1u << nfill) - 1u));
-                    word &= okm & lane_pat;
-                    nint += __popc(word);   // the force loop takes the (rare) slots beyond the exact cut off again
-                    if(first)
-                      {
-                        m = word;
-                        q = sq;
-                        first = false;
-                      }
-                    else
-                      {
-                        lds_st_u32(newest_q + ER_NM + lane4, word);
-                        if(lane == 0)
-                          lds_st_u32(newest_q + ER_NEXT, sq);
-                      }
-                    lds_st_u32(sq + ER_NM + lane4, 0u);
-                    if(lane == 0)
-                      lds_st_u32(sq + ER_NEXT, sq);
-                    newest_q = sq;
-                    wave_sync();
-                    wr_pos -= nfill;
-                    wr_slot = wr_slot + 1 >= K ? 0 : wr_slot + 1;
-                    nlive++;
-                    continue;
                   }
-                if(flush)
+                // ---- consume: the oldest blocks, until the chunk fits (no chunk left: until the ring is empty)
+                while(nlive > 0 && (!have_chunk || K * 32 - (nlive * 32 + wr_pos) < WAVE))
                   {
-                    if(!first && lane == 0)
-                      lds_st_u32(newest_q + ER_NEXT, term_q);   // the list ends here
-                    closed = true;
-                    wave_sync();
-                    continue;
-                  }
-                if(cc < nchunks && K * 32 - (nlive * 32 + wr_pos) >= WAVE)
-                  {
-                    // ---- produce: cull chunk cc (its record was requested one chunk ago) into the ring
-                    double ex = rx - bcx, ey = ry - bcy, ez = rz - bcz;
-                    if(!nowrap)
-                      {
-                        ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
-                        ey = nearest_abs(ey, wp.box, invbox);
-                        ez = nearest_abs(ez, wp.box, invbox);
-                      }
-                    // a source farther than the cut from the whole bounding box contributes to no target
-                    const double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
-                    const bool live = rw != 0.0 && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
-                    const unsigned long long lm = __ballot(live ? 1 : 0);
-                    if(live)
-                      {
-                        const int L = wr_pos + lane_prefix(lm);   // < 160: at most three slots from wr_slot on
-                        const int s1 = wr_slot + 1 >= K ? wr_slot + 1 - K : wr_slot + 1, s2 = wr_slot + 2 >= K ? wr_slot + 2 - K : wr_slot + 2;
-                        const unsigned q0 = wbase + (unsigned)wr_slot * ER_SLOT, q1 = wbase + (unsigned)s1 * ER_SLOT,
-                                       q2 = wbase + (unsigned)s2 * ER_SLOT;
-                        const unsigned sq = L < 32 ? q0 : (L < 64 ? q1 : q2);
-                        const unsigned ea = sq + ER_ENT + 32u * (unsigned)(L & 31);
-                        typedef double d2 __attribute__((ext_vector_type(2)));
-                        d2 lo;
-                        lo.x = LW ? rx : ex;
-                        lo.y = LW ? ry : ey;
-                        ER_AS3(d2, ea) = lo;
-                        ER_AS3(double, ea + 16u) = LW ? rz : ez;
-                        ER_AS3(double, ea + 24u) = rw;
-                        if(!usoft)
-                          lds_st_u8(sq + ER_TYPE + (unsigned)(L & 31), (unsigned char)(hs1 & 7));
-                      }
-                    wr_pos += __popcll(lm);
-                    cc++;
-                    fetch(cc);
-                    wave_sync();
-                    continue;
-                  }
-                break;
-                }
-                if(nlive == 0)
-                  break;
-                // ---- consume: trips until no lane is left on the oldest block
-                {
                   const unsigned tail_q = wbase + (unsigned)tail_slot * ER_SLOT;
                   if constexpr(!LW && (ET || !YUK))
                     {
@@ -768,7 +694,144 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
                     }
                   tail_slot = tail_slot + 1 >= K ? 0 : tail_slot + 1;
                   nlive--;
+                  }
+                if(!have_chunk)
+                  break;
+                // ---- produce: cull the chunk into the ring
+                {
+                  const int s1 = wr_slot + 1 >= K ? wr_slot + 1 - K : wr_slot + 1, s2 = wr_slot + 2 >= K ? wr_slot + 2 - K : wr_slot + 2;
+                  const unsigned q0 = wbase + (unsigned)wr_slot * ER_SLOT, q1 = wbase + (unsigned)s1 * ER_SLOT, q2 = wbase + (unsigned)s2 * ER_SLOT;
+                  if(!LW && usoft)
+                    {
+                      int cnt;
+#define ER_CULL_CALL(WRAPSEG)                                                                                                     \
+  asm volatile(ER_CULL_ASM(WRAPSEG)                                                                                                \
+               : [cnt] "=&s"(cnt)                                                                                                   \
+               : [rx] "v"(rx), [ry] "v"(ry), [rz] "v"(rz), [rw] "v"(rw), [bcx] "s"(bcx), [bcy] "s"(bcy), [bcz] "s"(bcz), [bhx] "s"(bhx),  \
+                 [bhy] "s"(bhy), [bhz] "s"(bhz), [reach2] "s"(wp.reach2), [box] "s"(wp.box), [invbox] "s"(invbox), [wrpos] "s"(wr_pos),   \
+                 [q0] "s"(q0), [q1] "s"(q1), [q2] "s"(q2)                                                                           \
+               : ER_CULL_CLOBBERS)
+                      if(nowrap)
+                        ER_CULL_CALL("");
+                      else
+                        ER_CULL_CALL(ER_CULL_WRAP);
+#undef ER_CULL_CALL
+                      wr_pos += cnt;
+                    }
+                  else
+                    {
+                      double ex = rx - bcx, ey = ry - bcy, ez = rz - bcz;
+                      if(!nowrap)
+                        {
+                          ex = nearest_abs(ex, wp.box, invbox);   // a tie (|ex| = box/2) is far beyond any reach
+                          ey = nearest_abs(ey, wp.box, invbox);
+                          ez = nearest_abs(ez, wp.box, invbox);
+                        }
+                      // a source farther than the cut from the whole bounding box contributes to no target
+                      const double b0 = fmax(0.0, fabs(ex) - bhx), b1 = fmax(0.0, fabs(ey) - bhy), b2 = fmax(0.0, fabs(ez) - bhz);
+                      const bool live = rw != 0.0 && (b0 * b0 + b1 * b1 + b2 * b2 < wp.reach2);
+                      const unsigned long long lm = __ballot(live ? 1 : 0);
+                      if(live)
+                        {
+                          const int L = wr_pos + lane_prefix(lm);   // < 96: at most three slots from wr_slot on
+                          const unsigned sq = L < 32 ? q0 : (L < 64 ? q1 : q2);
+                          const unsigned ea = sq + ER_ENT + 32u * (unsigned)(L & 31);
+                          typedef double d2 __attribute__((ext_vector_type(2)));
+                          d2 lo;
+                          lo.x = LW ? rx : ex;
+                          lo.y = LW ? ry : ey;
+                          ER_AS3(d2, ea) = lo;
+                          ER_AS3(double, ea + 16u) = LW ? rz : ez;
+                          ER_AS3(double, ea + 24u) = rw;
+                          if(!usoft)
+                            lds_st_u8(sq + ER_TYPE + (unsigned)(L & 31), (unsigned char)(hs1 & 7));
+                        }
+                      wr_pos += __popcll(lm);
+                    }
+                  wave_sync();
                 }
+                // ---- the blocks the chunk completed (after the last chunk: also the partial one) get their masks
+                const bool last = cc + 1 >= nchunks;
+                while(wr_pos >= 32 || (last && wr_pos > 0))
+                  {
+                    // ---- the reach masks of the block in slot wr_slot (nfill entries) and its publication
+                    const int nfill = wr_pos < 32 ? wr_pos : 32;
+                    const unsigned sq = wbase + (unsigned)wr_slot * ER_SLOT;
+                    unsigned word = 0;
+                    if(fastmask)
+                      {
+                        const double4 er = lds_d4(sq + mrow_off);
+                        const float fx = (float)er.x, fy = (float)er.y, fz = (float)er.z;
+                        const float e2 = __builtin_fmaf(fz, fz, __builtin_fmaf(fy, fy, fx * fx));
+                        const float a0 = mh ? fy : fx, a1 = mh ? e2 : fz, a2 = mh ? 0.0f : 1.0f;
+                        unsigned wt[2];
+#pragma unroll
+                        for(int tb = 0; tb < 2; tb++)
+                          {
+                            f16v acc;
+#pragma unroll
+                            for(int r = 0; r < 16; r++)
+                              acc[r] = 0.0f;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, mB[tb][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, mB[tb][1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, mB[tb][2], acc, 0, 0, 0);
+                            unsigned w_ = 0;
+#pragma unroll
+                            for(int r = 15; r >= 0; r--)
+                              w_ = __builtin_amdgcn_alignbit(w_, __float_as_uint(acc[r]), 31);
+                            wt[tb] = w_;
+                          }
+                        // lanes 32-63 of wt[0] <-> lanes 0-31 of wt[1]: afterwards [0] = this lane's target against entries 0-15, [1] = 16-31
+                        const auto sw = __builtin_amdgcn_permlane32_swap(wt[0], wt[1], false, false);
+                        word = sw[0] | (sw[1] << 16);
+                      }
+                    else
+                      {
+                        for(int b = 0; b < nfill; b++)
+                          {
+                            const double4 e = lds_d4(sq + ER_ENT + 32u * (unsigned)b);
+                            double dx = e.x - tpx, dy = e.y - tpy, dz = e.z - tpz;
+                            if(LW)
+                              {
+                                dx = nearest(dx, wp.box, wp.boxhalf);
+                                dy = nearest(dy, wp.box, wp.boxhalf);
+                                dz = nearest(dz, wp.box, wp.boxhalf);
+                              }
+                            const double r2 = dx * dx + dy * dy + dz * dz;
+                            word |= (r2 < wp.reach2) ? (1u << b) : 0u;
+                          }
+                      }
+                    // entries beyond nfill are stale; lanes without a target take nothing; S lanes of a target share the entries
+                    const unsigned okm = !valid ? 0u : (nfill >= 32 ? ~0u : ((1u << nfill) - 1u));
+                    word &= okm & lane_pat;
+                    nint += __popc(word);   // the force loop takes the (rare) slots beyond the exact cut off again
+                    if(first)
+                      {
+                        m = word;
+                        q = sq;
+                        first = false;
+                      }
+                    else
+                      {
+                        lds_st_u32(newest_q + ER_NM + lane4, word);
+                        if(lane == 0)
+                          lds_st_u32(newest_q + ER_NEXT, sq);
+                      }
+                    lds_st_u32(sq + ER_NM + lane4, 0u);
+                    if(lane == 0)
+                      lds_st_u32(sq + ER_NEXT, sq);
+                    newest_q = sq;
+                    wave_sync();
+                    wr_pos -= nfill;
+                    wr_slot = wr_slot + 1 >= K ? 0 : wr_slot + 1;
+                    nlive++;
+                  }
+                if(last)
+                  {
+                    if(!first && lane == 0)
+                      lds_st_u32(newest_q + ER_NEXT, term_q);   // the list ends here
+                    wave_sync();
+                  }
               }
             wave_sync();
           }
@@ -822,7 +885,7 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
 // ---- host side ---------------------------------------------------------------------------------------------------
 static size_t er_fixed_bytes(const WalkParams &wp)
 {
-  return sizeof(double) * (size_t)(wp.ntab_lds + wp.exp_tab) * NTAB + 40 * sizeof(double) + NG_MAX * NG_MAX * sizeof(ErLaw);
+  return sizeof(double) * (size_t)(wp.ntab_lds + wp.exp_tab) * NTAB + 40 * sizeof(double) + (size_t)wp.ng * wp.ng * sizeof(ErLaw);
 }
 // How many ring slots fit beside the tables for `waves` waves (0: the ring kernel cannot run -- fewer than 4 slots)
 int eval_ring_slots(const WalkParams &wp, int waves)
