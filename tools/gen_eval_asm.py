@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""Writes gadget-2.0.7-ngravs_amd/csrc/eval_asm.inc: the gfx950 assembly blocks of the ring-pool evaluation kernel
+(kernels_eval.hip) as C string macros, from templates with NAMED registers.
+
+  tools/gen_eval_asm.py            (no arguments; the output is committed, the build does not run this script)
+
+Registers.  The blocks use v104 .. v127 and s90 .. s95 as temporaries and say so in their clobber lists; everything that lives
+from one block to the next is an operand.  (Tried and dropped: keeping the records of the chunk in flight in registers above an
+amdgpu_waves_per_eu cap, out of the compiler's sight -- the cap does not hold where the register pressure is highest, and the
+request written in assembly was not faster than the compiler's.)  A VALU instruction of this ISA takes ONE scalar operand
+(SGPR, VCC or literal).
+"""
+import os
+import re
+import struct
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gadget-2.0.7-ngravs_amd", "csrc", "eval_asm.inc")
+
+
+def pair(n):
+    return "v[%d:%d]" % (n, n + 1)
+
+
+REGS = {
+    # trip loop
+    "E0": "v[104:107]", "E1": "v[108:111]",          # entry as loaded: (x, y), (z, mass)
+    "DX": pair(104), "DY": pair(106), "DZ": pair(108), "MW": pair(110), "MWLO": "v110", "MWHI": "v111",
+    "R2": pair(112), "TT": pair(112),                # r^2, later the short-range table value
+    "RI": pair(114), "RR": pair(116),                # 1/r; r^2 + tiny, then r
+    "T1": pair(118), "T1LO": "v118", "T2": pair(120), "T2LO": "v120", "T2HI": "v121",
+    "T3": pair(122), "T3LO": "v122", "T3HI": "v123",  # fac
+    "TE": pair(124), "TELO": "v124", "TEHI": "v125",
+    "I1": "v112", "I2": "v113",                      # table offsets / addresses (R2 is dead by then ... see the loop)
+    "J": "v126", "A": "v127",
+    # cull
+    "EX": pair(104), "EY": pair(106), "EXY": "v[104:107]", "EZ": pair(108), "B0": pair(110), "B1": pair(112), "B2": pair(114),
+    "L": "v116", "SQ": "v117", "EA": "v118", "SQ2": "v119",
+}
+
+
+def lit(x):
+    lo, hi = struct.unpack("<II", struct.pack("<d", x))
+    return "0x%08x" % lo, "0x%08x" % hi
+
+
+def smov(pair_lo, x):
+    lo, hi = lit(x)
+    return ["s_mov_b32 s%d, %s" % (pair_lo, lo), "s_mov_b32 s%d, %s" % (pair_lo + 1, hi)]
+
+
+def subst(lines):
+    out = []
+    for l in lines:
+        code, _, comment = l.partition(";;")
+        code = re.sub(r"\{(\w+)\}", lambda m: REGS[m.group(1)], code.rstrip())
+        out.append((code, comment.strip()))
+    return out
+
+
+def macro(name, lines, params=""):
+    body = subst(lines)
+    txt = ["#define %s%s \\" % (name, params)]
+    for i, (code, comment) in enumerate(body):
+        if code.startswith("@"):           # a macro parameter spliced in
+            s = "  %s" % code[1:]
+        else:
+            s = '  "%s\\n"' % code
+        if comment:
+            s = s.ljust(78) + "/* " + comment + " */"
+        txt.append(s + (" \\" if i + 1 < len(body) else ""))
+    return "\n".join(txt) + "\n"
+
+
+def clobbers(name, vregs, sregs):
+    items = ['"v%d"' % v for v in vregs] + ['"s%d"' % s for s in sregs] + ['"vcc"', '"scc"', '"memory"']
+    return "#define %s %s\n" % (name, ", ".join(items))
+
+
+# ---- trip loop ---------------------------------------------------------------------------------------------------------------
+YUK_ET = [
+    "v_fract_f64_e32 {T1}, {T1}                      ;; fb: position inside the table bin",
+    "v_mul_f64 {T3}, {T1}, %[ec3]",
+    "v_lshl_add_u32 {I2}, {I1}, 3, %[etab]",
+    "v_add_f64 {T3}, {T3}, -%[ec2]",
+    "ds_read_b64 {TE}, {I2}                          ;; E[bin] = exp(-ym r_bin)",
+    "v_lshl_add_u32 {I1}, {I1}, 3, %[trow]",
+    "v_fma_f64 {T3}, {T3}, {T1}, %[ec1]",
+    "ds_read_b64 {TT}, {I1}                          ;; short-range table",
+    "v_fma_f64 {T3}, {T3}, {T1}, -%[ec0]",
+    "v_mul_f64 {T2}, {RI}, {RI}                      ;; 1/r^2",
+    "v_fma_f64 {T3}, {T3}, {T1}, 1.0                 ;; exp(-ym (r - r_bin)), degree 4",
+    "s_waitcnt lgkmcnt(1)",
+    "v_mul_f64 {T3}, {TE}, {T3}                      ;; exp(-ym r)",
+    "v_mul_f64 {T3}, %[cY], {T3}",
+    "v_fma_f64 {TE}, %[ym], {RI}, {T2}               ;; ym/r + 1/r^2",
+    "v_mul_f64 {T3}, {TE}, {T3}",
+    "v_fmac_f64_e32 {T3}, %[cN], {T2}                ;; + cN/r^2",
+]
+NOYUK = [
+    "v_lshl_add_u32 {I1}, {I1}, 3, %[trow]",
+    "ds_read_b64 {TT}, {I1}",
+    "v_mul_f64 {T2}, {RI}, {RI}",
+    "v_mul_f64 {T3}, %[cN], {T2}",
+]
+TRIP = [
+    "s_mov_b32 %[ntr], 0",
+    "L_er_top_%=:",
+    "v_cmp_eq_u32_e32 vcc, %[tail], %[q]",
+    "s_cbranch_vccz L_er_done_%=",
+    "s_add_u32 %[ntr], %[ntr], 1",
+    "v_ffbl_b32_e32 {J}, %[m]                        ;; -1 for an empty mask: the NULL entry",
+    "v_add_co_u32_e64 {I1}, s[90:91], %[m], -1       ;; carry <=> m != 0: the lanes with a real entry",
+    "v_lshl_add_u32 {A}, {J}, 5, %[q]",
+    "v_and_b32_e32 %[m], {I1}, %[m]",
+    "v_cmp_eq_u32_e32 vcc, 0, %[m]",
+    "s_and_saveexec_b64 s[92:93], vcc                ;; lanes whose block is used up follow the link",
+    "v_add_u32_e32 {I1}, %[q], %[lane4]",
+    "ds_read_b32 %[q], %[q] offset:256",
+    "ds_read_b32 %[m], {I1}",
+    "s_mov_b64 exec, s[92:93]",
+    "ds_read_b128 {E0}, {A} offset:336",
+    "ds_read_b128 {E1}, {A} offset:352",
+    "s_waitcnt lgkmcnt(1)                            ;; (right whether or not the masked reads were counted)",
+    "v_add_f64 {DX}, {DX}, -%[tpx]",
+    "v_add_f64 {DY}, {DY}, -%[tpy]",
+    "v_mul_f64 {R2}, {DY}, {DY}",
+    "s_waitcnt lgkmcnt(0)",
+    "v_add_f64 {DZ}, {DZ}, -%[tpz]",
+    "v_fmac_f64_e32 {R2}, {DX}, {DX}",
+    "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
+    "v_cmp_ngt_f64_e32 vcc, %[reach2], {R2}          ;; !(r2 < reach2)",
+    "s_and_b64 s[94:95], vcc, s[90:91]",
+    "s_cmp_eq_u64 s[94:95], 0",
+    "s_cbranch_scc1 L_er_incut_%=",
+    "v_cndmask_b32_e64 {MWHI}, {MWHI}, 0, s[94:95]   ;; rare: beyond the exact cut -- no mass, not counted",
+    "v_cndmask_b32_e64 {MWLO}, {MWLO}, 0, s[94:95]",
+    "v_cndmask_b32_e64 {T1LO}, 0, 1, s[94:95]",
+    "v_sub_u32_e32 %[nint], %[nint], {T1LO}",
+    "L_er_incut_%=:",
+    "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
+    "v_rsq_f64_e32 {RI}, {RR}",
+    "v_cmp_lt_f64_e64 s[94:95], {R2}, %[h2max]       ;; closer than the largest softening length?",
+    "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
+    "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
+    "v_mul_f64 {T2}, {RI}, 0.5",
+    "v_fma_f64 {RI}, {T2}, {T1}, {RI}                ;; 1/r",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; r",
+    "v_mul_f64 {T1}, {RR}, %[asmthfac]",
+    "v_cvt_i32_f64_e32 {I1}, {T1}                    ;; table bin (saturating conversion, then clamped); r2 is no longer needed",
+    "v_min_i32_e32 {I1}, 0x7ff, {I1}",
+    "@YUKSEG",
+    "s_waitcnt lgkmcnt(0)",
+    "v_fma_f64 {T3}, -%[utor2wpi], {TT}, {T3}        ;; - long-range part",
+    "v_mul_f64 {T3}, {MW}, {T3}",
+    "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
+    "s_cmp_lg_u64 s[94:95], 0",
+    "s_cbranch_scc1 L_er_soft_%=",
+    "L_er_acc_%=:",
+    "v_fmac_f64_e32 %[ax], {DX}, {T3}",
+    "v_fmac_f64_e32 %[ay], {DY}, {T3}",
+    "v_fmac_f64_e32 %[az], {DZ}, {T3}",
+    "s_branch L_er_top_%=",
+    # ---- rare: a pair possibly inside the softening radius (forcetree.c:1415-1417, ngravs.c:420-434)
+    "L_er_soft_%=:",
+    "v_mul_i32_i24_e32 {T1LO}, 0xffffffe1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 31 j + 272",
+    "v_add_u32_e32 {T1LO}, {A}, {T1LO}",
+    "ds_read_u8 {T1LO}, {T1LO} offset:272",
+    "s_waitcnt lgkmcnt(0)",
+    "v_lshl_add_u32 {T1LO}, {T1LO}, 3, %[etab]",
+    "@\"ds_read_b64 {TE}, {T1LO} offset:\" FSTOFF \"\\n\"".replace("{TE}", REGS["TE"]).replace("{T1LO}", REGS["T1LO"]) + " ;; softening length of the source's type",
+    "s_waitcnt lgkmcnt(0)",
+    "v_max_f64 {TE}, {TE}, %[hT]                     ;; h = max(target, source)",
+    "v_rcp_f64_e32 {TT}, {TE}",
+    "v_cmp_lt_f64_e64 s[94:95], {RR}, {TE}           ;; soft = r < h",
+    "v_fma_f64 {T1}, -{TE}, {TT}, 1.0                ;; 1/h: two Newton steps",
+    "v_fma_f64 {TT}, {TT}, {T1}, {TT}",
+    "v_fma_f64 {T1}, -{TE}, {TT}, 1.0",
+    "v_fma_f64 {TT}, {TT}, {T1}, {TT}                ;; h_inv",
+    "v_mul_f64 {RI}, {TE}, {RI}                      ;; 1/u = h/r",
+    "v_mul_f64 {T1}, {RR}, {TT}                      ;; u = r/h",
+    "v_mul_f64 {T2}, {T1}, {T1}                      ;; u^2",
+    "v_ldexp_f64 {TE}, {T1}, 5                       ;; 32 u",
+] + smov(90, 38.4) + [
+    "v_add_f64 {TE}, {TE}, -s[90:91]",
+] + smov(92, 10.666666666667) + [
+    "v_fma_f64 {TE}, {T2}, {TE}, s[92:93]            ;; u < 1/2: 10.67 + u^2 (32 u - 38.4)",
+    "v_mul_f64 {RR}, {T2}, {T1}                      ;; u^3 (r is no longer needed)",
+    "v_mul_f64 {T2}, {T2}, s[90:91]                  ;; 38.4 u^2",
+] + smov(90, 21.333333333333) + [
+    "v_add_f64 {T2}, {T2}, s[90:91]                  ;; 21.33 + 38.4 u^2",
+] + smov(90, -48.0) + [
+    "v_fma_f64 {T2}, {T1}, s[90:91], {T2}            ;; - 48 u",
+    "v_fma_f64 {T2}, -{RR}, s[92:93], {T2}           ;; - 10.67 u^3",
+    "v_mul_f64 {RR}, {RI}, {RI}",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; 1/u^3",
+] + smov(90, 0.066666666667) + [
+    "v_fma_f64 {T2}, -{RR}, s[90:91], {T2}           ;; - 0.0667 / u^3",
+    "v_cmp_gt_f64_e32 vcc, 0.5, {T1}                 ;; u < 1/2",
+    "v_cndmask_b32_e32 {T2LO}, {T2LO}, {TELO}, vcc",
+    "v_cndmask_b32_e32 {T2HI}, {T2HI}, {TEHI}, vcc",
+    "v_mul_f64 {TE}, %[cS], {MW}                     ;; cS m h_inv^3 v",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {T2}",
+    "v_cndmask_b32_e64 {T3LO}, {T3LO}, {TELO}, s[94:95]",
+    "v_cndmask_b32_e64 {T3HI}, {T3HI}, {TEHI}, s[94:95]",
+    "s_branch L_er_acc_%=",
+    "L_er_done_%=:",
+]
+
+# ---- cull --------------------------------------------------------------------------------------------------------------------
+CULL_WRAP = [
+    "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
+    "v_mul_f64 {B1}, {EY}, %[invbox]",
+    "v_mul_f64 {B2}, {EZ}, %[invbox]",
+    "v_rndne_f64_e32 {B0}, {B0}",
+    "v_rndne_f64_e32 {B1}, {B1}",
+    "v_rndne_f64_e32 {B2}, {B2}",
+    "v_fma_f64 {EX}, -{B0}, %[box], {EX}",
+    "v_fma_f64 {EY}, -{B1}, %[box], {EY}",
+    "v_fma_f64 {EZ}, -{B2}, %[box], {EZ}",
+]
+CULL = [
+    "v_add_f64 {EX}, %[rx], -%[bcx]",
+    "v_add_f64 {EY}, %[ry], -%[bcy]",
+    "v_add_f64 {EZ}, %[rz], -%[bcz]",
+    "@WRAPSEG",
+    "v_add_f64 {B0}, |{EX}|, -%[bhx]                 ;; a source farther than the cut from the whole box ...",
+    "v_add_f64 {B1}, |{EY}|, -%[bhy]",
+    "v_add_f64 {B2}, |{EZ}|, -%[bhz]",
+    "v_max_f64 {B0}, {B0}, 0",
+    "v_max_f64 {B1}, {B1}, 0",
+    "v_max_f64 {B2}, {B2}, 0",
+    "v_mul_f64 {B0}, {B0}, {B0}",
+    "v_fma_f64 {B0}, {B1}, {B1}, {B0}",
+    "v_fma_f64 {B0}, {B2}, {B2}, {B0}",
+    "v_cmp_gt_f64_e32 vcc, %[reach2], {B0}           ;; ... contributes to no target",
+    "v_cmp_neq_f64_e64 s[90:91], 0, %[rw]            ;; nor does a massless one (empty species of a node)",
+    "s_and_b64 s[90:91], s[90:91], vcc",
+    "s_bcnt1_i32_b64 %[cnt], s[90:91]",
+    "v_mbcnt_lo_u32_b32 {L}, s90, 0",
+    "v_mbcnt_hi_u32_b32 {L}, s91, {L}",
+    "v_add_u32_e32 {L}, %[wrpos], {L}                ;; position among the waiting entries",
+    "s_and_saveexec_b64 s[92:93], s[90:91]",
+    "v_cmp_gt_u32_e32 vcc, 32, {L}                   ;; (vcc is a scalar operand too: the slots go through VGPRs)",
+    "v_mov_b32_e32 {SQ}, %[q0]",
+    "v_mov_b32_e32 {SQ2}, %[q1]",
+    "v_cndmask_b32_e32 {SQ}, {SQ2}, {SQ}, vcc",
+    "v_cmp_gt_u32_e32 vcc, 64, {L}",
+    "v_mov_b32_e32 {SQ2}, %[q2]",
+    "v_cndmask_b32_e32 {SQ}, {SQ2}, {SQ}, vcc",
+    "v_and_b32_e32 {EA}, 31, {L}",
+    "v_lshl_add_u32 {EA}, {EA}, 5, {SQ}",
+    "ds_write_b128 {EA}, {EXY} offset:336",
+    "ds_write_b64 {EA}, {EZ} offset:352",
+    "ds_write_b64 {EA}, %[rw] offset:360",
+    "s_mov_b64 exec, s[92:93]",
+]
+
+
+def main():
+    hdr = ("// eval_asm.inc -- generated by tools/gen_eval_asm.py (named registers -> numbers); do not edit by hand.\n"
+           "// The gfx950 assembly blocks of k_eval_ring (kernels_eval.hip): temporaries v[104:127], s[90:95] (clobbers).\n\n")
+    out = [hdr]
+    out.append("#define ER_FST_OFF_ET \"16640\"   /* fsT behind the exp(-ym r_bin) table: NTAB * 8 + 32 * 8 */\n#define ER_FST_OFF_NOET \"256\"\n")
+    out.append(macro("ER_YUK_ET", YUK_ET))
+    out.append(macro("ER_NOYUK", NOYUK))
+    out.append(macro("ER_TRIP_ASM", TRIP, "(YUKSEG, FSTOFF)"))
+    out.append(clobbers("ER_TRIP_CLOBBERS", range(104, 128), range(90, 96)))
+    out.append(macro("ER_CULL_WRAP", CULL_WRAP))
+    out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
+    out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
+    with open(OUT, "w") as f:
+        f.write("\n".join(out))
+    print("wrote", OUT)
+
+
+main()
