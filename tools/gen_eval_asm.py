@@ -209,6 +209,217 @@ TRIP = [
     "L_er_done_%=:",
 ]
 
+# ---- trip loop, two entries per trip (ER_TRIP2_ASM) --------------------------------------------------------------------------------
+# A wave at 4 waves per SIMD spends most of its time waiting on its own dependent chain (LDS round trips, v_rsq_f64, ~35 dependent
+# fp64 instructions per entry): measured 69.6 / 77.8 / 98.5 ms with 16 / 12 / 8 waves per CU.  Two entries per trip as two
+# interleaved instruction streams (a, b) halve that chain per entry.  Stream b takes the lane's NEXT bit after stream a's cursor
+# update, so it may come from the next block: no slot is lost to pairing.
+def stream_regs(s):
+    base = 104 if s == "a" else 80
+    r = {}
+    names = {"DX": 0, "DY": 2, "DZ": 4, "MW": 6, "R2": 8, "TT": 8, "RI": 10, "RR": 12, "T1": 14, "T2": 16, "T3": 18, "TE": 20}
+    for k, o in names.items():
+        r[k] = pair(base + o)
+        r[k + "LO"] = "v%d" % (base + o)
+        r[k + "HI"] = "v%d" % (base + o + 1)
+    r["E0"] = "v[%d:%d]" % (base, base + 3)
+    r["E1"] = "v[%d:%d]" % (base + 4, base + 7)
+    r["I1"], r["I2"] = "v%d" % (base + 8), "v%d" % (base + 9)
+    r["J"], r["A"] = "v%d" % (base + 22), "v%d" % (base + 23)
+    r["ACT"] = "s[90:91]" if s == "a" else "s[88:89]"
+    r["SOFT"] = "s[94:95]" if s == "a" else "s[86:87]"
+    r["S"] = s
+    return r
+
+
+def fill(lines, r):
+    out = []
+    for l in lines:
+        code, sep, comment = l.partition(";;")
+        code = re.sub(r"\{(\w+)\}", lambda m: r[m.group(1)], code)
+        out.append(code + (sep + comment if sep else ""))
+    return out
+
+
+def zipl(a, b):
+    out = []
+    for i in range(max(len(a), len(b))):
+        if i < len(a):
+            out.append(a[i])
+        if i < len(b):
+            out.append(b[i])
+    return out
+
+
+T2_FETCH = [
+    "v_ffbl_b32_e32 {J}, %[m]                        ;; -1 for an empty mask: the NULL entry",
+    "v_add_co_u32_e64 {I1}, {ACT}, %[m], -1          ;; carry <=> m != 0: the lanes with a real entry",
+    "v_lshl_add_u32 {A}, {J}, 5, %[q]",
+    "ds_read_b128 {E0}, {A} offset:336",
+    "ds_read_b128 {E1}, {A} offset:352",
+    "v_and_b32_e32 %[m], {I1}, %[m]",
+    "v_cmp_eq_u32_e32 vcc, 0, %[m]",
+    "s_and_saveexec_b64 s[92:93], vcc                ;; lanes whose block is used up follow the link",
+    "v_add_u32_e32 {I1}, %[q], %[lane4]",
+    "ds_read_b32 %[q], %[q] offset:256",
+    "ds_read_b32 %[m], {I1}",
+    "s_mov_b64 exec, s[92:93]",
+]
+T2_S1 = [
+    "v_add_f64 {DX}, {DX}, -%[tpx]",
+    "v_add_f64 {DY}, {DY}, -%[tpy]",
+    "v_add_f64 {DZ}, {DZ}, -%[tpz]",
+    "v_mul_f64 {R2}, {DY}, {DY}",
+    "v_fmac_f64_e32 {R2}, {DX}, {DX}",
+    "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
+    "v_cmp_ngt_f64_e32 vcc, %[reach2], {R2}          ;; !(r2 < reach2)",
+    "s_and_b64 s[92:93], vcc, {ACT}",
+    "s_cmp_eq_u64 s[92:93], 0",
+    "s_cbranch_scc1 L_er_incut{S}_%=",
+    "v_cndmask_b32_e64 {MWHI}, {MWHI}, 0, s[92:93]   ;; rare: beyond the exact cut -- no mass, not counted",
+    "v_cndmask_b32_e64 {MWLO}, {MWLO}, 0, s[92:93]",
+    "v_cndmask_b32_e64 {T1LO}, 0, 1, s[92:93]",
+    "v_sub_u32_e32 %[nint], %[nint], {T1LO}",
+    "L_er_incut{S}_%=:",
+]
+T2_S2 = [
+    "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
+    "v_rsq_f64_e32 {RI}, {RR}",
+    "v_cmp_lt_f64_e64 {SOFT}, {R2}, %[h2max]         ;; closer than the largest softening length?",
+    "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
+    "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
+    "v_mul_f64 {T2}, {RI}, 0.5",
+    "v_fma_f64 {RI}, {T2}, {T1}, {RI}                ;; 1/r",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; r",
+    "v_mul_f64 {T1}, {RR}, %[asmthfac]",
+    "v_cvt_i32_f64_e32 {I1}, {T1}                    ;; table bin (saturating conversion, then clamped); r2 is no longer needed",
+    "v_min_i32_e32 {I1}, 0x7ff, {I1}",
+]
+T2_S3_YUK = [
+    "v_fract_f64_e32 {T1}, {T1}                      ;; fb: position inside the table bin",
+    "v_lshl_add_u32 {I2}, {I1}, 3, %[etab]",
+    "ds_read_b64 {TE}, {I2}                          ;; E[bin] = exp(-ym r_bin)",
+    "v_lshl_add_u32 {I1}, {I1}, 3, %[trow]",
+    "ds_read_b64 {TT}, {I1}                          ;; short-range table",
+    "v_mul_f64 {T3}, {T1}, %[ec3]",
+    "v_add_f64 {T3}, {T3}, -%[ec2]",
+    "v_fma_f64 {T3}, {T3}, {T1}, %[ec1]",
+    "v_fma_f64 {T3}, {T3}, {T1}, -%[ec0]",
+    "v_mul_f64 {T2}, {RI}, {RI}                      ;; 1/r^2",
+    "v_fma_f64 {T3}, {T3}, {T1}, 1.0                 ;; exp(-ym (r - r_bin)), degree 4",
+]
+T2_S4_YUK = [
+    "v_mul_f64 {T3}, {TE}, {T3}                      ;; exp(-ym r)",
+    "v_mul_f64 {T3}, %[cY], {T3}",
+    "v_fma_f64 {TE}, %[ym], {RI}, {T2}               ;; ym/r + 1/r^2",
+    "v_mul_f64 {T3}, {TE}, {T3}",
+    "v_fmac_f64_e32 {T3}, %[cN], {T2}                ;; + cN/r^2",
+    "v_fma_f64 {T3}, -%[utor2wpi], {TT}, {T3}        ;; - long-range part",
+    "v_mul_f64 {T3}, {MW}, {T3}",
+    "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
+]
+T2_S3_NOYUK = [
+    "v_lshl_add_u32 {I1}, {I1}, 3, %[trow]",
+    "ds_read_b64 {TT}, {I1}",
+    "v_mul_f64 {T2}, {RI}, {RI}",
+    "v_mul_f64 {T3}, %[cN], {T2}",
+]
+T2_S4_NOYUK = [
+    "v_fma_f64 {T3}, -%[utor2wpi], {TT}, {T3}        ;; - long-range part",
+    "v_mul_f64 {T3}, {MW}, {T3}",
+    "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
+]
+T2_S5 = [
+    "s_cmp_lg_u64 {SOFT}, 0",
+    "s_cbranch_scc1 L_er_soft{S}_%=",
+    "L_er_acc{S}_%=:",
+    "v_fmac_f64_e32 %[ax], {DX}, {T3}",
+    "v_fmac_f64_e32 %[ay], {DY}, {T3}",
+    "v_fmac_f64_e32 %[az], {DZ}, {T3}",
+]
+T2_SOFT = [
+    "L_er_soft{S}_%=:",
+    "v_mul_i32_i24_e32 {T1LO}, 0xffffffe1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 31 j + 272",
+    "v_add_u32_e32 {T1LO}, {A}, {T1LO}",
+    "ds_read_u8 {T1LO}, {T1LO} offset:272",
+    "s_waitcnt lgkmcnt(0)",
+    "v_lshl_add_u32 {T1LO}, {T1LO}, 3, %[etab]",
+    "@FST {TE}, {T1LO} ;; softening length of the source's type",
+    "s_waitcnt lgkmcnt(0)",
+    "v_max_f64 {TE}, {TE}, %[hT]                     ;; h = max(target, source)",
+    "v_rcp_f64_e32 {TT}, {TE}",
+    "v_cmp_lt_f64_e64 {SOFT}, {RR}, {TE}             ;; soft = r < h",
+    "v_fma_f64 {T1}, -{TE}, {TT}, 1.0                ;; 1/h: two Newton steps",
+    "v_fma_f64 {TT}, {TT}, {T1}, {TT}",
+    "v_fma_f64 {T1}, -{TE}, {TT}, 1.0",
+    "v_fma_f64 {TT}, {TT}, {T1}, {TT}                ;; h_inv",
+    "v_mul_f64 {RI}, {TE}, {RI}                      ;; 1/u = h/r",
+    "v_mul_f64 {T1}, {RR}, {TT}                      ;; u = r/h",
+    "v_mul_f64 {T2}, {T1}, {T1}                      ;; u^2",
+    "v_ldexp_f64 {TE}, {T1}, 5                       ;; 32 u",
+] + smov(90, 38.4) + [
+    "v_add_f64 {TE}, {TE}, -s[90:91]",
+] + smov(92, 10.666666666667) + [
+    "v_fma_f64 {TE}, {T2}, {TE}, s[92:93]            ;; u < 1/2: 10.67 + u^2 (32 u - 38.4)",
+    "v_mul_f64 {RR}, {T2}, {T1}                      ;; u^3 (r is no longer needed)",
+    "v_mul_f64 {T2}, {T2}, s[90:91]                  ;; 38.4 u^2",
+] + smov(90, 21.333333333333) + [
+    "v_add_f64 {T2}, {T2}, s[90:91]                  ;; 21.33 + 38.4 u^2",
+] + smov(90, -48.0) + [
+    "v_fma_f64 {T2}, {T1}, s[90:91], {T2}            ;; - 48 u",
+    "v_fma_f64 {T2}, -{RR}, s[92:93], {T2}           ;; - 10.67 u^3",
+    "v_mul_f64 {RR}, {RI}, {RI}",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; 1/u^3",
+] + smov(90, 0.066666666667) + [
+    "v_fma_f64 {T2}, -{RR}, s[90:91], {T2}           ;; - 0.0667 / u^3",
+    "v_cmp_gt_f64_e32 vcc, 0.5, {T1}                 ;; u < 1/2",
+    "v_cndmask_b32_e32 {T2LO}, {T2LO}, {TELO}, vcc",
+    "v_cndmask_b32_e32 {T2HI}, {T2HI}, {TEHI}, vcc",
+    "v_mul_f64 {TE}, %[cS], {MW}                     ;; cS m h_inv^3 v",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {TT}",
+    "v_mul_f64 {TE}, {TE}, {T2}",
+    "v_cndmask_b32_e64 {T3LO}, {T3LO}, {TELO}, {SOFT}",
+    "v_cndmask_b32_e64 {T3HI}, {T3HI}, {TEHI}, {SOFT}",
+    "s_branch L_er_acc{S}_%=",
+]
+
+
+def trip2(yuk):
+    ra, rb = stream_regs("a"), stream_regs("b")
+    s3, s4 = (T2_S3_YUK, T2_S4_YUK) if yuk else (T2_S3_NOYUK, T2_S4_NOYUK)
+    seq = ["s_mov_b32 %[ntr], 0",
+           "L_er_top_%=:",
+           "v_cmp_eq_u32_e32 vcc, %[tail], %[q]",
+           "s_cbranch_vccz L_er_done_%=",
+           "s_add_u32 %[ntr], %[ntr], 2"]
+    seq += fill(T2_FETCH, ra)
+    seq += ["s_waitcnt lgkmcnt(0)                            ;; stream b takes the lane's NEXT bit: after the cursor update"]
+    seq += fill(T2_FETCH, rb)
+    seq += fill(T2_S1, ra)
+    seq += ["s_waitcnt lgkmcnt(0)"]
+    seq += fill(T2_S1, rb)
+    seq += zipl(fill(T2_S2, ra), fill(T2_S2, rb))
+    seq += zipl(fill(s3, ra), fill(s3, rb))
+    seq += ["s_waitcnt lgkmcnt(0)"]
+    seq += zipl(fill(s4, ra), fill(s4, rb))
+    seq += fill(T2_S5, ra) + fill(T2_S5, rb)
+    seq += ["s_branch L_er_top_%="]
+    seq += fill(T2_SOFT, ra) + fill(T2_SOFT, rb)
+    seq += ["L_er_done_%=:"]
+    # the FST splice: ds_read_b64 with the offset as a macro parameter
+    out = []
+    for l in seq:
+        if l.startswith("@FST"):
+            code, _, comment = l.partition(";;")
+            regs_ = code[len("@FST"):].strip()
+            out.append("@\"ds_read_b64 %s offset:\" FSTOFF \"\\n\" ;;%s" % (regs_, comment))
+        else:
+            out.append(l)
+    return out
+
+
 # ---- cull --------------------------------------------------------------------------------------------------------------------
 CULL_WRAP = [
     "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
@@ -268,6 +479,9 @@ def main():
     out.append(macro("ER_NOYUK", NOYUK))
     out.append(macro("ER_TRIP_ASM", TRIP, "(YUKSEG, FSTOFF)"))
     out.append(clobbers("ER_TRIP_CLOBBERS", range(104, 128), range(90, 96)))
+    out.append(macro("ER_TRIP2_YUK_ASM", trip2(True), "(FSTOFF)"))
+    out.append(macro("ER_TRIP2_NOYUK_ASM", trip2(False), "(FSTOFF)"))
+    out.append(clobbers("ER_TRIP2_CLOBBERS", range(80, 128), range(86, 96)))
     out.append(macro("ER_CULL_WRAP", CULL_WRAP))
     out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
     out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
