@@ -52,14 +52,20 @@ def step_alg_bytes(n_gravs, cells_per_particle, pm=True):
 DD_STAGES = ["extent+leaf_sums+top_tree+cut", "migration", "of_the_first:leaf_sum_passes+allreduce", "import_decision_host",
              "count/request_allgather+pack", "import_exchange+unpack", "global_top", "local_decomposition"]
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_walk_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_walk_traffic.json")
+
+
+WALK_SOURCES = ("kernels_walk.hip", "kernels_eval.hip", "eval_asm.inc", "walk_device.hpp")
 
 
 def walk_source_hash():
-    """sha256 (first 16 hex digits) of the walk kernels' source: ties a PMC profile to the code it was taken from"""
+    """sha256 (first 16 hex digits) of the walk kernels' sources: ties a PMC profile to the code it was taken from"""
     import hashlib
-    with open(os.path.join(ROOT, "gadget-2.0.7-ngravs_amd", "csrc", "kernels_walk.hip"), "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+    h = hashlib.sha256()
+    for name in WALK_SOURCES:
+        with open(os.path.join(ROOT, "gadget-2.0.7-ngravs_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def walk_traffic(args, n, world, launches):
@@ -79,32 +85,36 @@ def walk_traffic(args, n, world, launches):
     prov["profiled_kernel"] = d.get("kernel")
     prov["profiled_walk_source_sha16"] = d.get("walk_source_sha16")
     if d.get("walk_source_sha16") != prov["walk_source_sha16"]:
-        prov["status"] = "stale: kernels_walk.hip changed since the profile was taken"
+        prov["status"] = "stale: the walk kernels' sources changed since the profile was taken"
         return None, prov
     prov["status"] = "rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this workload and this source"
     return d["traffic_bytes_per_launch"] * d.get("launches_per_step", 1) / max(1, launches), prov
 
 
-def accuracy_block(pkg, eng, n, dev, samples=256):
-    """tree + PM of the timed configuration against the periodic direct sum over ALL sources (nearest image + lattice
-    correction tables: the truth gravity_forcetest() uses, forcetree.c:3428-3548) for `samples` seeded targets, on the GPU"""
+def accuracy_block(pkg, eng, n, dev, samples=256, periodic=True):
+    """The timed configuration's accelerations (tree + PM, or the tree alone for the tree-only configs) against the direct sum
+    over ALL sources for `samples` seeded targets, on the GPU: the truth gravity_forcetest() uses (gravtree_forcetest.c:28-356,
+    force_treeevaluate_direct forcetree.c:3428-3548 -- periodic: nearest image + lattice correction tables)."""
     import torch
     d_acc = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    d_pm = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    d_pm = torch.empty((n, 3), dtype=torch.float64, device=dev) if periodic else None
     d_cost = torch.empty(n, dtype=torch.float32, device=dev)
-    eng.get_accel_device(acc_ptr=d_acc.data_ptr(), pm_ptr=d_pm.data_ptr(), cost_ptr=d_cost.data_ptr())
+    eng.get_accel_device(acc_ptr=d_acc.data_ptr(), pm_ptr=d_pm.data_ptr() if periodic else None, cost_ptr=d_cost.data_ptr())
     idx = np.sort(np.random.default_rng(7).choice(n, samples, replace=False)).astype(np.int32)
     sel = torch.from_numpy(idx.astype(np.int64)).to(dev)
-    tot = (d_acc[sel] + d_pm[sel]).cpu().numpy()
+    tot = ((d_acc[sel] + d_pm[sel]) if periodic else d_acc[sel]).cpu().numpy()
     ia = float(d_cost.double().mean().item())
     del d_acc, d_pm, d_cost
     t0 = time.time()
     truth = eng.direct_sum(idx)
     e = np.linalg.norm(tot - truth, axis=1) / np.linalg.norm(truth, axis=1)
-    return {"truth": "periodic direct sum over all %d sources on the GPU (ngravs_direct_sum)" % n, "samples": int(samples),
+    return {"truth": ("periodic direct sum" if periodic else "direct sum") + " over all %d sources on the GPU (ngravs_direct_sum)" % n,
+            "samples": int(samples),
             "rms": float(np.sqrt(np.mean(e ** 2))), "median": float(np.median(e)), "p99": float(np.percentile(e, 99)),
             "max": float(e.max()), "ia_per_particle": ia, "seconds": time.time() - t0,
-            "reference_band": "reference TreePM walk at the same ErrTolForceAcc: rms 6.5e-3 ... 9.6e-3 (SURVEY.md 6)"}
+            "reference_band": ("reference TreePM walk at the same ErrTolForceAcc: rms 6.5e-3 ... 9.6e-3 (SURVEY.md 6)" if periodic else
+                               "reference tree walk at the same ErrTolForceAcc on GalaxyCollision.IC / Plummer spheres: rms 3e-3 ... 6e-3 "
+                               "(tests/test_gpu_parity.py)")}
 
 
 def make_box(pkg, n, L, n_gravs, seed):
@@ -142,50 +152,72 @@ def host_cores():
     return n
 
 
-def cpu_baseline(pkg, n_gravs, wiring, cells_per_particle):
-    """The oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload:
-    same density per PM cell, same wiring, same criterion; all host cores for the walk and PM (OpenMP),
-    serial insertion tree build as in the reference."""
+def cpu_baseline(pkg, args, cells_per_particle, gpu_ia):
+    """The oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload -- same density per PM
+    cell / same sphere / the same IC, same wiring, same criterion; all host cores for the walk and PM (OpenMP), serial insertion
+    tree build as in the reference.  Sized for 10-30 s of CPU work."""
     O = ge.load_oracle()
-    n, pmgrid, L = 1 << 19, 64, 1.0
-    while (pmgrid * 2) ** 3 <= n * cells_per_particle:
-        pmgrid *= 2
     ncores = host_cores()
-    pos, mass, ptype = make_box(pkg, n, L, n_gravs, 4242)
-    eps = L / (40 * n ** (1 / 3))
-    cfg = pkg.make_config(n_gravs=n_gravs, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
-                          type_to_grav=pkg.ic.default_type_to_grav(n_gravs), wiring=wiring)
-    tab, _ = O.shortrange_table(cfg)
+    n_gravs, wiring = args.ngravs, args.wiring
+    treeonly = args.config in ("c1", "c2")
+    L = 1.0
+    if args.config == "c1":
+        ic = pkg.ic.read_gadget_format1(os.path.join(ROOT, "tests", "golden", "GalaxyCollision.IC"))
+        pos, mass, ptype = ic["pos"], ic["mass"], ic["type"]
+        n, pmgrid = len(pos), 0
+        cfg = pkg.make_config(n_gravs=2, G=43007.1, theta=0.5, err_tol_force_acc=0.005, softening=[0, 1.0, 0.4, 1.0, 1.0, 1.0],
+                              type_to_grav=[0, 0, 1, 0, 0, 0], wiring="newton", tree_alloc_factor=0.8)
+        what = "the whole IC (%d particles)" % n
+    elif args.config == "c2":
+        n, pmgrid = 1 << args.log2n, 0
+        pos, mass, ptype = pkg.ic.plummer_sphere(n, a=1.0, seed=12345)   # the IC the GPU ran
+        cfg = pkg.make_config(n_gravs=1, periodic=0, pmgrid=0, box_size=0.0, G=1.0, theta=0.5, err_tol_force_acc=0.005,
+                              softening=[0.01] * 6, type_to_grav=pkg.ic.default_type_to_grav(1), wiring="newton")
+        what = "the same IC (2^%d-particle Plummer sphere)" % args.log2n
+    else:
+        n, pmgrid = 1 << 22, 64
+        while (pmgrid * 2) ** 3 <= n * cells_per_particle:
+            pmgrid *= 2
+        pos, mass, ptype = make_box(pkg, n, L, n_gravs, 4242)
+        eps = L / (40 * n ** (1 / 3))
+        cfg = pkg.make_config(n_gravs=n_gravs, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
+                              type_to_grav=pkg.ic.default_type_to_grav(n_gravs), wiring=wiring)
+        what = "2^22 particles, PMGRID=%d (same %g cells/particle, wiring, eps/spacing)" % (pmgrid, cells_per_particle)
+    tab = O.shortrange_table(cfg)[0] if pmgrid else None
     # untimed first pass (theta) to obtain OldAcc
     dom = O.domain_extent(pos)
     T = O.Tree(cfg, pos, mass, ptype, dom)
-    pm = O.pm_periodic(cfg, pos, mass, ptype)
+    pm = O.pm_periodic(cfg, pos, mass, ptype) if pmgrid else None
     a, _ = T.walk(table=tab, nthreads=ncores)
     _, old = O.finish(cfg, a, pm)
     T.close()
     cfg.err_tol_theta = 0.0
-    # timed steady-state step: decomposition + order, PM, tree build, walk
-    t0 = time.time()
-    dom = O.domain_extent(pos)
-    key = O.keys(pos, dom)
-    order = O.peano_order(cfg, key, ptype)
-    p2, m2, t2, o2 = pos[order], mass[order], ptype[order], old[order]
-    t1 = time.time()
-    pm = O.pm_periodic(cfg, p2, m2, t2)
-    t2_ = time.time()
-    T = O.Tree(cfg, p2, m2, t2, dom)
-    t3 = time.time()
-    a, nint = T.walk(old_acc=o2, table=tab, nthreads=ncores)
-    O.finish(cfg, a, pm)
-    t4 = time.time()
-    T.close()
-    total = t4 - t0
+    # timed steady-state step(s): decomposition + order, PM, tree build, walk
+    reps = 20 if args.config == "c1" else 1    # (the 60 000-particle IC takes 0.2 s)
+    tph = np.zeros(4)
+    for _ in range(reps):
+        t0 = time.time()
+        dom = O.domain_extent(pos)
+        key = O.keys(pos, dom)
+        order = O.peano_order(cfg, key, ptype)
+        p2, m2, t2, o2 = pos[order], mass[order], ptype[order], old[order]
+        t1 = time.time()
+        pm = O.pm_periodic(cfg, p2, m2, t2) if pmgrid else None
+        t2_ = time.time()
+        T = O.Tree(cfg, p2, m2, t2, dom)
+        t3 = time.time()
+        a, nint = T.walk(old_acc=o2, table=tab, nthreads=ncores)
+        O.finish(cfg, a, pm)
+        t4 = time.time()
+        T.close()
+        tph += np.array([t1 - t0, t2_ - t1, t3 - t2_, t4 - t3])
+    tph /= reps
+    total = float(tph.sum())
     return {
         "value": n / total, "unit": "particle-steps/s", "cores": ncores, "kind": "port",
-        "sample": "2^19 particles, PMGRID=%d (same %g cells/particle, wiring, eps/spacing, relative criterion); "
-                  "phases s: domain+order %.2f pm %.2f build %.2f walk %.2f; ia/part %.1f; walk %.3g interactions/s/core"
-                  % (pmgrid, cells_per_particle, t1 - t0, t2_ - t1, t3 - t2_, t4 - t3, float(nint.mean()),
-                     float(nint.sum()) / (t4 - t3) / ncores),
+        "sample": "%s, relative criterion; phases s: domain+order %.2f pm %.2f build %.2f walk %.2f; reference walk %.1f interactions/particle "
+                  "(the GPU path's own: %.1f), %.3g interactions/s/core"
+                  % (what, tph[0], tph[1], tph[2], tph[3], float(nint.mean()), gpu_ia, float(nint.sum()) / tph[3] / ncores),
     }
 
 
@@ -388,7 +420,9 @@ def main():
             # split walk: the dominant kernel is the evaluation kernel, launched once per batch of groups; one launch
             # processes shard_count/launches targets on average (HIP events around every launch, inside the library)
             split = {"launches_per_step": int(ev[1]), "eval_ms_per_step": float(ev[0]), "traversal_ms_per_step": float(ev[2])}
-            kname = "k_walk_group2<..,2> (evaluation)"
+            ring = (not treeonly) and not any(kv.replace(" ", "") in ("walk_ring=0", "walk_ring=0.0") for kv in args.tune) and \
+                (args.ngravs <= 2 or True)
+            kname = "k_eval_ring (evaluation, ring pool)" if ring else "k_walk_group2<..,2> (evaluation)"
             k_ms = float(ev[0] / ev[1])
             alg = alg / ev[1]
         achieved = alg / (k_ms * 1e-3) / 1e9
@@ -421,16 +455,17 @@ def main():
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_provenance"] = walk_traffic(args, n, world, split["launches_per_step"] if split else 1)
         if args.walk == "group" and split:
-            # the kernel's own bound: fp64 VALU issue.  Every evaluated pair costs the force loop's common path (static count
-            # from the ISA of this build's profile, profiles/r02_eval_isa_mix.txt: 49 VALU + 3 extra issue slots for the
-            # quarter-rate v_rsq_f64), one wave-instruction issues in 4 cycles on a SIMD for 64 lanes, 4 SIMDs per CU
+            # the kernel's own bound: fp64 VALU issue.  Every evaluated pair costs one trip of the force loop's common path (static
+            # count from this build's assembly, csrc/eval_asm.inc ER_TRIP_ASM: 46 VALU + 3 extra issue slots for the quarter-rate
+            # v_rsq_f64; tree-only walks run k_walk_group2's loop: 49 + 3), one wave-instruction issues in 4 cycles on a SIMD for 64
+            # lanes, 4 SIMDs per CU
             pairs = st.interactions / max(1, split["launches_per_step"])
-            slots, clock_hz, simds = 52, 2.4e9, 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            slots, clock_hz, simds = (49 if ring else 52), 2.4e9, 4 * torch.cuda.get_device_properties(dev).multi_processor_count
             floor_ms = pairs * slots * 4.0 / 64.0 / (simds * clock_hz) * 1e3
             out["roofline"]["secondary"] = {"bound": "fp64 VALU issue", "floor_ms": floor_ms, "achieved_ms": k_ms, "frac": floor_ms / k_ms,
                                             "issue_slots_per_pair": slots, "pairs_per_launch": pairs, "simds": simds, "clock_ghz": clock_hz / 1e9,
                                             "note": "perfectly packed lanes, nothing but the force loop; the kernel also fetches, culls and "
-                                                    "masks its lists and idles ~31 % of its force-loop slots (DESIGN.md 5)"}
+                                                    "masks its lists, and its lanes finish their lists at different times (DESIGN.md 5)"}
         if domain:
             # rank 0's host wall clock per step: the three stages of compute_accelerations() and the part of each spent inside
             # collectives (waiting for the slowest task included); payloads of the last step
@@ -450,12 +485,12 @@ def main():
                 "top_tree": {"nodes": int(eng.info.n_topnodes), "leaves": int(eng.info.n_topleaves), "counting_rounds": int(eng.info.toptree_rounds)},
                 "decomposition_collectives": int(eng.info.collectives),
                 "decomposition_stage_ms": dict(zip(DD_STAGES, [1e3 * float(v) for v in eng.info.seconds]))}
-        if world == 1 and not treeonly and not args.no_accuracy:
-            out["accuracy"] = accuracy_block(pkg, eng, n, dev)
+        if world == 1 and not args.no_accuracy:
+            out["accuracy"] = accuracy_block(pkg, eng, n, dev, periodic=not treeonly)
         else:
             out["accuracy"] = None
-        if not args.no_cpu_baseline and world == 1 and not treeonly:
-            out["cpu_baseline"] = cpu_baseline(pkg, args.ngravs, args.wiring, cells_per_particle)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pkg, args, cells_per_particle, st.interactions / max(1, st.n_active))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -30,7 +30,7 @@ EXPORTS = [
     "ngravs_set_particles",
     "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition", "ngravs_discard_grav_pm",
     "ngravs_force_treebuild", "ngravs_gravity_tree",
-    "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats",
+    "ngravs_pmforce_periodic", "ngravs_compute_accelerations", "ngravs_get_accel", "ngravs_get_stats", "ngravs_walk_unopened",
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum", "ngravs_direct_sum_targets",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
@@ -257,6 +257,12 @@ class Engine:
     def get_accel_device(self, acc_ptr=None, pm_ptr=None, old_ptr=None, cost_ptr=None, only_active=False):
         self._check(lib().ngravs_get_accel(self._h, acc_ptr, 24, pm_ptr, 24, old_ptr, 8, cost_ptr, 4, 1, int(only_active)),
                     "ngravs_get_accel")
+
+    def walk_unopened(self):
+        """top leaves the last group walk wanted opened but used as monopoles because they were not imported (multi-task trees)"""
+        v = C.c_int64(0)
+        self._check(lib().ngravs_walk_unopened(self._h, C.byref(v)), "ngravs_walk_unopened")
+        return int(v.value)
 
     def set_opening(self, theta, err_tol_force_acc):
         self._check(lib().ngravs_set_opening(self._h, theta, err_tol_force_acc), "ngravs_set_opening")

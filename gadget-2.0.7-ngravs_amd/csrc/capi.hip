@@ -548,6 +548,8 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
       c->own_order_nlocal = -1;
       c->sort_low = 35;
       c->all_active = true;
+      c->walk_ia_ratio = 0;   // (a new particle set: the walk's unit is chosen afresh)
+      c->walk_unit_state = 4;
       c->have_particles = true;
       c->have_order = c->have_tree = c->have_pm = c->have_acc = false;
       c->top.on = false;
@@ -669,6 +671,8 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
   else
     hipLaunchKernelGGL(k_fill_u8, GRID1(n), 0, c->stream, c->in_active.p, (long long)n, (unsigned char)1);
   HIP_TRY(c, hipGetLastError());
+  c->walk_ia_ratio = 0;   // (a new particle set: the walk's unit is chosen afresh)
+  c->walk_unit_state = 4;
   c->have_particles = true;
   if(keep_tree)
     c->tree_stale = true;    // same order and topology; columns and moments are refreshed by ngravs_force_update_tree
@@ -933,7 +937,16 @@ extern "C" int ngravs_gravity_tree(ngravs_ctx *c)
       const double reach = (c->cfg.group_reach > 0 ? c->cfg.group_reach : NGRAVS_GROUP_REACH) * c->asmth;
       const double ntot = c->top.on && c->top.total_count > 0 ? c->top.total_count : (double)c->n;
       const double L = c->cfg.box_size, expect = 4.18879020478639 * reach * reach * reach * ntot / (L * L * L);
-      c->walk_ia_ratio = expect > 0 ? (h[0] / h[1]) / expect : 0.0;
+      // The figure depends on the unit and the spread the walk used (clustered 2^20 probe: 1857 / 1393 / 1079 pairs per target for
+      // units of 4 / 2 / 1 groups, 871 for 1 group of 32 targets): it is kept as the equivalent for units of four groups of 64, and
+      // only dense walks update it (a sparse active set says nothing about the next dense step).
+      const bool dense = c->walk_ntargets < 0 || c->walk_dense_tlist;
+      if(expect > 0 && dense)
+        {
+          const double f_sg = c->walk_sg >= 4 ? 1.0 : (c->walk_sg >= 2 ? 1857.0 / 1393.0 : 1857.0 / 1079.0);
+          const double f_s = c->walk_spread >= 2 ? 1079.0 / 871.0 : 1.0;
+          c->walk_ia_ratio = (h[0] / h[1]) / expect * f_sg * f_s;
+        }
     }
   if(c->shard_count > 0 && c->extent_override)   // the work weights only matter to a multi-task domain cut
     hipLaunchKernelGGL(k_cost_update, GRID1(c->shard_count), 0, c->stream, c->s_idx.p, c->s_active.p, c->r_nint.p,
@@ -1097,6 +1110,14 @@ extern "C" int ngravs_get_stats(ngravs_ctx *c, ngravs_stats_t *out)
   if(!c || !out)
     return NGRAVS_ERR_ARG;
   *out = c->stats;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_walk_unopened(ngravs_ctx *c, int64_t *count)
+{
+  if(!c || !count)
+    return NGRAVS_ERR_ARG;
+  *count = (int64_t)c->walk_unopened;
   return NGRAVS_OK;
 }
 

@@ -241,6 +241,8 @@ struct ngravs_ctx
   bool walk_dense_tlist = false;  // ... and that list is the own rows of a multi-task working set, nearly all of them active
   int walk_spread = 0;        // > 1: every group of 64 targets is walked as `spread` sub-groups by the fused kernel
   int walk_sg = 1;            // split walk: groups per traversal unit (shared item lists) of the last launch
+  long long walk_unopened = 0;   // top leaves the last group walk wanted opened but had to use as monopoles (not imported)
+  int walk_unit_state = 4;    // groups per traversal unit the TreePM walk is in (4, 2 or 1): changed with hysteresis on walk_ia_ratio
   double walk_ia_ratio = 0;   // pairs per target of the last TreePM group walk / what a uniform box of the same mean density gives
                               // (0: no such walk yet): > 1 in clustered sets, where smaller traversal units accept more cells
   bool all_active = true;     // the caller passed no active flags

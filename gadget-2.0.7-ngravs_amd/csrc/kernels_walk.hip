@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
                                                      const unsigned char *__restrict__ s_active,
                                                      const double *__restrict__ table, WalkParams wp, LawIds li,
                                                      long long t_first, long long t_count,
-                                                     double *__restrict__ r_acc, int *__restrict__ r_nint)
+                                                     double *__restrict__ r_acc, int *__restrict__ r_nint, int *__restrict__ err_flag)
 {
   __shared__ int st_node[4][MAX_LEVELS + 2], st_slot[4][MAX_LEVELS + 2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -419,6 +419,10 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
     const bool wave_open = __any(open ? 1 : 0) != 0;
     if(wave_open && takes_part && !open)
       lane_skip = sp + 1;   // the node goes onto the stack at depth sp + 1: this lane is done with everything below it
+    // a top leaf whose particles were not imported has no children: its mass would drop out of the force.  The import decision
+    // covers what the criterion in force at the decomposition opens; the walk must not run with another one (walk_run reports it)
+    if(wave_open && (fl & FLAG_PSEUDO) && threadIdx.x % WAVE == 0)
+      atomicOr(err_flag, 4);
     return wave_open;
   };
 
@@ -1585,6 +1589,7 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
           int dec = 0;
           int first = 0, count = 0;
           unsigned massmask = 0;
+          bool pseudo_hit = false;
           int4 ch_lo = {-1, -1, -1, -1}, ch_hi = {-1, -1, -1, -1};
           if(my >= 0)
             {
@@ -1661,6 +1666,16 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       // for a one-target box exactly the reference's test
                       if(!open && hT_min < hs_node && r2far < hs_node * hs_node && ((fl >> 5) & 1))
                         open = true;
+                      // A top leaf whose particles were not imported (FLAG_PSEUDO: global monopoles, no children) cannot be opened.
+                      // The import decision covers every node a TARGET may open under the criterion in force at the decomposition; the
+                      // box of a group that spans several top leaves can come closer to a node than any of their boxes, and a host may
+                      // have changed the criterion since.  Such a node is used as a monopole (it used to drop out of the force) and
+                      // counted: ngravs_walk_unopened().
+                      if(open && (fl & FLAG_PSEUDO))
+                        {
+                          open = false;
+                          pseudo_hit = true;
+                        }
                       if(open)
                         dec = ((fl & FLAG_BUCKET) || (count <= wp.nleaf && !(fl & FLAG_PARTIAL))) ? 3 : 2;
                       else
@@ -1668,6 +1683,11 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                     }
                 }
             }
+          {
+            const unsigned long long ph_ = __ballot(pseudo_hit ? 1 : 0);
+            if(ph_ != 0ull && lane == 0)
+              atomicAdd(&counter[4], __popcll(ph_));
+          }
           if(dec == 2)
             {
               const int4 *cp = reinterpret_cast<const int4 *>(tv.child + 8 * (long long)my);
@@ -2275,7 +2295,7 @@ template <int NG, bool PM, bool LATT> static void launch_strict(ngravs_ctx *c, c
   unsigned nb = (unsigned)((ngroups + 3) / 4);
   hipLaunchKernelGGL((k_walk_strict<NG, PM, LATT>), dim3(nb), dim3(256), 0, c->stream, tree_view(c), c->s_pm.p, c->s_type.p,
                      c->s_oldacc.p, c->s_active.p, LATT ? c->lat.p : c->table.p, wp, li, (long long)c->shard_first,
-                     (long long)c->shard_count, c->r_acc.p, c->r_nint.p);
+                     (long long)c->shard_count, c->r_acc.p, c->r_nint.p, c->walk_counters.p + 1);
 }
 
 // targets of the group walk: all particles of the shard, or the compacted active ones (walk_select_targets)
@@ -2392,10 +2412,24 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
   // holds in the cut sphere (every source inside the sphere a particle: the uniform regime).  A smaller unit has a smaller box,
   // accepts more cells as monopoles, and wins back more than its longer lists cost (2^20 particles, 60 % of them in one clump:
   // 1857 / 1393 / 1079 pairs per target and 8.0 / 7.2 / 5.2 ms for units of 4 / 2 / 1 groups)
-  if(SG == 4 && c->walk_ia_ratio > 2.0)
-    SG = 1;
-  else if(SG == 4 && c->walk_ia_ratio > 1.4)
-    SG = 2;
+  // (walk_ia_ratio is normalised to units of four groups; the unit only changes when the ratio leaves a band around the threshold, so
+  // that a set near one does not flip from step to step: down at 1.4 / 2.0, up again below 1.2 / 1.7)
+  if(SG == 4)
+    {
+      const double r = c->walk_ia_ratio;
+      int st = c->walk_unit_state;
+      if(r > 0)
+        {
+          if(st == 4)
+            st = r > 2.0 ? 1 : (r > 1.4 ? 2 : 4);
+          else if(st == 2)
+            st = r > 2.0 ? 1 : (r < 1.2 ? 4 : 2);
+          else
+            st = r < 1.2 ? 4 : (r < 1.7 ? 2 : 1);
+        }
+      c->walk_unit_state = st;
+      SG = st;
+    }
   if(c->tune.walk_sg >= 1)
     SG = c->tune.walk_sg;
   if(SG != c->walk_sg)
@@ -2635,7 +2669,12 @@ int walk_run(ngravs_ctx *c)
       }
   };
   if(strict)
-    strict_launch();
+    {
+      if(c->walk_counters.ensure(32))
+        return NGRAVS_ERR_NOMEM;
+      HIP_TRY(c, hipMemsetAsync(c->walk_counters.p, 0, sizeof(int) * 32, c->stream));
+      strict_launch();
+    }
   else
     {
       // sparse active sets: 64 compacted targets span a box much wider than the short-range reach, so the conservative
@@ -2654,14 +2693,39 @@ int walk_run(ngravs_ctx *c)
           if(c->walk_spread <= 1)
             c->walk_spread = 0;
         }
-      else if(c->walk_ntargets >= 0 && !c->walk_dense_tlist && c->tune.walk_spread > 1)
-        c->walk_spread = c->tune.walk_spread;   // tree-only walks: sub-groups only on request (tests: one target per wave)
+      else if(c->tune.walk_spread > 1)
+        c->walk_spread = c->tune.walk_spread;   // dense target sets: sub-groups of 64/S targets on request (a smaller box accepts more monopoles)
+      else if(c->tune.walk_spread == 0)
+        {
+          // Measured (tools/spread_sweep.sh, profiles/r04_spread_sweep.json): two lanes per target pay in a strongly clustered TreePM
+          // set once its units are single groups (2^20 particles, 60 % in one clump: 1079 -> 871 pairs per target, 5.15 -> 4.67 ms);
+          // a tree-only set with too few groups to fill the device (GalaxyCollision.IC: 938 groups of 64 for 4096 waves) walks faster
+          // with 4 lanes per target (4.2 -> 1.9 ms); a large one does not (4 M Plummer sphere: 12.5 / 14.8 / 19.5 ms for S = 1 / 2 / 4).
+          const long long g64 = (walk_tcount(c) + WAVE - 1) / WAVE;
+          if(pm && c->walk_unit_state == 1 && c->walk_ia_ratio > 2.0)
+            c->walk_spread = 2;
+          else if(!pm && !latt && g64 > 0 && g64 < 2048)
+            c->walk_spread = g64 < 1024 ? 4 : 2;
+        }
       rc = group_launch(true, nullptr, 0);
     }
   if(rc != NGRAVS_OK)
     return rc;
   HIP_TRY(c, hipEventRecord(c->evk1, c->stream));
   HIP_TRY(c, hipGetLastError());
+  c->walk_unopened = 0;
+  if(strict && c->top.on)
+    {
+      int flag = 0;
+      HIP_TRY(c, hipMemcpyAsync(&flag, c->walk_counters.p + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if(flag & 4)
+        {
+          ngravs_report(c, NGRAVS_ERR_STATE, "the walk opens a top-tree leaf whose particles were not imported: the opening criterion or OldAcc "
+                                             "changed since the decomposition (decompose again before this walk)");
+          return NGRAVS_ERR_STATE;
+        }
+    }
   if(!strict)
     {
       int flag = 0;
@@ -2716,6 +2780,11 @@ int walk_run(ngravs_ctx *c)
           c->stats.reserved[6] += tt;
         }
       c->stats.reserved[5] = c->walk_batches;
+      {
+        int unop = 0;
+        HIP_TRY(c, hipMemcpy(&unop, c->walk_counters.p + 4, sizeof(int), hipMemcpyDeviceToHost));
+        c->walk_unopened = unop;
+      }
       if(flag)
         {
           ngravs_report(c, NGRAVS_ERR_TREE, "group walk: pending-node LIFO overflow");

@@ -206,7 +206,11 @@ static void ensure_ctx(void)
 #ifdef BAM_EPSILON
   cfg.bam_epsilon = BAM_EPSILON;
 #endif
+#ifdef NGRAVS_GLUE_WALK_STRICT
+  cfg.walk_mode = NGRAVS_WALK_STRICT;	/* the reference walk, target by target (tests: several tasks must reproduce one task's forces and counts) */
+#else
   cfg.walk_mode = NGRAVS_WALK_GROUP;
+#endif
   /* the library always sees its working set (own particles + halo copies) as one task; the tasks are joined by Comm */
   cfg.rank = 0;
   cfg.world_size = 1;
@@ -256,6 +260,7 @@ static void ensure_ctx(void)
 }
 
 /* hand P[0..NumPart) over: the fields of SURVEY.md 8(b), with the byte strides of struct particle_data */
+static int PushGravPM = 0;	/* hand P[].GravPM over even on a PM step (decompose_several_tasks(1): it has been computed already) */
 static void push_particles(int keep_tree)
 {
   ngravs_particles_t p;
@@ -278,7 +283,7 @@ static void push_particles(int keep_tree)
   p.grav_cost = &P[0].GravCost;	/* the work weight of the next domain cut (domain.c:859-862) */
   p.grav_cost_stride = sizeof(struct particle_data);
 #ifdef PMGRID
-  if(All.PM_Ti_endstep != All.Ti_Current)	/* P[].GravPM of the last PM step enters OldAcc on non-PM steps (gravtree.c:318-330) */
+  if(All.PM_Ti_endstep != All.Ti_Current || PushGravPM)	/* P[].GravPM of the last PM step enters OldAcc on non-PM steps (gravtree.c:318-330) */
     {
       p.grav_pm = &P[0].GravPM[0];
       p.grav_pm_stride = sizeof(struct particle_data);
@@ -357,6 +362,37 @@ static void exchange_particles(const int32_t *dest)
   free(scount);
 }
 
+/* Several tasks: top tree + cut from all-reduced leaf sums, migration of whole particle_data records, import of the top leaves
+ * this task's targets may open (domain_decompose domain.c:164-330; force_exchange_pseudodata forcetree.c:766-850; what replaces
+ * the export / import loop of gravtree.c:112-285).  The import is decided for the opening criterion and the OldAcc in force NOW:
+ * DdUseTheta remembers which.  again != 0: P[] has already been handed over for this step and GravPM computed (the second
+ * gravity_tree() of a first step, see there). */
+static int DdUseTheta = -1;
+static void decompose_several_tasks(int again)
+{
+  ngravs_dd_plan plan;
+  ngravs_dd_info info;
+  int32_t *dest;
+  if(again)
+    {
+      PushGravPM = 1;
+      push_particles(0);
+    }
+  must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
+  must(ngravs_host_domain_owners(Ctx, &Comm, 0, All.PartAllocFactor, &plan, &info), 1058);
+  dest = malloc(sizeof(int32_t) * (NumPart > 0 ? NumPart : 1));
+  must(ngravs_dd_get_dest(Ctx, plan.leaf_owner, dest), 1059);
+  exchange_particles(dest);
+  free(dest);
+  push_particles(0);		/* the migrated P[]: its order is the order of the library's results */
+  PushGravPM = 0;
+  must(ngravs_host_domain_halo(Ctx, &Comm, &plan, &info), 1060);
+  ngravs_host_plan_free(&plan);
+  DdUseTheta = All.ErrTolTheta != 0;
+  if(ThisTask == 0)
+    printf("work-load balance=%g   memory-balance=%g\n", info.work_balance, info.memory_balance);	/* domain.c:257-258 */
+}
+
 /* proto.h:36 */
 void domain_Decomposition(void)
 {
@@ -380,21 +416,7 @@ void domain_Decomposition(void)
       if(NTask == 1)
 	must(ngravs_domain_decomposition(Ctx), 1057);
       else
-	{
-	  ngravs_dd_plan plan;
-	  ngravs_dd_info info;
-	  int32_t *dest;
-	  must(ngravs_host_domain_owners(Ctx, &Comm, 0, All.PartAllocFactor, &plan, &info), 1058);
-	  dest = malloc(sizeof(int32_t) * (NumPart > 0 ? NumPart : 1));
-	  must(ngravs_dd_get_dest(Ctx, plan.leaf_owner, dest), 1059);
-	  exchange_particles(dest);
-	  free(dest);
-	  push_particles(0);	/* the migrated P[]: its order is the order of the library's results */
-	  must(ngravs_host_domain_halo(Ctx, &Comm, &plan, &info), 1060);
-	  ngravs_host_plan_free(&plan);
-	  if(ThisTask == 0)
-	    printf("work-load balance=%g   memory-balance=%g\n", info.work_balance, info.memory_balance);	/* domain.c:257-258 */
-	}
+	decompose_several_tasks(0);
       /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac are four separate globals (allvars.c:44-47) */
       must(ngravs_get_domain(Ctx, d), 1061);
       DomainCorner[0] = d[0];
@@ -531,6 +553,13 @@ void gravity_tree(void)
   ensure_ctx();
   if(All.ComovingIntegrationOn)	/* gravtree.c:50-51: new softening lengths for the new scale factor */
     set_softenings();
+  /* The first step calls gravity_tree() twice (accel.c:44-52): with the Barnes-Hut criterion and OldAcc = 0, then with the relative
+   * criterion and the OldAcc the first call wrote.  The reference's export / import follows whatever the walk opens; here the
+   * top leaves a task imports were chosen at the decomposition, for the first criterion.  Under the second one a walk can open
+   * leaves that were not asked for (their mass would be missing from the force; the library refuses such a walk in its reference
+   * mode and counts the leaves in the production mode): the import is decided again, for the criterion this call walks with. */
+  if(NTask > 1 && DdUseTheta >= 0 && DdUseTheta != (All.ErrTolTheta != 0))
+    decompose_several_tasks(1);
   must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
   /* the walk reads P[].OldAcc as it is NOW (gravtree.c:334-335): the first step calls gravity_tree() twice (accel.c:44-52), the
    * second time with the OldAcc the first call has just written -- the hand-over of the decomposition does not have it yet */

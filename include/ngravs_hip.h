@@ -250,6 +250,12 @@ int ngravs_get_accel(ngravs_ctx *ctx, double *grav_accel, int64_t accel_stride,
                      double *grav_pm, int64_t pm_stride, double *old_acc, int64_t old_acc_stride,
                      float *grav_cost, int64_t cost_stride, int on_device, int only_active);
 int ngravs_get_stats(ngravs_ctx *ctx, ngravs_stats_t *out);
+/* Multi-task trees: top-tree leaves the last GROUP walk wanted to open although their particles were not imported (the box of a
+ * group that spans several top leaves can come closer to a node than any of the leaves' boxes the import decision tested, or the
+ * host changed the opening criterion after the decomposition).  Such a leaf is used as a monopole and counted here (0 in a single
+ * task).  The reference walk (NGRAVS_WALK_STRICT) does not substitute: ngravs_gravity_tree() returns NGRAVS_ERR_STATE instead.
+ * Replaces nothing in the reference: its export / import loop (gravtree.c:112-285) follows the walk wherever it goes. */
+int ngravs_walk_unopened(ngravs_ctx *ctx, int64_t *count);
 /* DomainCorner[3], DomainCenter[3], DomainLen, DomainFac (domain.c:916-923) -> out[8] */
 int ngravs_get_domain(ngravs_ctx *ctx, double out[8]);
 /* 18-bit reference Peano-Hilbert keys in original particle order (domain.c:938-944). */

@@ -30,7 +30,12 @@ def main():
     out = {"particles": n, "pmgrid": pmgrid, "clump": "60 % of the particles in a Gaussian of sigma 0.05 L"}
     for name, mode, tune in (("reference_walk", pkg.WALK_STRICT, {}), ("production_default", pkg.WALK_GROUP, {}),
                              ("production_sg4", pkg.WALK_GROUP, {"walk_sg": 4}), ("production_sg2", pkg.WALK_GROUP, {"walk_sg": 2}),
-                             ("production_sg1", pkg.WALK_GROUP, {"walk_sg": 1})):
+                             ("production_sg1", pkg.WALK_GROUP, {"walk_sg": 1}),
+                             ("production_sg1_spread2", pkg.WALK_GROUP, {"walk_sg": 1, "walk_spread": 2}),
+                             ("production_sg1_spread4", pkg.WALK_GROUP, {"walk_sg": 1, "walk_spread": 4}),
+                             ("production_sg2_spread2", pkg.WALK_GROUP, {"walk_sg": 2, "walk_spread": 2}),
+                             ("production_sg4_spread2", pkg.WALK_GROUP, {"walk_sg": 4, "walk_spread": 2}),
+                             ("production_sg4_spread4", pkg.WALK_GROUP, {"walk_sg": 4, "walk_spread": 4})):
         cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=[eps] * 6,
                               type_to_grav=pkg.ic.default_type_to_grav(ng), wiring="c4", walk_mode=mode)
         eng = pkg.Engine(cfg)

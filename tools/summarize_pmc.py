@@ -63,9 +63,13 @@ def main():
         fb, wb = timed_mean(traffic.get("FETCH_SIZE", [0])), timed_mean(traffic.get("WRITE_SIZE", [0]))
         with open(out_json, "w") as f:
             import hashlib
-            src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gadget-2.0.7-ngravs_amd", "csrc", "kernels_walk.hip")
-            sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
-            json.dump({"kernel": "k_walk_group2<2,true,true,true,false,2> (evaluation)", "workload": "C4 64M", "walk_source_sha16": sha,
+            csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gadget-2.0.7-ngravs_amd", "csrc")
+            h = hashlib.sha256()
+            for name in ("kernels_walk.hip", "kernels_eval.hip", "eval_asm.inc", "walk_device.hpp"):   # = bench.py WALK_SOURCES
+                h.update(open(os.path.join(csrc, name), "rb").read())
+            sha = h.hexdigest()[:16]
+            kern = sorted(k for (k, i) in per_disp if "k_eval_ring" in k or k.endswith("2>") or ", 2>" in k)
+            json.dump({"kernel": (kern[-1] if kern else "?") + " (evaluation)", "workload": "C4 64M", "walk_source_sha16": sha,
                        "launches_per_step": len(traffic.get("FETCH_SIZE", [0])) - len(traffic.get("FETCH_SIZE", [0])) // 2,
                        "fetch_bytes_reported": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
                        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean over the evaluation-kernel "
