@@ -234,11 +234,23 @@ def self_launch(ngpus):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on these hosts (RCCL across processes)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:                             # rank 0 prints the one JSON line; anything else is passed through too
-        sys.stdout.write(line)
-        sys.stdout.flush()
-    return proc.wait()
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+") as errf:
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=errf, text=True)
+        for line in proc.stdout:                         # rank 0 prints the one JSON line; anything else is passed through too
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        rc = proc.wait()
+        # the ranks' stderr: all of it when they failed (a communicator that gives up says which task, which collective and the
+        # byte counts per peer there, and ends its process with exit code 86), its tail otherwise
+        errf.seek(0)
+        lines = errf.read().splitlines()
+        if rc != 0:
+            sys.stderr.write("bench.py: the ranks ended with exit code %d; their stderr:\n" % rc)
+        for line in (lines if rc != 0 else lines[-20:]):
+            sys.stderr.write(line + "\n")
+        sys.stderr.flush()
+    return rc
 
 
 def main():

@@ -26,7 +26,7 @@ _LIB = None
 EXPORTS = [
     "ngravs_abi_version", "ngravs_build_info", "ngravs_config_default", "ngravs_create", "ngravs_destroy",
     "ngravs_set_fatal_handler", "ngravs_set_opening", "ngravs_set_walk_mode", "ngravs_set_softening", "ngravs_dd_record_bytes", "ngravs_get_config", "ngravs_set_tuning",
-    "ngravs_memcpy",
+    "ngravs_memcpy", "ngravs_device_alloc", "ngravs_device_free",
     "ngravs_set_particles",
     "ngravs_set_old_acc", "ngravs_update_particles", "ngravs_force_update_tree", "ngravs_domain_decomposition", "ngravs_discard_grav_pm",
     "ngravs_force_treebuild", "ngravs_gravity_tree",
@@ -40,7 +40,7 @@ EXPORTS = [
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
-HOST_EXPORTS = ["ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
+HOST_EXPORTS = ["ngravs_host_comm_selftest", "ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
                 "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
                 "ngravs_host_pm_seconds", "ngravs_host_toptree_init", "ngravs_host_toptree_from_children", "ngravs_host_toptree_adapt",
                 "ngravs_host_toptree_free", "ngravs_host_import_request"]

@@ -506,6 +506,27 @@ extern "C" int ngravs_memcpy(ngravs_ctx *c, void *dst, const void *src, int64_t 
   return NGRAVS_OK;
 }
 
+extern "C" int ngravs_device_alloc(ngravs_ctx *c, void **ptr, int64_t bytes)
+{
+  if(!c || !ptr || bytes < 0)
+    return NGRAVS_ERR_ARG;
+  *ptr = nullptr;
+  (void)hipSetDevice(c->cfg.device);
+  if(hipMalloc(ptr, (size_t)(bytes > 0 ? bytes : 1)) != hipSuccess)
+    return NGRAVS_ERR_NOMEM;
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_device_free(ngravs_ctx *c, void *ptr)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  if(ptr)
+    (void)hipFree(ptr);
+  return NGRAVS_OK;
+}
+
 // ---- data hand-over -----------------------------------------------------------------------------
 static int upload_column_f64(ngravs_ctx *c, const void *src, int64_t stride, int ncomp, int64_t n, int on_device, double *dst)
 {

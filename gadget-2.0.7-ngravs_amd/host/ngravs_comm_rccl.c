@@ -9,6 +9,12 @@
  * over the direct link of its two GPUs, all pairs at once.
  * Host-memory reductions / gathers (the vtable's allreduce / allgather): staged through a device scratch buffer that grows
  * on demand -- hipMemcpyAsync in, collective, hipMemcpyAsync out on the one stream, one synchronisation.
+ *
+ * No wait is unbounded: every callback waits for its stream by polling (wait_stream), looks at ncclCommGetAsyncError() while it
+ * does, and gives up after `timeout_s` seconds (default 300; ngravs_rccl_set_timeout): it then writes the task, the collective and
+ * the byte counts per peer to stderr and -- unless the host asked for an error return instead -- ends the process with exit code 86.
+ * A collective that does not complete cannot be retried in the same process (the communicator is in an unknown state); a job
+ * that hangs until an outer time limit kills it tells nobody where.
  */
 #define _POSIX_C_SOURCE 199309L
 #ifndef __HIP_PLATFORM_AMD__
@@ -18,9 +24,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 #include "ngravs_comm_rccl.h"
+#include "ngravs_comm_selftest.h"
 
 struct ngravs_rccl
 {
@@ -31,6 +39,8 @@ struct ngravs_rccl
   size_t scratch_bytes;
   int64_t calls;
   double seconds, bytes;
+  double timeout_s;       /* limit of every wait */
+  int exit_on_timeout;    /* 1 (default): a wait that runs out ends the process (exit code 86) after the message; 0: error return */
   char err[256];
 };
 
@@ -63,6 +73,72 @@ static double now_s(void)
         }                                                                               \
     }                                                                                   \
   while(0)
+
+/* ... inside an ncclGroupStart / ncclGroupEnd bracket: the group is closed before the error is returned */
+#define NCCLOK_G(r, expr)                                                               \
+  do                                                                                    \
+    {                                                                                   \
+      ncclResult_t e__ = (expr);                                                        \
+      if(e__ != ncclSuccess)                                                            \
+        {                                                                               \
+          snprintf((r)->err, sizeof((r)->err), "%s: %s", #expr, ncclGetErrorString(e__)); \
+          (void)ncclGroupEnd();                                                         \
+          return 1;                                                                     \
+        }                                                                               \
+    }                                                                                   \
+  while(0)
+
+/* Wait for the communicator's stream without blocking for ever: poll the stream, look at the communicator's asynchronous error
+ * state, give up after timeout_s.  `what` and the byte counts per peer (may be NULL) go into the message. */
+static int wait_stream(ngravs_rccl *r, const char *what, const int64_t *sbytes, const int64_t *rbytes)
+{
+  const double t0 = now_s();
+  long spins = 0;
+  for(;;)
+    {
+      hipError_t e = hipStreamQuery(r->stream);
+      if(e == hipSuccess)
+        return 0;
+      if(e != hipErrorNotReady)
+        {
+          snprintf(r->err, sizeof(r->err), "%s: hipStreamQuery: %s", what, hipGetErrorString(e));
+          return 1;
+        }
+      if((++spins & 255) == 0)
+        {
+          ncclResult_t ae = ncclSuccess;
+          double waited = now_s() - t0;
+          if(ncclCommGetAsyncError(r->comm, &ae) == ncclSuccess && ae != ncclSuccess && ae != ncclInProgress)
+            {
+              snprintf(r->err, sizeof(r->err), "%s: RCCL reports an asynchronous error: %s", what, ncclGetErrorString(ae));
+              return 1;
+            }
+          if(waited > r->timeout_s)
+            {
+              char msg[1024];
+              int n = snprintf(msg, sizeof(msg), "ngravs_rccl: task %d of %d: %s did not complete within %.0f s", r->rank, r->size, what, r->timeout_s);
+              if(sbytes && rbytes)
+                {
+                  int p;
+                  n += snprintf(msg + n, sizeof(msg) - (size_t)n, "; bytes to / from peer:");
+                  for(p = 0; p < r->size && n < (int)sizeof(msg) - 40; p++)
+                    n += snprintf(msg + n, sizeof(msg) - (size_t)n, " %d:%lld/%lld", p, (long long)sbytes[p], (long long)rbytes[p]);
+                }
+              snprintf(r->err, sizeof(r->err), "%s: no completion within %.0f s", what, r->timeout_s);
+              fprintf(stderr, "%s\n", msg);
+              fflush(stderr);
+              if(r->exit_on_timeout)
+                _exit(86);
+              return 1;
+            }
+          if(waited > 2e-4)   /* a collective of this path takes tens of microseconds: past that, stop burning the core */
+            {
+              struct timespec ts = {0, 20000};
+              (void)nanosleep(&ts, NULL);
+            }
+        }
+    }
+}
 
 static int need_scratch(ngravs_rccl *r, size_t bytes)
 {
@@ -97,7 +173,8 @@ static int rccl_allreduce_dev(void *user, void *dev, int64_t count, int dtype, i
     return 0;
   HIPOK(r, hipSetDevice(r->device));
   NCCLOK(r, ncclAllReduce(dev, dev, (size_t)count, red_type(dtype), red_op(op), r->comm, r->stream));
-  HIPOK(r, hipStreamSynchronize(r->stream));
+  if(wait_stream(r, "all-reduce (device buffer)", NULL, NULL))
+    return 1;
   account(r, t0, 8.0 * (double)count);
   return 0;
 }
@@ -116,7 +193,8 @@ static int rccl_allreduce(void *user, void *buf, int64_t count, int dtype, int o
   HIPOK(r, hipMemcpyAsync(r->scratch, buf, bytes, hipMemcpyHostToDevice, r->stream));
   NCCLOK(r, ncclAllReduce(r->scratch, r->scratch, (size_t)count, red_type(dtype), red_op(op), r->comm, r->stream));
   HIPOK(r, hipMemcpyAsync(buf, r->scratch, bytes, hipMemcpyDeviceToHost, r->stream));
-  HIPOK(r, hipStreamSynchronize(r->stream));
+  if(wait_stream(r, "all-reduce", NULL, NULL))
+    return 1;
   account(r, t0, (double)bytes);
   return 0;
 }
@@ -137,7 +215,8 @@ static int rccl_allgather(void *user, const void *send, void *recv, int64_t byte
   HIPOK(r, hipMemcpyAsync(d, send, b, hipMemcpyHostToDevice, r->stream));
   NCCLOK(r, ncclAllGather(d, d + off, b, ncclInt8, r->comm, r->stream));
   HIPOK(r, hipMemcpyAsync(recv, d + off, all, hipMemcpyDeviceToHost, r->stream));
-  HIPOK(r, hipStreamSynchronize(r->stream));
+  if(wait_stream(r, "all-gather", NULL, NULL))
+    return 1;
   account(r, t0, (double)all);
   return 0;
 }
@@ -170,16 +249,17 @@ static int rccl_alltoallv(void *user, const void *send, const int64_t *sbytes, c
           if(p == r->rank)
             continue;
           if(rbytes[p] > 0)
-            NCCLOK(r, ncclRecv((char *)recv + rdispl[p], (size_t)rbytes[p], ncclInt8, p, r->comm, r->stream));
+            NCCLOK_G(r, ncclRecv((char *)recv + rdispl[p], (size_t)rbytes[p], ncclInt8, p, r->comm, r->stream));
           if(sbytes[p] > 0)
             {
-              NCCLOK(r, ncclSend((const char *)send + sdispl[p], (size_t)sbytes[p], ncclInt8, p, r->comm, r->stream));
+              NCCLOK_G(r, ncclSend((const char *)send + sdispl[p], (size_t)sbytes[p], ncclInt8, p, r->comm, r->stream));
               moved += (double)sbytes[p];
             }
         }
       NCCLOK(r, ncclGroupEnd());
     }
-  HIPOK(r, hipStreamSynchronize(r->stream));
+  if(wait_stream(r, "all-to-all-v", sbytes, rbytes))
+    return 1;
   account(r, t0, moved);
   return 0;
 }
@@ -208,6 +288,8 @@ int ngravs_rccl_create(const char id[NGRAVS_RCCL_ID_BYTES], int rank, int size, 
   r->rank = rank;
   r->size = size;
   r->device = device;
+  r->timeout_s = 300.0;
+  r->exit_on_timeout = 1;
   memcpy(&u, id, sizeof(u));
   if(hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess)
     {
@@ -277,88 +359,67 @@ int ngravs_rccl_world(ngravs_rccl *r)
   return n;
 }
 
-/* Every collective of the vtable once, with known answers: a reduction, a gather and an all-to-all-v with unequal and empty
- * blocks (block r -> p: (r + 2 p) mod 5 words of value 64 r + p; none when (r + p) mod 7 == 3).  Collective; 0 = all as
- * expected on this task.  A host calls it once after ngravs_rccl_create() -- what it costs is three small collectives -- so
- * that a fabric or bootstrap problem shows as an error message before the first step, not as a hang inside one. */
-static int64_t st_words(int from, int to) { return (from + to) % 7 == 3 ? 0 : (from + 2 * to) % 5; }
+void ngravs_rccl_set_timeout(ngravs_rccl *r, double seconds, int exit_on_timeout)
+{
+  if(!r)
+    return;
+  if(seconds > 0)
+    r->timeout_s = seconds;
+  r->exit_on_timeout = exit_on_timeout ? 1 : 0;
+}
+
+/* Every collective of the vtable once, with known answers (include/ngravs_comm_selftest.h): reductions, a gather and an
+ * all-to-all-v with unequal and empty blocks.  Collective, and collective-SAFE: every task runs every stage whatever it finds, the
+ * verdicts are combined by a last all-reduce, all tasks return the same status (0 = all as expected everywhere).  The buffers of the
+ * all-to-all-v are filled on the communicator's own stream (a memset on the null stream could land after the receives). */
+static void *rst_alloc(void *user, size_t bytes)
+{
+  ngravs_rccl *r = user;
+  void *p = NULL;
+  if(hipSetDevice(r->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess)
+    return NULL;
+  return p;
+}
+static void rst_release(void *user, void *p)
+{
+  (void)user;
+  (void)hipFree(p);
+}
+static int rst_upload(void *user, void *dev, const void *host, size_t bytes)
+{
+  ngravs_rccl *r = user;
+  if(bytes && hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, r->stream) != hipSuccess)
+    return 1;
+  return wait_stream(r, "self test upload", NULL, NULL);
+}
+static int rst_download(void *user, void *host, const void *dev, size_t bytes)
+{
+  ngravs_rccl *r = user;
+  if(bytes && hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, r->stream) != hipSuccess)
+    return 1;
+  return wait_stream(r, "self test download", NULL, NULL);
+}
+static int rst_fill(void *user, void *dev, int byte, size_t bytes)
+{
+  ngravs_rccl *r = user;
+  if(bytes && hipMemsetAsync(dev, byte, bytes, r->stream) != hipSuccess)
+    return 1;
+  return wait_stream(r, "self test fill", NULL, NULL);
+}
 
 int ngravs_rccl_selftest(ngravs_rccl *r)
 {
-  int64_t sum[2], *hs = NULL, *hr = NULL, sb[64], sd[64], rb[64], rd[64], ns = 0, nr = 0, k;
-  unsigned char *g = NULL, mine[3];
-  void *ds = NULL, *dr = NULL;
-  int p, rc = 1;
+  ngravs_comm cm;
+  ngravs_selftest_mem mem = {rst_alloc, rst_release, rst_upload, rst_download, rst_fill, r};
+  char why[200];
+  int st;
   if(!r || r->size > 64)
     return 1;
-  sum[0] = r->rank + 1;
-  sum[1] = -(int64_t)r->rank;
-  if(rccl_allreduce(r, sum, 1, NGRAVS_T_I64, NGRAVS_OP_SUM) || rccl_allreduce(r, sum + 1, 1, NGRAVS_T_I64, NGRAVS_OP_MIN))
-    return 1;
-  if(sum[0] != (int64_t)r->size * (r->size + 1) / 2 || sum[1] != -(int64_t)(r->size - 1))
-    {
-      snprintf(r->err, sizeof(r->err), "self test: all-reduce gave %lld / %lld", (long long)sum[0], (long long)sum[1]);
-      return 1;
-    }
-  g = malloc(3 * (size_t)r->size);
-  if(!g)
-    return 1;
-  mine[0] = (unsigned char)r->rank;
-  mine[1] = (unsigned char)(r->rank ^ 0x5a);
-  mine[2] = 7;
-  if(rccl_allgather(r, mine, g, 3))
-    goto done;
-  for(p = 0; p < r->size; p++)
-    if(g[3 * p] != (unsigned char)p || g[3 * p + 1] != (unsigned char)(p ^ 0x5a) || g[3 * p + 2] != 7)
-      {
-        snprintf(r->err, sizeof(r->err), "self test: all-gather block %d is wrong", p);
-        goto done;
-      }
-  for(p = 0; p < r->size; p++)
-    {
-      sb[p] = 8 * st_words(r->rank, p);
-      rb[p] = 8 * st_words(p, r->rank);
-      sd[p] = 8 * ns;
-      rd[p] = 8 * nr;
-      ns += st_words(r->rank, p);
-      nr += st_words(p, r->rank);
-    }
-  hs = malloc(8 * (size_t)(ns + 1));
-  hr = calloc((size_t)(nr + 1), 8);
-  if(!hs || !hr || hipMalloc(&ds, 8 * (size_t)(ns + 1)) != hipSuccess || hipMalloc(&dr, 8 * (size_t)(nr + 1)) != hipSuccess)
-    goto done;
-  for(p = 0, k = 0; p < r->size; p++)
-    {
-      int64_t q;
-      for(q = 0; q < st_words(r->rank, p); q++)
-        hs[k++] = 64 * r->rank + p;
-    }
-  if(hipMemcpy(ds, hs, 8 * (size_t)ns, hipMemcpyHostToDevice) != hipSuccess || hipMemset(dr, 0xff, 8 * (size_t)(nr + 1)) != hipSuccess)
-    goto done;
-  if(rccl_alltoallv(r, ds, sb, sd, dr, rb, rd))
-    goto done;
-  if(hipMemcpy(hr, dr, 8 * (size_t)nr, hipMemcpyDeviceToHost) != hipSuccess)
-    goto done;
-  for(p = 0, k = 0; p < r->size; p++)
-    {
-      int64_t q;
-      for(q = 0; q < st_words(p, r->rank); q++)
-        if(hr[k++] != 64 * p + r->rank)
-          {
-            snprintf(r->err, sizeof(r->err), "self test: all-to-all-v block from task %d is wrong", p);
-            goto done;
-          }
-    }
-  rc = 0;
-done:
-  free(g);
-  free(hs);
-  free(hr);
-  if(ds)
-    (void)hipFree(ds);
-  if(dr)
-    (void)hipFree(dr);
-  return rc;
+  ngravs_rccl_fill(r, &cm);
+  st = ngravs_comm_selftest_run(&cm, &mem, 0, why, (int)sizeof(why));
+  if(st && why[0] && !strstr(r->err, "self test"))
+    snprintf(r->err, sizeof(r->err), "%s", why);
+  return st;
 }
 
 int ngravs_rccl_barrier(ngravs_rccl *r)

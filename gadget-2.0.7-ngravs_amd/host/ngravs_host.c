@@ -1171,6 +1171,34 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, dou
   return status_of(rc);
 }
 
+/* ---- the communicator proves itself (include/ngravs_comm_selftest.h) ------------------------------------------------------------ */
+#include "ngravs_comm_selftest.h"
+static void *st_alloc(void *user, size_t bytes)
+{
+  void *p = NULL;
+  return ngravs_device_alloc(user, &p, (int64_t)bytes) ? NULL : p;
+}
+static void st_release(void *user, void *p) { (void)ngravs_device_free(user, p); }
+static int st_upload(void *user, void *dev, const void *host, size_t bytes) { return ngravs_memcpy(user, dev, host, (int64_t)bytes, 1); }
+static int st_download(void *user, void *host, const void *dev, size_t bytes) { return ngravs_memcpy(user, host, dev, (int64_t)bytes, 2); }
+static int st_fill(void *user, void *dev, int byte, size_t bytes)
+{
+  void *h = malloc(bytes ? bytes : 1);
+  int rc;
+  if(!h)
+    return 1;
+  memset(h, byte, bytes);
+  rc = ngravs_memcpy(user, dev, h, (int64_t)bytes, 1);
+  free(h);
+  return rc;
+}
+
+int ngravs_host_comm_selftest(ngravs_ctx *ctx, const ngravs_comm *cm, int fail_stage, char *why, int why_len)
+{
+  ngravs_selftest_mem mem = {st_alloc, st_release, st_upload, st_download, st_fill, ctx};
+  return ngravs_comm_selftest_run(cm, (cm && cm->device_buffers && ctx) ? &mem : NULL, fail_stage, why, why_len);
+}
+
 /* ---- pmforce_periodic on the slab-decomposed mesh -------------------------------------------------------------------------- */
 /* per host thread (host_shim_test runs two tasks as two threads); last call: [0] deposit + bounding boxes, then per stage s:
  * [1+3s] pack, [2+3s] exchange, [3+3s] unpack */

@@ -43,9 +43,14 @@ const char *ngravs_rccl_last_error(ngravs_rccl *r);
 /* the world size RCCL itself reports (ncclCommCount) */
 int ngravs_rccl_world(ngravs_rccl *r);
 /* every callback of the vtable once with known answers (reductions, a gather, an all-to-all-v with unequal and empty blocks);
- * collective over all tasks, 0 = all as expected on this task, else ngravs_rccl_last_error() says what differed.  Call it once
- * after ngravs_rccl_create(): a bootstrap or fabric problem then shows before the first step instead of inside it. */
+ * collective over all tasks and collective-safe (include/ngravs_comm_selftest.h: every task runs every stage, all tasks return the
+ * same status); 0 = all as expected on every task, else ngravs_rccl_last_error() says what this task found.  Call it once after
+ * ngravs_rccl_create(): a bootstrap or fabric problem then shows before the first step instead of inside it. */
 int ngravs_rccl_selftest(ngravs_rccl *r);
+/* Every wait of the communicator is bounded: after `seconds` (default 300) without completion a callback writes the task, the
+ * collective and the byte counts per peer to stderr and ends the process with exit code 86 (exit_on_timeout != 0, the default: a
+ * collective that did not complete cannot be retried in the same process) or returns an error (exit_on_timeout == 0). */
+void ngravs_rccl_set_timeout(ngravs_rccl *r, double seconds, int exit_on_timeout);
 /* barrier (an all-reduce of one int) -- convenience for hosts without another communicator */
 int ngravs_rccl_barrier(ngravs_rccl *r);
 

@@ -199,6 +199,9 @@ int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
 /* Plain copies for hosts that do not link HIP themselves (a C/MPI host staging exchange buffers through host memory):
  * kind 1 = host->device, 2 = device->host, 3 = device->device.  Synchronous. */
 int ngravs_memcpy(ngravs_ctx *ctx, void *dst, const void *src, int64_t bytes, int kind);
+/* ... and device memory for such a host's own exchange buffers (hipMalloc / hipFree on the context's device) */
+int ngravs_device_alloc(ngravs_ctx *ctx, void **ptr, int64_t bytes);
+int ngravs_device_free(ngravs_ctx *ctx, void *ptr);
 
 /* ---- data hand-over ---------------------------------------------------------------------- */
 /* Replace the engine's particle set (the role of P[] + NumPart).  PERIODIC runs: positions must lie in [0, BoxSize], as they do

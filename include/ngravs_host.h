@@ -114,6 +114,12 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *comm, double l
                               ngravs_dd_info *info);
 int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *comm, const ngravs_dd_plan *plan, ngravs_dd_info *info);
 void ngravs_host_plan_free(ngravs_dd_plan *plan);
+/* Every callback of the communicator once, with known answers (include/ngravs_comm_selftest.h: collective-safe -- every task runs
+ * every stage and all tasks return the same status: 0, or bits 0-2 for the stage that gave a wrong answer on some task, bit 3 for a
+ * missing buffer).  Collective.  ctx: the context whose device holds the exchange buffers of a device_buffers communicator (may be
+ * NULL for a host-buffer communicator).  fail_stage (tests): this task pretends stage 1-3 failed.  why (may be NULL): this task's
+ * own finding.  A host calls it once after it has filled its vtable, so that a fabric problem shows before the first step. */
+int ngravs_host_comm_selftest(ngravs_ctx *ctx, const ngravs_comm *comm, int fail_stage, char *why, int why_len);
 int ngravs_host_pmforce_periodic(ngravs_ctx *ctx, const ngravs_comm *comm);
 /* host wall-clock seconds of the last ngravs_host_pmforce_periodic() of this thread: [0] brick deposit + bounding-box all-gather,
  * then for the four exchanges s = 0..3: [1+3s] pack (incl. the FFTs and the Green's function that precede it), [2+3s] the

@@ -176,3 +176,89 @@ def test_shards_partition_the_peano_order(pkg, n, ws):
         assert first % 64 == 0
         covered += count
     assert covered == n
+
+
+def _selftest_worker(rank, world, port, out_dir, fail_rank, fail_stage):
+    """a host-buffer communicator over gloo (Python callbacks in a struct ngravs_comm) through ngravs_host_comm_selftest"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import time
+    import importlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module(pkg.__name__ + ".distributed")
+    L = pkg.lib()
+    ncalls = [0]
+
+    def view(ptr, nbytes):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(int(nbytes),)) if nbytes > 0 else np.zeros(0, np.uint8)
+
+    def allreduce(user, buf, count, dtype, op):
+        ncalls[0] += 1
+        h = view(buf, 8 * count).view(np.float64 if dtype == 0 else np.int64)
+        t = torch.from_numpy(h.copy())
+        dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[op])
+        h[:] = t.numpy()
+        return 0
+
+    def allgather(user, send, recv, nbytes):
+        ncalls[0] += 1
+        t = torch.from_numpy(view(send, nbytes).copy())
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        view(recv, world * nbytes)[:] = torch.cat(outs).numpy()
+        return 0
+
+    def alltoallv(user, send, sbytes, sdispl, recv, rbytes, rdispl):
+        ncalls[0] += 1
+        sb, rb = [int(sbytes[r]) for r in range(world)], [int(rbytes[r]) for r in range(world)]
+        pad = max(1, max(sum(sb), 1))
+        mx = torch.tensor([pad], dtype=torch.int64)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        buf = torch.zeros(int(mx.item()) + 8 * world, dtype=torch.uint8)
+        hdr = torch.tensor(sb, dtype=torch.int64)
+        buf[:8 * world] = torch.from_numpy(hdr.numpy().view(np.uint8).copy())
+        buf[8 * world: 8 * world + sum(sb)] = torch.from_numpy(view(send, sum(sb)).copy())
+        outs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        out = view(recv, sum(rb))
+        at = 0
+        for r in range(world):
+            cnt = outs[r][:8 * world].numpy().view(np.int64)
+            off = int(cnt[:rank].sum())
+            out[at: at + rb[r]] = outs[r][8 * world + off: 8 * world + off + int(cnt[rank])].numpy()
+            at += rb[r]
+        return 0
+
+    cbs = (dd._ALLREDUCE(allreduce), dd._ALLGATHER(allgather), dd._ALLTOALLV(alltoallv))
+    cm = dd.Comm(rank, world, 0, 0, None, *cbs, C.cast(None, dd._ALLREDUCE))
+    L.ngravs_host_comm_selftest.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+    why = C.create_string_buffer(200)
+    t0 = time.time()
+    st = L.ngravs_host_comm_selftest(None, C.byref(cm), fail_stage if rank == fail_rank else 0, why, 200)
+    np.savez(os.path.join(out_dir, "st%d.npz" % rank), status=st, seconds=time.time() - t0, calls=ncalls[0], why=why.value.decode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_stage", [0, 1, 2, 3])
+def test_comm_selftest_is_collective_safe(pkg, have_lib, tmp_path, fail_stage):
+    """ngravs_host_comm_selftest (include/ngravs_comm_selftest.h; the same code is ngravs_rccl_selftest): three tasks over gloo, task 1
+    is made to find a wrong answer in stage `fail_stage`.  Every task must still run every collective (equal call counts: nobody
+    leaves early and lets the others wait), all three must return the SAME status -- the failing stage's bit, or 0 -- within seconds."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 31500 + (os.getpid() % 2000) + fail_stage
+    mp.spawn(_selftest_worker, args=(world, port, str(tmp_path), 1, fail_stage), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "st%d.npz" % r)) for r in range(world)]
+    want = 0 if fail_stage == 0 else 1 << (fail_stage - 1)
+    for r, d in enumerate(res):
+        print("stage %d: task %d status %d after %.2f s, %d collective callbacks, says %r" % (fail_stage, r, d["status"], d["seconds"], d["calls"], str(d["why"])))
+        assert int(d["status"]) == want
+        assert int(d["calls"]) == int(res[0]["calls"]) and float(d["seconds"]) < 20
+    if fail_stage:
+        assert "self test" in str(res[1]["why"]) and "another task" in str(res[0]["why"])
