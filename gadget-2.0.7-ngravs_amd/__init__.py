@@ -47,7 +47,7 @@ HOST_EXPORTS = ["ngravs_host_comm_selftest", "ngravs_host_toptree_borrow", "ngra
 # include/ngravs_comm_rccl.h (libngravs_rccl.so: the communicator vtable over RCCL, plain C)
 RCCL_LIB_PATH = os.path.join(_HERE, "libngravs_rccl.so")
 RCCL_EXPORTS = ["ngravs_rccl_selftest", "ngravs_rccl_unique_id", "ngravs_rccl_create", "ngravs_rccl_fill", "ngravs_rccl_destroy", "ngravs_rccl_stats",
-                "ngravs_rccl_last_error", "ngravs_rccl_world", "ngravs_rccl_barrier"]
+                "ngravs_rccl_last_error", "ngravs_rccl_world", "ngravs_rccl_barrier", "ngravs_rccl_set_timeout"]
 
 
 class NgravsError(RuntimeError):

@@ -775,7 +775,7 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
   double lo[3], hi[3], bounds[2] = {1e300, 1e300}, e[10], total = 0, wtot = 0, wmax = 0, cmax = 0, *sums = NULL, *lcount = NULL, *lwork,
          *twork = NULL, thresh, n_own;
   int32_t *owner = NULL, i;
-  int r, k, q, cw, rc = 0, W, round;
+  int r, k, q, cw, rc = 0, W, round, have_tree = 0;
   ngravs_dd_info local;
   if(!ctx || !cm || !plan || cm->size < 1 || cm->size > 64 || cm->rank < 0 || cm->rank >= cm->size)
     return NGRAVS_ERR_ARG;
@@ -799,6 +799,18 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
   if(!rc)
     rc = ngravs_dd_target_bounds(ctx, bounds);
   n_own = (double)ngravs_dd_num_local(ctx);
+  /* the top tree of the last decomposition is cloned BEFORE the first collective, so that a task that cannot (out of memory) says
+   * so through that collective's status word and all tasks return together */
+  if(!rc)
+    {
+      ngravs_toptree view;
+      rc = ngravs_host_toptree_borrow(ctx, &view);   /* the library's finished copy of the last tree: levels, coordinates, leaf numbers */
+      if(!rc && view.nnode > 0)
+        {
+          rc = tt_clone(&view, &tree);
+          have_tree = !rc;
+        }
+    }
   /* one collective for both ends of the extent (max(hi) = -min(-hi)), the bounds of the opening tests and the status */
   for(r = 0; r < 3; r++)
     {
@@ -816,7 +828,11 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
       return status_of(rcc);
   }
   if(e[8] < -0.5)
-    return rc ? status_of(rc) : NGRAVS_ERR_STATE;
+    {
+      if(have_tree)
+        ngravs_host_toptree_free(&tree);
+      return rc ? status_of(rc) : NGRAVS_ERR_STATE;
+    }
   for(r = 0; r < 3; r++)
     {
       lo[r] = e[r];
@@ -824,16 +840,11 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
     }
   plan->bounds[0] = e[6];
   plan->bounds[1] = e[7];
-  rc = ngravs_dd_set_extent(ctx, lo, hi);
-  /* the top tree of the last decomposition, or a first guess: the complete tree whose leaves a uniform filling would leave
-   * with about the threshold */
-  if(!rc)
+  rc = ngravs_dd_set_extent(ctx, lo, hi);   /* (the same numbers on every task: it fails everywhere or nowhere) */
+  /* no tree yet: a first guess, the complete tree whose leaves a uniform filling would leave with about the threshold (a few
+   * hundred bytes: the one allocation of this function whose failure is not reported through a collective) */
+  if(!rc && !have_tree)
     {
-      ngravs_toptree view;
-      rc = ngravs_host_toptree_borrow(ctx, &view);   /* the library's finished copy of the last tree: levels, coordinates, leaf numbers */
-      if(!rc && view.nnode > 0)
-        rc = tt_clone(&view, &tree);
-      else if(!rc)
         {
           /* (sized from all-reduced numbers only: a guess from the own count would give tasks with different counts different
            * trees, and the all-reduce of the leaf sums that follows different lengths) */
@@ -844,8 +855,12 @@ static int domain_owners(ngravs_ctx *ctx, const ngravs_comm *cm, double leaf_max
           rc = ngravs_host_toptree_init(&tree, lvl);
         }
     }
-  if(rc)   /* without a tree the following collective cannot even be sized: the other tasks are left waiting */
-    return status_of(rc);
+  if(rc)   /* (set_extent fails everywhere or nowhere; the first guess is the one local failure left) */
+    {
+      if(have_tree)
+        ngravs_host_toptree_free(&tree);
+      return status_of(rc);
+    }
   for(round = 0; round < 32; round++)
     {
       const int64_t want = (int64_t)tree.nleaf * cw;
