@@ -111,24 +111,34 @@ static void must(int rc, int code)
     }
 }
 
+static double CommSeconds = 0;	/* wall time inside the communicator's callbacks (All.CPU_CommSum, gravtree.c:452) */
 #ifndef NGRAVS_WITH_RCCL
 /* ---- the communicator vtable over MPI (include/ngravs_host.h); with -DNGRAVS_WITH_RCCL: include/ngravs_comm_rccl.h instead ---- */
 static int mpi_allreduce(void *user, void *buf, int64_t count, int dtype, int op)
 {
   MPI_Op o = op == NGRAVS_OP_SUM ? MPI_SUM : (op == NGRAVS_OP_MIN ? MPI_MIN : MPI_MAX);
+  const double t0 = second();
+  int rc;
   (void)user;
-  return MPI_Allreduce(MPI_IN_PLACE, buf, (int)count, dtype == NGRAVS_T_F64 ? MPI_DOUBLE : MPI_LONG_LONG, o, MPI_COMM_WORLD) != MPI_SUCCESS;
+  rc = MPI_Allreduce(MPI_IN_PLACE, buf, (int)count, dtype == NGRAVS_T_F64 ? MPI_DOUBLE : MPI_LONG_LONG, o, MPI_COMM_WORLD) != MPI_SUCCESS;
+  CommSeconds += timediff(t0, second());
+  return rc;
 }
 static int mpi_allgather(void *user, const void *send, void *recv, int64_t bytes)
 {
+  const double t0 = second();
+  int rc;
   (void)user;
-  return MPI_Allgather((void *)send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, MPI_COMM_WORLD) != MPI_SUCCESS;
+  rc = MPI_Allgather((void *)send, (int)bytes, MPI_BYTE, recv, (int)bytes, MPI_BYTE, MPI_COMM_WORLD) != MPI_SUCCESS;
+  CommSeconds += timediff(t0, second());
+  return rc;
 }
 /* blocks beyond 2 GB per peer are cut into rounds of <= 1 GB (MPI counts are int) */
 static int mpi_alltoallv(void *user, const void *send, const int64_t *sbytes, const int64_t *sdispl, void *recv,
                          const int64_t *rbytes, const int64_t *rdispl)
 {
   const int64_t chunk = 1 << 30;
+  const double t0 = second();
   int64_t off = 0, more = 1;
   int *sc = malloc(sizeof(int) * 4 * NTask), *sd = sc + NTask, *rc = sd + NTask, *rd = rc + NTask, r, err = 0;
   (void)user;
@@ -160,6 +170,7 @@ static int mpi_alltoallv(void *user, const void *send, const int64_t *sbytes, co
   (void)sd;
   (void)rd;
   free(sc);
+  CommSeconds += timediff(t0, second());
   return err;
 }
 #endif
@@ -368,6 +379,7 @@ static void exchange_particles(const int32_t *dest)
  * DdUseTheta remembers which.  again != 0: P[] has already been handed over for this step and GravPM computed (the second
  * gravity_tree() of a first step, see there). */
 static int DdUseTheta = -1;
+static long long NumImported = 0;	/* copies of other tasks' particles in this task's tree (the last decomposition) */
 static void decompose_several_tasks(int again)
 {
   ngravs_dd_plan plan;
@@ -389,6 +401,7 @@ static void decompose_several_tasks(int again)
   must(ngravs_host_domain_halo(Ctx, &Comm, &plan, &info), 1060);
   ngravs_host_plan_free(&plan);
   DdUseTheta = All.ErrTolTheta != 0;
+  NumImported = (long long)info.n_halo;
   if(ThisTask == 0)
     printf("work-load balance=%g   memory-balance=%g\n", info.work_balance, info.memory_balance);	/* domain.c:257-258 */
 }
@@ -545,11 +558,77 @@ void pmpotential_periodic(void)
 #endif
 #endif
 
+/* gravtree.c:384-456: the per-step block of timings.txt and the CPU_* sums it feeds, line for line in the reference's format.
+ * What the numbers mean here: Nf / total-Nf as there; ex-frac -- there the exported targets per force computation -- is the
+ * imported particles (copies of other tasks' top leaves in this task's tree) per force computation; iter is 1 (the import is
+ * decided before the walk, nothing is iterated); work-load balance from the tasks' device times of the walk; particle-load
+ * balance max(NumPart) * NTask / TotNumPart; max. nodes of the device trees; part/sec | ia/part as there; the count in brackets
+ * (node-level Ewald corrections per force) is 0: the lattice correction is walked on the force walk's own interaction list. */
+static void write_timings(const ngravs_stats_t *st)
+{
+  double mine[7], *all = NULL, ntot = 0, sumt = 0, maxt = 0, sumcomm = 0, costtotal = 0, plb_max = 0, nimp = 0, sumimb = 0;
+  long long nt;
+  int i, maxnumnodes = 0;
+#ifdef NGRAVS_WITH_RCCL
+  {
+    int64_t calls;
+    double sec = 0, bytes;
+    ngravs_rccl_stats(Rccl, &calls, &sec, &bytes, 1);
+    CommSeconds += sec;
+  }
+#endif
+  mine[0] = (double)st->n_active;
+  mine[1] = st->interactions;
+  mine[2] = st->t_treewalk;
+  mine[3] = CommSeconds;	/* since the last block: decomposition, mesh exchanges and imports of this step */
+  mine[4] = (double)st->n_nodes;
+  mine[5] = (double)NumImported;
+  mine[6] = (double)NumPart;
+  CommSeconds = 0;
+  all = malloc(sizeof(double) * 7 * NTask);
+  MPI_Allgather(mine, 7, MPI_DOUBLE, all, 7, MPI_DOUBLE, MPI_COMM_WORLD);
+  for(i = 0; i < NTask; i++)
+    {
+      const double *a = all + 7 * i;
+      ntot += a[0];
+      costtotal += a[1];
+      sumt += a[2];
+      maxt = a[2] > maxt ? a[2] : maxt;
+      sumcomm += a[3];
+      maxnumnodes = (int)a[4] > maxnumnodes ? (int)a[4] : maxnumnodes;
+      nimp += a[5];
+      plb_max = a[6] * NTask / (double)All.TotNumPart > plb_max ? a[6] * NTask / (double)All.TotNumPart : plb_max;
+    }
+  for(i = 0; i < NTask; i++)
+    sumimb += maxt - all[7 * i + 2];
+  nt = (long long)ntot;
+  All.NumForcesSinceLastDomainDecomp += nt;	/* gravtree.c:74-78 */
+  All.CPU_TreeConstruction += st->t_treebuild;
+  if(ThisTask == 0)
+    {
+      All.TotNumOfForces += nt;
+      fprintf(FdTimings, "Step= %d  t= %g  dt= %g \n", All.NumCurrentTiStep, All.Time, All.TimeStep);
+      fprintf(FdTimings, "Nf= %d%09d  total-Nf= %d%09d  ex-frac= %g  iter= %d\n", (int)(nt / 1000000000), (int)(nt % 1000000000),
+	      (int)(All.TotNumOfForces / 1000000000), (int)(All.TotNumOfForces % 1000000000), nimp / (ntot + 1.0e-20), 1);
+      fprintf(FdTimings, "work-load balance: %g  max=%g avg=%g PE0=%g\n", maxt / (sumt / NTask + 1.0e-20), maxt, sumt / NTask, all[2]);
+      fprintf(FdTimings, "particle-load balance: %g\n", plb_max);
+      fprintf(FdTimings, "max. nodes: %d, filled: %g\n", maxnumnodes, maxnumnodes / (All.TreeAllocFactor * All.MaxPart + 1.0e-20));
+      fprintf(FdTimings, "part/sec=%g | %g  ia/part=%g (%g)\n", ntot / (sumt + 1.0e-20), ntot / (maxt * NTask + 1.0e-20),
+	      costtotal / (ntot + 1.0e-20), 0.0);
+      fprintf(FdTimings, "\n");
+      fflush(FdTimings);
+      All.CPU_TreeWalk += sumt / NTask;
+      All.CPU_Imbalance += sumimb / NTask;
+      All.CPU_CommSum += sumcomm / NTask;
+    }
+  free(all);
+}
+
 /* proto.h:114 */
 void gravity_tree(void)
 {
   ngravs_stats_t st;
-  double t0 = second(), nf = 0, ia = 0, tw = 0, sum[3];
+  int64_t unopened = 0;
   ensure_ctx();
   if(All.ComovingIntegrationOn)	/* gravtree.c:50-51: new softening lengths for the new scale factor */
     set_softenings();
@@ -573,22 +652,11 @@ void gravity_tree(void)
   if(All.TypeOfOpeningCriterion == 1)
     All.ErrTolTheta = 0;	/* gravtree.c:334-335 */
   ngravs_get_stats(Ctx, &st);
-  sum[0] = (double)st.n_active;
-  sum[1] = st.interactions;
-  sum[2] = st.t_treewalk;
-  MPI_Allreduce(MPI_IN_PLACE, sum, 2, MPI_DOUBLE, MPI_SUM, MPI_COMM_WORLD);
-  MPI_Allreduce(MPI_IN_PLACE, &sum[2], 1, MPI_DOUBLE, MPI_MAX, MPI_COMM_WORLD);
-  nf = sum[0];
-  ia = sum[1];
-  tw = sum[2];
-  All.TotNumOfForces += (long long)nf;
-  All.NumForcesSinceLastDomainDecomp += (long long)nf;	/* gravtree.c:74-78 */
-  All.CPU_TreeConstruction += st.t_treebuild;
-  All.CPU_TreeWalk += st.t_treewalk;
-  All.CPU_Imbalance += tw - st.t_treewalk;
-  if(ThisTask == 0)
-    fprintf(FdTimings, "Step= %d  t= %g  Nf= %ld  part/sec=%g  ia/part=%g  (MI355X, %g s)\n", All.NumCurrentTiStep,
-	    All.Time, (long)nf, nf / (tw * NTask + 1e-30), ia / (nf + 1e-30), timediff(t0, second()));
+  write_timings(&st);
+  (void)ngravs_walk_unopened(Ctx, &unopened);
+  if(unopened > 0)
+    printf("ngravs-hip: task %d: %ld top leaves were used as monopoles where a group of targets wanted them opened (not imported)\n",
+	   ThisTask, (long)unopened);
 }
 
 #ifdef PMGRID

@@ -40,7 +40,7 @@ extern struct global_data_all_processes
   double ErrTolTheta, ErrTolForceAcc;
   int TypeOfOpeningCriterion;
   long long TotNumOfForces, NumForcesSinceLastDomainDecomp;
-  double G, BoxSize, Time;
+  double G, BoxSize, Time, TimeStep;
   int NumCurrentTiStep, Ti_Current, PM_Ti_endstep;
   double Asmth[2], Rcut[2];
   double ForceSoftening[6], SofteningTable[6];
@@ -49,7 +49,7 @@ extern struct global_data_all_processes
   double MinGasHsml, MinGasHsmlFractional;
   int ComovingIntegrationOn;
   double TreeDomainUpdateFrequency;
-  double CPU_TreeConstruction, CPU_TreeWalk, CPU_Imbalance, CPU_PM, CPU_Domain, CPU_Peano;
+  double CPU_TreeConstruction, CPU_TreeWalk, CPU_Imbalance, CPU_CommSum, CPU_PM, CPU_Domain, CPU_Peano;
   char OutputDir[MAXLEN_FILENAME];
 } All;
 

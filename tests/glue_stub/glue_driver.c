@@ -413,7 +413,14 @@ int main(int argc, char **argv)
         GreensFxns[i][j] = cross ? pgcoloyuk : pgdelta;
         NormedGreensFxns[i][j] = cross ? normed_pgcoloyuk : normed_pgdelta;
       }
-  FdTimings = fopen("/dev/null", "w");
+  if(ThisTask == 0)              /* begrun.c:223-230 opens timings.txt on task 0 */
+    {
+      char tn[600];
+      snprintf(tn, sizeof(tn), "%stimings.txt", argc > 3 ? argv[3] : "/tmp/");
+      FdTimings = fopen(tn, "w");
+    }
+  else
+    FdTimings = fopen("/dev/null", "w");
   set_softenings();              /* init.c:60 */
   force_treeallocate((int)(All.TreeAllocFactor * All.MaxPart), All.MaxPart);
 #ifdef PMGRID

@@ -254,6 +254,23 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
     assert np.array_equal(s2[idle, 0:3], s1[idle, 0:3]) and np.array_equal(s2[idle, 6], s1[idle, 6])   # inactive rows keep their values
     assert np.array_equal(s2[idle, 7], s1[idle, 7])
     print("glue on %d task(s), particles per task and step: %s" % (ntask, own))
+    # timings.txt: the reference's block per gravity_tree() call (gravtree.c:408-444), six lines + a blank one, in its formats
+    import re
+    blocks = open(str(tmp_path / "timings.txt")).read().split("\n\n")
+    blocks = [b for b in blocks if b.strip()]
+    assert len(blocks) == (4 if ntask == 1 else 3)          # first step: two calls; then one per step
+    pat = [r"^Step= -?\d+  t= \S+  dt= \S+ $", r"^Nf= \d+\d{9}  total-Nf= \d+\d{9}  ex-frac= \S+  iter= \d+$",
+           r"^work-load balance: \S+  max=\S+ avg=\S+ PE0=\S+$", r"^particle-load balance: \S+$", r"^max\. nodes: \d+, filled: \S+$",
+           r"^part/sec=\S+ \| \S+  ia/part=\S+ \(\S+\)$"]
+    for b in blocks:
+        lines = b.split("\n")
+        assert len(lines) == 6 and all(re.match(p_, ln) for p_, ln in zip(pat, lines)), lines
+    nf = [int(b.split("\n")[1].split()[1]) for b in blocks]
+    assert nf[0] == n and nf[1] == n                          # every particle is active on the first step
+    ia = float(blocks[1].split("\n")[5].split("ia/part=")[1].split()[0])
+    assert abs(ia / s1[:, 7].mean() - 1) < 1e-6               # ia/part is the mean of P[].GravCost
+    exf = float(blocks[1].split("\n")[1].split("ex-frac=")[1].split()[0])
+    assert exf == 0 if ntask == 1 else (exf > 0 or n <= 100)
     if "-DFORCETEST=0.02" in opts:
         lines = [ln.split() for ln in open(str(tmp_path / "forcetest.txt"))]
         want = sum(1 for i in range(n) if ((((i + 1) * 2654435761) & 0xffffffff) ^ ((((i + 1) * 2654435761) & 0xffffffff) >> 15)) % 1000 < 20)
@@ -267,3 +284,43 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
         assert np.allclose(t[:, 9:12], s1[ids, 0:3], rtol=1e-14 if pm else 1e-5, atol=0)  # the GravAccel column is P[].GravAccel
         print("forcetest.txt: %d lines, tree+PM vs direct sum rms %.2e max %.2e" % (len(lines), np.sqrt(np.mean(err ** 2)), err.max()))
         assert np.sqrt(np.mean(err ** 2)) < 2e-2
+
+
+def test_stubs_declare_what_the_reference_declares(pkg):
+    """tests/glue_stub/{allvars,proto,ngravs}.h are hand-written stand-ins for the reference's headers (which need GSL and FFTW-2).
+    tools/glue_stub_check.py recorded, from the reference's headers, type / array extent / order of every struct field, the type
+    of every global and the signature of every prototype the stubs declare (tests/golden/glue_stub_check.json: names and types
+    only).  The stubs, parsed the same way, must say the same: same types and extents, struct particle_data's fields in the
+    reference's order (it travels as raw bytes in the glue's particle exchange), same prototypes -- and nothing the reference lacks."""
+    import importlib.util
+    import json
+    root = os.path.join(os.path.dirname(pkg.__file__), "..")
+    spec = importlib.util.spec_from_file_location("glue_stub_check", os.path.join(root, "tools", "glue_stub_check.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    want = json.load(open(os.path.join(root, "tests", "golden", "glue_stub_check.json")))
+    assert want["missing_in_reference"] == []
+    sv = g.stub_view()
+    n = 0
+    for sname, fields in sv["structs"].items():
+        last = -1
+        for name, t, ext in fields:
+            r = want["structs"][sname].get(name)
+            assert r is not None, "struct %s: the stub declares %s, the reference does not" % (sname, name)
+            assert [t, ext] in r["forms"], (sname, name, t, ext, r)      # (forms: one per #ifdef branch of the reference, e.g. LONGIDS)
+            if sname == "particle_data":
+                assert r["order"] > last, "struct particle_data: %s is out of the reference's order" % name
+                last = r["order"]
+            n += 1
+    for name, (t, ext) in sv["globals"].items():
+        if name in ("All", "P"):
+            continue
+        r = want["globals"].get(name)
+        assert r is not None and (r["type"], r["extent"]) == (t, ext), (name, t, ext, r)
+        n += 1
+    for name, (ret, params) in sv["prototypes"].items():
+        r = want["prototypes"].get(name)
+        assert r is not None and (r["returns"], r["parameters"]) == (ret, list(params)), (name, ret, params, r)
+        n += 1
+    print("%d declarations of the stubs agree with the reference's headers" % n)
+    assert n > 90
