@@ -36,11 +36,12 @@ EXPORTS = [
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
     "ngravs_dd_get_toptree", "ngravs_dd_peano_order", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
     "ngravs_dd_pack_leaves", "ngravs_dd_set_top", "ngravs_dd_recv_buffer", "ngravs_dd_apply_migration", "ngravs_dd_set_halo",
+    "ngravs_dd_leaf_sums_kept", "ngravs_dd_pack_leaves_kept", "ngravs_dd_refresh_halo", "ngravs_dd_update_top", "ngravs_dd_get_kept",
     "ngravs_dd_set_ids", "ngravs_dd_get_ids",
     "ngravs_pm_slab_begin", "ngravs_pm_slab_pack", "ngravs_pm_slab_unpack", "ngravs_pm_slab_bytes",
 ]
 # include/ngravs_host.h (plain-C multi-task drivers over a communicator vtable, linked into the same library)
-HOST_EXPORTS = ["ngravs_host_comm_selftest", "ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
+HOST_EXPORTS = ["ngravs_host_comm_selftest", "ngravs_host_kept_step", "ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
                 "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
                 "ngravs_host_pm_seconds", "ngravs_host_toptree_init", "ngravs_host_toptree_from_children", "ngravs_host_toptree_adapt",
                 "ngravs_host_toptree_free", "ngravs_host_import_request"]

@@ -577,9 +577,12 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
       c->pm_parked = false;
       return NGRAVS_OK;
     }
-  if(keep_tree && (!c->have_order || !c->have_tree || p->n != c->n || c->n_local != c->n))
+  // (a multi-task working set: the caller's rows are its own particles; the imported copies behind them are refreshed by their
+  // owners, ngravs_host_kept_step)
+  const bool keep_halo = keep_tree && c->n_local != c->n;
+  if(keep_tree && (!c->have_order || !c->have_tree || p->n != c->n_local))
     {
-      ngravs_report(c, NGRAVS_ERR_STATE, "ngravs_update_particles: needs a built tree over the same particles (no halo copies)");
+      ngravs_report(c, NGRAVS_ERR_STATE, "ngravs_update_particles: needs a built tree over the same own particles");
       return NGRAVS_ERR_STATE;
     }
   if(p->n >= (1ll << 31) - 64)
@@ -595,7 +598,8 @@ static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool k
       ngravs_report(c, NGRAVS_ERR_NOMEM, "device allocation failed");
       return NGRAVS_ERR_NOMEM;
     }
-  c->n = n;
+  if(!keep_halo)
+    c->n = n;
   c->n_local = n;
   if(!keep_tree)
     {
@@ -1131,6 +1135,57 @@ extern "C" int ngravs_get_stats(ngravs_ctx *c, ngravs_stats_t *out)
   if(!c || !out)
     return NGRAVS_ERR_ARG;
   *out = c->stats;
+  return NGRAVS_OK;
+}
+
+// ---- kept decomposition (include/ngravs_hip.h, ngravs_host_kept_step)
+extern "C" int ngravs_dd_leaf_sums_kept(ngravs_ctx *c, void **dev_sums, int64_t *count)
+{
+  if(!c || !dev_sums || !count)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_leaf_sums_kept(c, dev_sums, count);
+}
+extern "C" int ngravs_dd_pack_leaves_kept(ngravs_ctx *c, int64_t *counts, void **dev_records, int64_t *nrec)
+{
+  if(!c || !counts || !dev_records || !nrec)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_pack_leaves_kept(c, counts, dev_records, nrec);
+}
+extern "C" int ngravs_dd_refresh_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  if(!c || nrec < 0 || (nrec > 0 && !dev_records))
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_refresh_halo(c, dev_records, nrec);
+}
+extern "C" int ngravs_dd_update_top(ngravs_ctx *c, const double *node_sums, const double *leaf_len)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return dd_update_top(c, node_sums, leaf_len);
+}
+extern "C" int ngravs_dd_get_kept(ngravs_ctx *c, int32_t *rank, int32_t *world, const int32_t **leaf_owner, const uint8_t **present,
+                                  const double **node_sums)
+{
+  if(!c)
+    return NGRAVS_ERR_ARG;
+  const TopTree &t = c->top;
+  if(!(t.on && t.h.nnode > 0 && t.own_leaf_n == c->n_local && t.kept_rank >= 0 && (int)t.h_leaf_owner.size() == t.h.nleaf &&
+       (int)t.h_present.size() == t.h.nleaf))
+    return NGRAVS_ERR_STATE;
+  if(rank)
+    *rank = t.kept_rank;
+  if(world)
+    *world = t.kept_world;
+  if(leaf_owner)
+    *leaf_owner = t.h_leaf_owner.data();
+  if(present)
+    *present = t.h_present.data();
+  if(node_sums)
+    *node_sums = t.h_node_sums.data();
   return NGRAVS_OK;
 }
 

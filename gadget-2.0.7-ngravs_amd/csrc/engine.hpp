@@ -148,6 +148,15 @@ struct TopTree
   DevBuf<int> leaf_owner;              // per leaf
   DevBuf<unsigned long long> reqmask;  // per leaf: tasks that asked for its particles
   DevBuf<double> leaf_sums;            // per leaf: TOP_CW doubles of the own particles (+ 1 spare word)
+  // ---- kept decomposition (the steps on which domain.c:76 keeps domain and tree: ngravs_host_kept_step) ----
+  DevBuf<int> own_leaf;                // per own row: its top leaf at the decomposition (ngravs_dd_pack_leaves); rows stay, positions drift
+  long long own_leaf_n = -1;           // own rows it covers (-1: none kept)
+  int kept_rank = -1, kept_world = 0;
+  std::vector<int> h_leaf_owner;       // host copies of the last decomposition's plan
+  std::vector<unsigned char> h_present;
+  std::vector<double> h_node_sums;
+  DevBuf<double> kept_sums;            // per leaf: TOP_CW + 1 doubles (the last one: the grown side of the leaf's cell, from its owner) + 1 status word
+  DevBuf<double> leaf_len;             // per leaf: grown side of its cell (all tasks' maximum), for the pseudo nodes of a refit
 };
 
 // slab-decomposed particle mesh of the multi-task path (kernels_pmslab.hip)
@@ -286,12 +295,18 @@ int dd_target_bounds(ngravs_ctx *c, double out[2]);
 int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks, int me, int64_t *counts, void **dev_records, int64_t *nrec);
 int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *present);
 int dd_set_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_leaf_sums_kept(ngravs_ctx *c, void **dev_sums, int64_t *count);
+int dd_pack_leaves_kept(ngravs_ctx *c, int64_t *counts, void **dev_records, int64_t *nrec);
+int dd_refresh_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec);
+int dd_update_top(ngravs_ctx *c, const double *node_sums, const double *leaf_len);
 int dd_peano_order_own(ngravs_ctx *c, int force);
 int dd_fill_ids(ngravs_ctx *c);
 int dd_record_doubles(const ngravs_ctx *c, int what);
 // ---- kernels_tree.hip
 int tree_build(ngravs_ctx *c);
 int tree_moments(ngravs_ctx *c, bool refit, bool counts = false);
+int tree_top_leaf_len(ngravs_ctx *c, double *dev_kept_sums, int stride);   // kept steps: the grown sides of the own top leaves' cells
+int tree_top_refit(ngravs_ctx *c);   // kept steps: moments of the top nodes from the new global sums, their sides from the leaves' up
 int dom_regather(ngravs_ctx *c);
 static inline bool cfg_has_bam(const ngravs_config_t &cfg)
 {
@@ -308,7 +323,7 @@ int walk_finish(ngravs_ctx *c);
 int direct_run(ngravs_ctx *c, const int *d_idx, int64_t nt, double *d_acc);
 int direct_run_targets(ngravs_ctx *c, const double4 *d_tpm, const int *d_ttype, int64_t nt, double *d_acc);
 // ---- kernels_eval.hip
-int eval_ring_slots(const WalkParams &wp, int waves);
+int eval_ring_slots(const WalkParams &wp, bool yuk, int waves);
 int launch_eval_ring(ngravs_ctx *c, const TreeView &tv, const WalkParams &wp, bool yuk, int nblk, int waves, int K, const int *region,
                      const int *gcount, long long g0, long long nb, int lcap, int scap, int S, const int *tlist, int SG, long long t_count);
 // ---- kernels_pm.hip

@@ -378,8 +378,12 @@ __device__ __forceinline__ bool dd_row(const unsigned int *__restrict__ order, l
 __global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__restrict__ mass, const int *__restrict__ type,
                               const double *__restrict__ cost, long long n, const unsigned int *__restrict__ order, long long norder,
                               double cx, double cy, double cz, double fac21, const int *__restrict__ t_child,
-                              const int *__restrict__ t_leaf, int ng, unsigned t2g_packed, double *__restrict__ sums)
+                              const int *__restrict__ t_leaf, int ng, unsigned t2g_packed, double *__restrict__ sums,
+                              const int *__restrict__ leaf_in = nullptr, int stride = 0)
 {
+  // leaf_in (kept decomposition): the leaf a row was in when the domains were cut -- the particle has drifted since, its
+  // membership has not (the reference's particles stay in their nodes, the nodes grow); stride: doubles per leaf (default TOP_CW)
+  const int cwl = stride > 0 ? stride : TOP_CW(ng);
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
     step[t >> 3][t & 7] = c_ph_step[t >> 3][t & 7];
@@ -393,7 +397,7 @@ __global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__re
   double m = 0, mx = 0, my = 0, mz = 0, w = 0;
   if(valid)
     {
-      leaf = dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
+      leaf = leaf_in ? leaf_in[i] : dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
       ty = type[i];
       g = (int)((t2g_packed >> (2 * ty)) & 3u);
       m = mass[i];
@@ -406,7 +410,7 @@ __global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__re
   const int leaf0 = __shfl(leaf, first);
   if(__builtin_amdgcn_ballot_w64(valid && leaf == leaf0) == vm)
     {
-      double *c = sums + (size_t)leaf0 * TOP_CW(ng);
+      double *c = sums + (size_t)leaf0 * cwl;
       const bool lead = (threadIdx.x & 63) == first;
       const double ws = wave_sum_f64(w);
       if(lead)
@@ -436,7 +440,7 @@ __global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__re
     }
   else if(valid)
     {
-      double *c = sums + (size_t)leaf * TOP_CW(ng);
+      double *c = sums + (size_t)leaf * cwl;
       atomicAdd(&c[0], w);
       atomicAdd(&c[1 + ty], 1.0);
       atomicAdd(&c[7 + 4 * g + 0], m);
@@ -450,7 +454,8 @@ __global__ void k_dd_leafsums(const double *__restrict__ pos, const double *__re
 // reqmask: every task that asked for its leaf (import)
 __global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx, double cy, double cz, double fac21,
                           const int *__restrict__ t_child, const int *__restrict__ t_leaf, const int *__restrict__ leaf_owner,
-                          const unsigned long long *__restrict__ reqmask, int me, unsigned long long *__restrict__ mask, int *__restrict__ dest)
+                          const unsigned long long *__restrict__ reqmask, int me, unsigned long long *__restrict__ mask, int *__restrict__ dest,
+                          int *__restrict__ leaf_out = nullptr, const int *__restrict__ leaf_in = nullptr)
 {
   __shared__ unsigned short step[48][8];
   for(int t = threadIdx.x; t < 48 * 8; t += blockDim.x)
@@ -459,7 +464,9 @@ __global__ void k_dd_dest(const double *__restrict__ pos, long long n, double cx
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if(i >= n)
     return;
-  const int leaf = dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
+  const int leaf = leaf_in ? leaf_in[i] : dd_leaf(step, pos, i, cx, cy, cz, fac21, t_child, t_leaf);
+  if(leaf_out)
+    leaf_out[i] = leaf;
   if(dest)
     dest[i] = leaf_owner[leaf];
   else if(leaf_owner)
@@ -842,6 +849,8 @@ int dd_pack(ngravs_ctx *c, int what, const int *leaf_owner, int nranks, int me, 
   if(c->dd_mask.ensure(n > 0 ? n : 1) || t.leaf_owner.ensure((size_t)t.h.nleaf) || c->dd_counts.ensure(3 * 65 + 2))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemcpyAsync(t.leaf_owner.p, leaf_owner, sizeof(int) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
+  t.h_leaf_owner.assign(leaf_owner, leaf_owner + t.h.nleaf);
+  t.own_leaf_n = -1;   // a new cut: nothing is kept until its leaves have been packed
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
   double fac21;
   dd_fac(c, &fac21);
@@ -910,6 +919,8 @@ int dd_get_dest(ngravs_ctx *c, const int *leaf_owner, int *dest)
   if(t.leaf_owner.ensure((size_t)t.h.nleaf) || d.ensure(n))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemcpyAsync(t.leaf_owner.p, leaf_owner, sizeof(int) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
+  t.h_leaf_owner.assign(leaf_owner, leaf_owner + t.h.nleaf);
+  t.own_leaf_n = -1;
   double fac21;
   dd_fac(c, &fac21);
   hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2],
@@ -927,16 +938,106 @@ int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks,
   if(nranks > 64 || t.h.nnode < 1)
     return NGRAVS_ERR_ARG;
   const long long n = c->n_local;
-  if(c->dd_mask.ensure(n > 0 ? n : 1) || t.reqmask.ensure((size_t)t.h.nleaf) || c->dd_counts.ensure(3 * 65 + 2))
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || t.reqmask.ensure((size_t)t.h.nleaf) || c->dd_counts.ensure(3 * 65 + 2) || t.own_leaf.ensure(n > 0 ? n : 1))
     return NGRAVS_ERR_NOMEM;
   HIP_TRY(c, hipMemcpyAsync(t.reqmask.p, reqmask, sizeof(unsigned long long) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
   double fac21;
   dd_fac(c, &fac21);
+  // (the leaf of every own row is kept: on the steps that keep this decomposition the rows are the same, their positions are not)
   if(n > 0)
     hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], fac21,
-                       t.child.p, t.leaf.p, (const int *)nullptr, t.reqmask.p, me, c->dd_mask.p, (int *)nullptr);
+                       t.child.p, t.leaf.p, (const int *)nullptr, t.reqmask.p, me, c->dd_mask.p, (int *)nullptr, t.own_leaf.p);
+  t.own_leaf_n = n;
+  t.kept_rank = me;
+  t.kept_world = nranks;
   return dd_pack_masked(c, 2, nranks, counts, dev_records, nrec);
+}
+
+// ---- kept decomposition: the same cut, the same requests, drifted particles (ngravs_host_kept_step) ---------------------------
+// force_update_pseudoparticles (forcetree.c:753) + the role of the export / import loop on a step that keeps domain and tree.
+static int kept_ok(const ngravs_ctx *c)
+{
+  const TopTree &t = c->top;
+  return t.on && t.h.nnode > 0 && t.own_leaf_n == c->n_local && t.kept_rank >= 0 && (int)t.h_leaf_owner.size() == t.h.nleaf &&
+         (int)t.h_present.size() == t.h.nleaf;
+}
+
+// the records of the own particles of every leaf another task asked for at the decomposition: same rows, same order, new positions
+int dd_pack_leaves_kept(ngravs_ctx *c, int64_t *counts, void **dev_records, int64_t *nrec)
+{
+  TopTree &t = c->top;
+  if(!kept_ok(c))
+    return NGRAVS_ERR_STATE;
+  const long long n = c->n_local;
+  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->dd_counts.ensure(3 * 65 + 2))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], 0.0,
+                       t.child.p, t.leaf.p, (const int *)nullptr, t.reqmask.p, t.kept_rank, c->dd_mask.p, (int *)nullptr, (int *)nullptr,
+                       t.own_leaf.p);
+  return dd_pack_masked(c, 2, t.kept_world, counts, dev_records, nrec);
+}
+
+// per leaf, by the membership of the decomposition: the sums of ngravs_dd_leaf_sums + one more word, the grown side of the leaf's
+// cell in the tree of its OWNER (every other task adds 0: the sum over the tasks is the owner's value)
+int dd_leaf_sums_kept(ngravs_ctx *c, void **dev_sums, int64_t *count)
+{
+  TopTree &t = c->top;
+  if(!kept_ok(c))
+    return NGRAVS_ERR_STATE;
+  const int cwk = TOP_CW(c->cfg.n_gravs) + 1;
+  const long long n = c->n_local, words = (long long)t.h.nleaf * cwk + 1;
+  if(t.kept_sums.ensure((size_t)words))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemsetAsync(t.kept_sums.p, 0, sizeof(double) * words, c->stream));
+  unsigned t2g_packed = 0;
+  for(int ty = 0; ty < NGRAVS_NTYPES; ty++)
+    t2g_packed |= ((unsigned)(c->cfg.type_to_grav[ty] & 3)) << (2 * ty);
+  if(n > 0)
+    hipLaunchKernelGGL(k_dd_leafsums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, c->in_mass.p, c->in_type.p,
+                       c->in_cost.p, n, (const unsigned int *)nullptr, n, c->dom[0], c->dom[1], c->dom[2], 0.0, t.child.p, t.leaf.p,
+                       c->cfg.n_gravs, t2g_packed, t.kept_sums.p, t.own_leaf.p, cwk);
+  HIP_TRY(c, hipGetLastError());
+  int rc = tree_top_leaf_len(c, t.kept_sums.p, cwk);
+  if(rc)
+    return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  *dev_sums = t.kept_sums.p;
+  *count = words;
+  return NGRAVS_OK;
+}
+
+// the imported copies take the positions (and masses) their owners hold now: the records arrive in the order of the
+// decomposition's import (ngravs_dd_set_halo), rows n_local ... of the input columns
+int dd_refresh_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
+{
+  if(!kept_ok(c) || nrec != c->n - c->n_local)
+    return NGRAVS_ERR_STATE;
+  if(nrec > 0)
+    hipLaunchKernelGGL(k_dd_unpack, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, c->stream, (const double *)dev_records, 7,
+                       (long long)nrec, (long long)c->n_local, 1, c->in_pos.p, c->in_mass.p, c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p,
+                       c->in_cost.p, (double *)nullptr);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->tree_stale = true;
+  return NGRAVS_OK;
+}
+
+// new global sums of every top node (counts and presence are those of the decomposition) and the grown sides of the leaves' cells
+int dd_update_top(ngravs_ctx *c, const double *node_sums, const double *leaf_len)
+{
+  TopTree &t = c->top;
+  if(!kept_ok(c) || !node_sums || !leaf_len || !c->have_tree)
+    return NGRAVS_ERR_STATE;
+  const int cw = TOP_CW(c->cfg.n_gravs), nn = t.h.nnode;
+  if(t.leaf_len.ensure((size_t)t.h.nleaf))
+    return NGRAVS_ERR_NOMEM;
+  HIP_TRY(c, hipMemcpyAsync(t.gsum.p, node_sums, sizeof(double) * (size_t)nn * cw, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(t.leaf_len.p, leaf_len, sizeof(double) * (size_t)t.h.nleaf, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return tree_top_refit(c);
 }
 
 // The global sums of every top node (all-reduced leaf sums, added up the tree by the host) and which leaves are present on
@@ -974,6 +1075,8 @@ int dd_set_top(ngravs_ctx *c, const double *node_sums, const unsigned char *pres
   HIP_TRY(c, hipMemcpyAsync(t.info.p, info.data(), (size_t)nn, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   t.on = true;
+  t.h_present.assign(present, present + t.h.nleaf);
+  t.h_node_sums.assign(node_sums, node_sums + (size_t)nn * cw);
   t.total_count = cnt.empty() ? 0.0 : (double)cnt[0];
   t.import_reach = c->cfg.walk_mode == NGRAVS_WALK_GROUP ? fmin(6.0, c->cfg.group_reach > 0 ? c->cfg.group_reach : NGRAVS_GROUP_REACH) : 6.0;
   c->have_tree = false;

@@ -946,6 +946,102 @@ static int tree_top_moments(ngravs_ctx *c)
   return NGRAVS_OK;
 }
 
+// ---- kept decomposition (ngravs_host_kept_step): the top of a refit tree from the data of all tasks ------------------------------
+// force_update_node_len_toptree / force_update_pseudoparticles (forcetree.c:753, 1096-1122): a top leaf whose particles live on
+// another task has no particles here to grow its cell from; its owner's refit knows the side the single-task refit would give it.
+// Tree nodes that are top LEAVES owned by this task: their grown side -> kept_sums[leaf * stride + stride - 1]
+__global__ void k_top_leaf_len(const int *__restrict__ n_top, const int *__restrict__ t_child, const int *__restrict__ t_leaf,
+                               const int *__restrict__ leaf_owner, int me, const double4 *__restrict__ n_geo, int node0, int nnodes_level,
+                               double *__restrict__ kept_sums, int stride)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  const int node = node0 + t, tn = n_top[node];
+  if(tn < 0 || t_child[tn] >= 0)
+    return;
+  const int leaf = t_leaf[tn];
+  if(leaf >= 0 && leaf_owner[leaf] == me)
+    kept_sums[(size_t)leaf * stride + stride - 1] = n_geo[node].w;
+}
+
+int tree_top_leaf_len(ngravs_ctx *c, double *dev_kept_sums, int stride)
+{
+  const TopTree &t = c->top;
+  if(!c->have_tree || !t.on)
+    return NGRAVS_ERR_STATE;
+  for(int l = (t.h.depth < c->nlevels - 1 ? t.h.depth : c->nlevels - 1); l >= 0; l--)
+    {
+      const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
+      if(lc <= 0)
+        continue;
+      hipLaunchKernelGGL(k_top_leaf_len, dim3((unsigned)((lc + 127) / 128)), dim3(128), 0, c->stream, c->n_top.p, t.child.p, t.leaf.p,
+                         t.leaf_owner.p, t.kept_rank, c->n_geo.p, (int)l0, (int)lc, dev_kept_sums, stride);
+    }
+  HIP_TRY(c, hipGetLastError());
+  return NGRAVS_OK;
+}
+
+// sides of the top nodes of a refit tree, bottom-up: an absent leaf (pseudo node) takes the side all tasks agreed on, a split top
+// node grows to enclose its (grown) children by the rule of k_moments' refit
+__global__ void k_top_len(const int *__restrict__ n_top, const int *__restrict__ t_child, const int *__restrict__ t_leaf,
+                          const double *__restrict__ leaf_len, const int *__restrict__ n_child, const int *__restrict__ n_flags,
+                          double4 *__restrict__ n_geo, int node0, int nnodes_level)
+{
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if(t >= nnodes_level)
+    return;
+  const int node = node0 + t, tn = n_top[node];
+  if(tn < 0)
+    return;
+  double4 geo = n_geo[node];
+  if(t_child[tn] < 0)
+    {
+      if(n_flags[node] & FLAG_PSEUDO)
+        {
+          const double want = leaf_len[t_leaf[tn]];
+          if(want > geo.w)
+            {
+              geo.w = want;
+              n_geo[node] = geo;
+            }
+        }
+      return;
+    }
+  double need = 0;
+  for(int k = 0; k < 8; k++)
+    {
+      const int ch = n_child[8 * (long long)node + k];
+      if(ch >= 0)
+        {
+          const double4 cg = n_geo[ch];
+          need = fmax(need, fmax(fabs(cg.x - geo.x), fmax(fabs(cg.y - geo.y), fabs(cg.z - geo.z))) + 0.5 * cg.w);
+        }
+    }
+  if(2.0 * need > geo.w)
+    {
+      geo.w = 2.0 * need;
+      n_geo[node] = geo;
+    }
+}
+
+int tree_top_refit(ngravs_ctx *c)
+{
+  const TopTree &t = c->top;
+  if(!c->have_tree || !t.on)
+    return NGRAVS_ERR_STATE;
+  for(int l = (t.h.depth < c->nlevels - 1 ? t.h.depth : c->nlevels - 1); l >= 0; l--)
+    {
+      const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
+      if(lc <= 0)
+        continue;
+      hipLaunchKernelGGL(k_top_len, dim3((unsigned)((lc + 127) / 128)), dim3(128), 0, c->stream, c->n_top.p, t.child.p, t.leaf.p, t.leaf_len.p,
+                         c->n_child.p, c->n_flags.p, c->n_geo.p, (int)l0, (int)lc);
+    }
+  HIP_TRY(c, hipGetLastError());
+  return tree_top_moments(c);
+}
+
 // multipole moments, softening flags (and, for a refit, grown cell sides) of all nodes, bottom-up, one launch per level
 int tree_moments(ngravs_ctx *c, bool refit, bool counts)
 {

@@ -2492,7 +2492,7 @@ template <int NG, bool PM, bool YUK, bool TAB_LDS, bool LATT> static int launch_
         ring_waves = GW2_MAXWAVES;
         if(c->tune.walk_waves > 0 && c->tune.walk_waves < ring_waves)
           ring_waves = c->tune.walk_waves;
-        ringK = eval_ring_slots(wp, ring_waves);
+        ringK = eval_ring_slots(wp, YUK, ring_waves);
         if(c->tune.walk_ring_k >= 4 && c->tune.walk_ring_k < ringK)
           ringK = c->tune.walk_ring_k;
         if(ringK)

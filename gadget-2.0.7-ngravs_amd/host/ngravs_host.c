@@ -1186,6 +1186,136 @@ int ngravs_host_domain_decomposition(ngravs_ctx *ctx, const ngravs_comm *cm, dou
   return status_of(rc);
 }
 
+/* ---- a step that keeps the decomposition (domain.c:76 with TreeDomainUpdateFrequency > 0) -----------------------------------------
+ * The caller has handed its own rows over again with ngravs_update_particles() (same rows, drifted positions).  Two collectives:
+ *   (1) all-to-all-v: the owners ship the drifted particles of the leaves that were requested at the decomposition (same records,
+ *       same order) -> the imported copies take their new positions; then the tree is refit (ngravs_force_update_tree)
+ *   (2) all-reduce (on the device if the communicator can): per leaf the sums of the own particles by the membership of the
+ *       decomposition + the grown side of the leaf's cell in its owner's tree + one status word -> global moments and sides of the
+ *       top nodes (force_update_pseudoparticles forcetree.c:753, force_update_node_len_toptree :1096-1122)
+ * A task that fails locally before (2) reports through its status word; (1) has none (the counts of the exchange are fixed by the
+ * decomposition: a task that cannot pack cannot take part).  info (may be NULL): collectives, seconds[4] pack, [5] exchange +
+ * refresh + refit, [2] leaf sums + all-reduce, [6] top update. */
+int ngravs_host_kept_step(ngravs_ctx *ctx, const ngravs_comm *cm, ngravs_dd_info *info)
+{
+  ngravs_dd_info local;
+  ngravs_config_t cfg;
+  ngravs_toptree tree;
+  const int32_t *owner = NULL;
+  const uint8_t *present = NULL;
+  const double *old_sums = NULL;
+  int32_t me = -1, W = 0;
+  int64_t sc[65], rcn[65], nrec = 0, nrecv = 0, count = 0, want, i;
+  double *sums = NULL, *node_sums = NULL, *leaf_len = NULL;
+  void *rec = NULL, *recvbuf = NULL, *dev = NULL;
+  int r, k, q, cw, cwk, rc, rcc = 0;
+  if(!ctx || !cm)
+    return NGRAVS_ERR_ARG;
+  if(!info)
+    info = &local;
+  memset(info, 0, sizeof(*info));
+  CHECK(ngravs_dd_get_kept(ctx, &me, &W, &owner, &present, &old_sums));
+  if(W != cm->size || me != cm->rank)
+    return NGRAVS_ERR_STATE;
+  memset(&cfg, 0, sizeof(cfg));
+  CHECK(ngravs_get_config(ctx, &cfg));
+  CHECK(ngravs_host_toptree_borrow(ctx, &tree));
+  cw = NGRAVS_TOP_CW(cfg.n_gravs > 0 ? cfg.n_gravs : 1);
+  cwk = cw + 1;
+  /* ---- (1) the imported copies follow their originals */
+  info->seconds[4] = -wall_now();
+  rc = ngravs_dd_pack_leaves_kept(ctx, sc, &rec, &nrec);
+  for(r = 0; r < W; r++)
+    rcn[r] = 0;
+  for(i = 0; i < tree.nleaf; i++)
+    if(present[i] && owner[i] != me)   /* requested then, received now: the global count of the leaf (nothing has migrated) */
+      rcn[owner[i]] += (int64_t)(old_sums[(size_t)tree.node_of_leaf[i] * cw] + 0.5);
+  for(r = 0; r < W; r++)
+    {
+      nrecv += rcn[r];
+      sc[r] = rc ? 0 : sc[r] * NGRAVS_DD_RECORD_BYTES;
+      rcn[r] *= NGRAVS_DD_RECORD_BYTES;
+    }
+  if(!rc)
+    rc = ngravs_dd_recv_buffer(ctx, nrecv, &recvbuf);
+  info->seconds[4] += wall_now();
+  if(rc)
+    return status_of(rc);   /* (see above: the exchange has no status word) */
+  info->seconds[5] = -wall_now();
+  rc = exchange(ctx, cm, rec, sc, recvbuf, rcn);
+  info->collectives++;
+  if(!rc)
+    rc = ngravs_dd_refresh_halo(ctx, recvbuf, nrecv);
+  if(!rc)
+    rc = ngravs_force_update_tree(ctx);
+  info->seconds[5] += wall_now();
+  /* ---- (2) the top of the tree from the sums of all tasks */
+  info->seconds[2] = -wall_now();
+  want = (int64_t)tree.nleaf * cwk;
+  sums = malloc(sizeof(double) * (size_t)(want + 1));
+  node_sums = calloc((size_t)tree.nnode * (size_t)cw, sizeof(double));
+  leaf_len = malloc(sizeof(double) * (size_t)(tree.nleaf > 0 ? tree.nleaf : 1));
+  if(!rc && (!sums || !node_sums || !leaf_len))
+    rc = NGRAVS_ERR_NOMEM;
+  if(!rc)
+    rc = ngravs_dd_leaf_sums_kept(ctx, &dev, &count);
+  if(!rc && count != want + 1)
+    rc = NGRAVS_ERR_STATE;
+  if(cm->allreduce_dev && !rc)
+    {
+      rcc = cm->allreduce_dev(cm->user, dev, want + 1, NGRAVS_T_F64, NGRAVS_OP_SUM);
+      info->collectives++;
+      if(!rcc)
+        rcc = ngravs_memcpy(ctx, sums, dev, (int64_t)sizeof(double) * (want + 1), 2);
+    }
+  else if(sums)
+    {
+      /* host all-reduce; a task that failed takes part with zeros and raises the status word */
+      if(!rc)
+        rc = ngravs_memcpy(ctx, sums, dev, (int64_t)sizeof(double) * want, 2);
+      if(rc)
+        memset(sums, 0, sizeof(double) * (size_t)want);
+      sums[want] = rc ? 1.0 : 0.0;
+      rcc = cm->allreduce(cm->user, sums, want + 1, NGRAVS_T_F64, NGRAVS_OP_SUM);
+      info->collectives++;
+    }
+  info->seconds[2] += wall_now();
+  if(!rc && !rcc && sums[want] > 0.5)
+    rc = NGRAVS_ERR_STATE;   /* another task failed */
+  if(!rc && !rcc)
+    {
+      info->seconds[6] = -wall_now();
+      for(i = tree.nnode - 1; i >= 0; i--)
+        {
+          double *dst = node_sums + (size_t)i * cw;
+          if(tree.child[i] < 0)
+            {
+              const double *p = sums + (size_t)tree.leaf[i] * cwk;
+              memcpy(dst, p, sizeof(double) * (size_t)cw);
+              dst[0] = p[1] + p[2] + p[3] + p[4] + p[5] + p[6];   /* [0] of a node: its particle count (as ngravs_dd_set_top takes it) */
+              leaf_len[tree.leaf[i]] = p[cw];
+            }
+          else
+            for(k = 0; k < 8; k++)
+              {
+                const double *src = node_sums + (size_t)(tree.child[i] + k) * cw;
+                for(q = 0; q < cw; q++)
+                  dst[q] += src[q];
+              }
+        }
+      rc = ngravs_dd_update_top(ctx, node_sums, leaf_len);
+      info->seconds[6] += wall_now();
+    }
+  info->n_local = ngravs_dd_num_local(ctx);
+  info->n_halo = nrecv;
+  info->n_topnodes = tree.nnode;
+  info->n_topleaves = tree.nleaf;
+  free(sums);
+  free(node_sums);
+  free(leaf_len);
+  return status_of(rc ? rc : rcc);
+}
+
 /* ---- the communicator proves itself (include/ngravs_comm_selftest.h) ------------------------------------------------------------ */
 #include "ngravs_comm_selftest.h"
 static void *st_alloc(void *user, size_t bytes)

@@ -360,6 +360,25 @@ int ngravs_dd_set_top(ngravs_ctx *ctx, const double *node_sums, const uint8_t *p
 int ngravs_dd_recv_buffer(ngravs_ctx *ctx, int64_t nrec, void **dev_records);
 int ngravs_dd_apply_migration(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
 int ngravs_dd_set_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
+/* ---- kept decomposition: the steps on which domain.c:76 keeps domain and tree (All.TreeDomainUpdateFrequency > 0) -------------
+ * The reference drifts its nodes with their velocities, refreshes the other tasks' top-leaf moments (force_update_pseudoparticles,
+ * forcetree.c:753) and the sides of the top nodes (force_update_node_len_toptree, :1096-1122), and goes on exporting targets.  Here
+ * the cut, the top tree and the import requests of the last decomposition stay; the caller hands its own rows over again
+ * (ngravs_update_particles: same rows, drifted positions) and ngravs_host_kept_step() (ngravs_host.h) does the rest with two
+ * collectives: the owners ship the drifted particles of the leaves that were asked for at the decomposition -- the same records in
+ * the same order (ngravs_dd_pack_leaves_kept -> all-to-all-v -> ngravs_dd_refresh_halo); the tree is refit
+ * (ngravs_force_update_tree); the per-leaf sums BY THE MEMBERSHIP OF THE DECOMPOSITION plus the grown side of every leaf's cell in
+ * its owner's tree are all-reduced (ngravs_dd_leaf_sums_kept: NGRAVS_TOP_CW + 1 doubles per leaf) and set
+ * (ngravs_dd_update_top: node sums as for ngravs_dd_set_top, one side per leaf).  The refit tree is then the single task's refit
+ * tree wherever this task's targets look.  NGRAVS_ERR_STATE without a kept decomposition (none yet, rows changed, single task). */
+int ngravs_dd_leaf_sums_kept(ngravs_ctx *ctx, void **dev_sums, int64_t *count);
+int ngravs_dd_pack_leaves_kept(ngravs_ctx *ctx, int64_t *counts, void **dev_records, int64_t *nrec);
+int ngravs_dd_refresh_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
+int ngravs_dd_update_top(ngravs_ctx *ctx, const double *node_sums, const double *leaf_len);
+/* the plan of the kept decomposition (host memory of the context, valid until the next decomposition): this task's rank and the
+ * task count, owner of every leaf, present[leaf] (own or imported here), global sums of every top node */
+int ngravs_dd_get_kept(ngravs_ctx *ctx, int32_t *rank, int32_t *world, const int32_t **leaf_owner, const uint8_t **present,
+                       const double **node_sums);
 int ngravs_dd_set_ids(ngravs_ctx *ctx, const int64_t *ids, int on_device);
 int ngravs_dd_get_ids(ngravs_ctx *ctx, int64_t *ids, int on_device);
 /* ---- pmforce_periodic() for many tasks: x-slab decomposed mesh -----------------------------------------------------------

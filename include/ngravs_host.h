@@ -114,6 +114,12 @@ int ngravs_host_domain_owners(ngravs_ctx *ctx, const ngravs_comm *comm, double l
                               ngravs_dd_info *info);
 int ngravs_host_domain_halo(ngravs_ctx *ctx, const ngravs_comm *comm, const ngravs_dd_plan *plan, ngravs_dd_info *info);
 void ngravs_host_plan_free(ngravs_dd_plan *plan);
+/* A step on which the decomposition is kept (domain.c:76, All.TreeDomainUpdateFrequency > 0): after ngravs_update_particles() with
+ * the own rows' drifted positions -- the imported copies are refreshed by their owners (one all-to-all-v with the requests of the
+ * decomposition), the tree is refit, and the global moments and cell sides of the top nodes are renewed from one all-reduce of
+ * per-leaf sums (force_update_pseudoparticles forcetree.c:753, force_update_node_len_toptree :1096-1122).  The refit tree is the
+ * single task's refit tree wherever this task's targets look.  Collective.  NGRAVS_ERR_STATE without a kept decomposition. */
+int ngravs_host_kept_step(ngravs_ctx *ctx, const ngravs_comm *comm, ngravs_dd_info *info);
 /* Every callback of the communicator once, with known answers (include/ngravs_comm_selftest.h: collective-safe -- every task runs
  * every stage and all tasks return the same status: 0, or bits 0-2 for the stage that gave a wrong answer on some task, bit 3 for a
  * missing buffer).  Collective.  ctx: the context whose device holds the exchange buffers of a device_buffers communicator (may be

@@ -1139,3 +1139,44 @@ def test_group_walk_unequal_softenings(pkg, O):
     print("unequal softenings: strict rms %.2e, group rms %.2e vs periodic direct sum; group vs strict median %.1e; ia %.0f / %.0f"
           % (rms(e_s), rms(e_g), np.median(d), out[pkg.WALK_STRICT][1].mean(), out[pkg.WALK_GROUP][1].mean()))
     assert rms(e_g) <= 1.05 * rms(e_s) + 1e-3 and np.median(d) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wiring,ng,pmgrid,soft", [("newton", 1, 32, "one"), ("newton", 1, 256, "one"), ("c4", 2, 64, "one"), ("c4", 2, 256, "one"),
+                                                   ("c4", 3, 256, "one"), ("c4", 2, 256, "two"), ("newton", 1, 256, "two")])
+def test_ring_pool_kernel_is_the_synchronous_kernel(pkg, wiring, ng, pmgrid, soft):
+    """The ring-pool evaluation kernel (kernels_eval.hip: per-lane cursors, trip loop / cull in assembly) against the synchronous one
+    (k_walk_group2<..., 2>, tuning walk_ring = 0) on the same item lists: identical interaction counts for every particle, forces to
+    rounding (the two sum a target's pairs in different orders).  The cases walk through the kernel's variants: with / without a
+    Yukawa law, the Yukawa factor through the table bins (PMGRID 256: ym * bin width < 1e-3) or through exp(), one softening length
+    (assembly cull) or two (type bytes), both opening criteria, 5 / 6 / 4 ring slots.  (PMGRID 256 without a Yukawa law is the C3
+    bench's case: its exp table is not staged, the softening lengths sit right behind the tables.)"""
+    n, L = 60000, 1.0
+    pos, mass, typ = pkg.ic.uniform_box(n, box=L, n_gravs=ng, seed=91)
+    pos[: n // 3] = np.mod(0.4 + 0.04 * np.random.default_rng(5).standard_normal((n // 3, 3)), 1.0)   # a clump: softened pairs
+    eps = L / (40 * n ** (1 / 3))
+    softening = [eps] * 6 if soft == "one" else [eps, eps, 2.5 * eps, eps, 1.7 * eps, eps]
+    out = {}
+    for name, tune in (("sync", {"walk_ring": 0}), ("ring", {}), ("ring4", {"walk_ring_k": 4})):
+        cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=softening,
+                              type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=pkg.WALK_GROUP)
+        eng = _engine(pkg, cfg, pos, mass, typ, tuning=tune)
+        eng.compute_accelerations(pm_step=True)
+        a1, o1, c1 = eng.get_accel()
+        eng.set_old_acc(o1)
+        eng.set_opening(0.0, 0.005)
+        eng.gravity_tree()
+        a2, _, c2 = eng.get_accel()
+        out[name] = (a1, c1, a2, c2, eng.stats().reserved[3])
+        eng.close()
+    s = out["sync"]
+    for name in ("ring", "ring4"):
+        r = out[name]
+        for k in (0, 2):
+            na = np.linalg.norm(s[k], axis=1)       # (a particle with nothing inside the cut has no short-range force at all)
+            e = np.linalg.norm(r[k] - s[k], axis=1) / np.maximum(na, 1e-6 * np.median(na))
+            print("%s %s ng %d pmgrid %d %s: pass %d max |da|/|a| %.1e, trips per group %.1f (synchronous %.1f)" %
+                  (name, wiring, ng, pmgrid, soft, k // 2 + 1, e.max(), r[4], s[4]))
+            assert np.array_equal(r[k + 1], s[k + 1])
+            assert e.max() < 1e-11
+        assert r[4] < s[4]
