@@ -155,6 +155,9 @@ struct TopTree
   std::vector<int> h_leaf_owner;       // host copies of the last decomposition's plan
   std::vector<unsigned char> h_present;
   std::vector<double> h_node_sums;
+  DevBuf<int> kept_row;                // kept decomposition: the own row in every slot of the leaf-import records (k_dd_fill's order)
+  std::vector<int64_t> kept_counts;    // ... records per receiving task
+  long long kept_total = -1;
   DevBuf<double> kept_sums;            // per leaf: TOP_CW + 1 doubles (the last one: the grown side of the leaf's cell, from its owner) + 1 status word
   DevBuf<double> leaf_len;             // per leaf: grown side of its cell (all tasks' maximum), for the pseudo nodes of a refit
 };

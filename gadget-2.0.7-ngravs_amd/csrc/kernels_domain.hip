@@ -531,7 +531,7 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
                                                               const unsigned char *__restrict__ active, const long long *__restrict__ id,
                                                               const double *__restrict__ cost, const unsigned long long *__restrict__ offs,
                                                               unsigned long long *__restrict__ cursor, double *__restrict__ out,
-                                                              const double *__restrict__ pm, int rdbl)
+                                                              const double *__restrict__ pm, int rdbl, int *__restrict__ slot_row)
 {
   __shared__ unsigned int lcnt[64];                                 // per destination: records of this block
   __shared__ unsigned long long lbase[64];                          // ... and where they start
@@ -585,7 +585,10 @@ __global__ __launch_bounds__(DD_FILL_THREADS) void k_dd_fill(const unsigned long
       const unsigned long long b = __builtin_amdgcn_ballot_w64(mine);
       if(mine)
         {
-          double *o = out + (size_t)(lbase[r] + woff[wave][r] + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))) * rdbl;
+          const unsigned long long slot = lbase[r] + woff[wave][r] + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+          double *o = out + (size_t)slot * rdbl;
+          if(slot_row)   // (the order of the records is the order the blocks arrived in: a later pack of the SAME rows reads it here)
+            slot_row[slot] = (int)i;
           o[0] = rec.x;
           o[1] = rec.y;
           o[2] = rec.z;
@@ -802,7 +805,7 @@ int dd_leaf_sums(ngravs_ctx *c, void **dev_sums, int64_t *count)
 }
 
 // records of the own particles grouped by destination; mask[i] = bit per receiving task (set by the caller's kernel)
-static int dd_pack_masked(ngravs_ctx *c, int what, int nranks, int64_t *counts, void **dev_records, int64_t *nrec)
+static int dd_pack_masked(ngravs_ctx *c, int what, int nranks, int64_t *counts, void **dev_records, int64_t *nrec, DevBuf<int> *slot_row = nullptr)
 {
   const long long n = c->n_local;
   unsigned nb = (unsigned)((n + 255) / 256);
@@ -821,14 +824,15 @@ static int dd_pack_masked(ngravs_ctx *c, int what, int nranks, int64_t *counts, 
       tot += h[r];
     }
   const int rdbl = dd_record_doubles(c, what);
-  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(double) * rdbl))
+  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(double) * rdbl) || (slot_row && slot_row->ensure((size_t)(tot > 0 ? tot : 1))))
     return NGRAVS_ERR_NOMEM;
   if(tot > 0)
     {
       HIP_TRY(c, hipMemcpyAsync(c->dd_counts.p + 65, offs.data(), sizeof(unsigned long long) * 65, hipMemcpyHostToDevice, c->stream));
       hipLaunchKernelGGL(k_dd_fill, dim3((unsigned)((n + DD_FILL_THREADS - 1) / DD_FILL_THREADS)), dim3(DD_FILL_THREADS), 0, c->stream, c->dd_mask.p, n, c->in_pos.p, c->in_mass.p, c->in_type.p,
                          c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, c->dd_counts.p + 65, c->dd_counts.p + 130,
-                         (double *)c->dd_send.p, (what == 0 && c->pm_parked) ? c->pm_orig.p : (const double *)nullptr, rdbl);
+                         (double *)c->dd_send.p, (what == 0 && c->pm_parked) ? c->pm_orig.p : (const double *)nullptr, rdbl,
+                         slot_row ? slot_row->p : (int *)nullptr);
     }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -951,7 +955,10 @@ int dd_pack_leaves(ngravs_ctx *c, const unsigned long long *reqmask, int nranks,
   t.own_leaf_n = n;
   t.kept_rank = me;
   t.kept_world = nranks;
-  return dd_pack_masked(c, 2, nranks, counts, dev_records, nrec);
+  int rc = dd_pack_masked(c, 2, nranks, counts, dev_records, nrec, &t.kept_row);
+  t.kept_counts.assign(counts, counts + nranks);
+  t.kept_total = rc ? -1 : *nrec;
+  return rc;
 }
 
 // ---- kept decomposition: the same cut, the same requests, drifted particles (ngravs_host_kept_step) ---------------------------
@@ -963,21 +970,46 @@ static int kept_ok(const ngravs_ctx *c)
          (int)t.h_present.size() == t.h.nleaf;
 }
 
-// the records of the own particles of every leaf another task asked for at the decomposition: same rows, same order, new positions
+// the records of the own particles of every leaf another task asked for at the decomposition: SAME rows in the SAME slots (the
+// receivers refresh their copies row by row), new positions.  The slots are those k_dd_fill handed out then (t.kept_row).
+__global__ void k_dd_fill_kept(const int *__restrict__ slot_row, long long nslot, const double *__restrict__ pos, const double *__restrict__ mass,
+                               const int *__restrict__ type, const double *__restrict__ oldacc, const unsigned char *__restrict__ active,
+                               const long long *__restrict__ id, const double *__restrict__ cost, double *__restrict__ out)
+{
+  const long long s = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if(s >= nslot)
+    return;
+  const long long i = slot_row[s];
+  double *o = out + (size_t)s * 7;
+  o[0] = pos[3 * i + 0];
+  o[1] = pos[3 * i + 1];
+  o[2] = pos[3 * i + 2];
+  o[3] = mass[i];
+  o[4] = oldacc[i];
+  o[5] = cost[i];
+  o[6] = __longlong_as_double((long long)type[i] | ((long long)(active[i] & 1) << 8) | (id[i] << 16));
+}
+
 int dd_pack_leaves_kept(ngravs_ctx *c, int64_t *counts, void **dev_records, int64_t *nrec)
 {
   TopTree &t = c->top;
-  if(!kept_ok(c))
+  if(!kept_ok(c) || t.kept_total < 0 || (int)t.kept_counts.size() != t.kept_world)
     return NGRAVS_ERR_STATE;
-  const long long n = c->n_local;
-  if(c->dd_mask.ensure(n > 0 ? n : 1) || c->dd_counts.ensure(3 * 65 + 2))
+  const long long tot = t.kept_total;
+  if(c->dd_send.ensure((size_t)(tot > 0 ? tot : 1) * sizeof(double) * 7))
     return NGRAVS_ERR_NOMEM;
-  HIP_TRY(c, hipMemsetAsync(c->dd_counts.p, 0, sizeof(unsigned long long) * (3 * 65 + 2), c->stream));
-  if(n > 0)
-    hipLaunchKernelGGL(k_dd_dest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->in_pos.p, n, c->dom[0], c->dom[1], c->dom[2], 0.0,
-                       t.child.p, t.leaf.p, (const int *)nullptr, t.reqmask.p, t.kept_rank, c->dd_mask.p, (int *)nullptr, (int *)nullptr,
-                       t.own_leaf.p);
-  return dd_pack_masked(c, 2, t.kept_world, counts, dev_records, nrec);
+  if(tot > 0)
+    hipLaunchKernelGGL(k_dd_fill_kept, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, t.kept_row.p, tot, c->in_pos.p, c->in_mass.p,
+                       c->in_type.p, c->in_oldacc.p, c->in_active.p, c->in_id.p, c->in_cost.p, (double *)c->dd_send.p);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  for(int r = 0; r < t.kept_world; r++)
+    counts[r] = t.kept_counts[r];
+  *dev_records = c->dd_send.p;
+  *nrec = tot;
+  c->dd_last_what = 2;
+  c->dd_last_sent = tot;
+  return NGRAVS_OK;
 }
 
 // per leaf, by the membership of the decomposition: the sums of ngravs_dd_leaf_sums + one more word, the grown side of the leaf's

@@ -283,6 +283,15 @@ class DistributedEngine(Engine):
         self.timings["migrated"], self.timings["halo"] = int(self.info.n_migrated_in), int(self.info.n_halo)
         self.n = self.num_local()
 
+    def kept_step(self, pos, mass, ptype, old_acc=None, active=None):
+        """A step that KEEPS the decomposition (domain.c:76 with All.TreeDomainUpdateFrequency > 0): the own rows (in the order of
+        local_ids()) with their drifted positions; the imported copies are refreshed by their owners, the tree is refit, the top
+        nodes get their global moments and sides again (ngravs_host_kept_step: two collectives).  Then gravity_tree() as usual."""
+        self.n = self.num_local()
+        self.update_particles(pos, mass, ptype, old_acc=old_acc, active=active)
+        self._L.ngravs_host_kept_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._host(self._L.ngravs_host_kept_step(self._h, C.byref(self.comm.c), C.byref(self.info)), "ngravs_host_kept_step")
+
     def pmforce_periodic(self):
         self._host(self._L.ngravs_host_pmforce_periodic(self._h, C.byref(self.comm.c)), "ngravs_host_pmforce_periodic")
 

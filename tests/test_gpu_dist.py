@@ -758,3 +758,83 @@ def test_three_rank_domain_decomposition(pkg, tmp_path):
     e = np.linalg.norm((acc + pm)[idx] - truth, axis=1) / np.linalg.norm(truth, axis=1)
     e_ref = np.linalg.norm(gold["ref_total"] - truth, axis=1) / np.linalg.norm(truth, axis=1)
     assert np.sqrt(np.mean(e ** 2)) <= np.sqrt(np.mean(e_ref ** 2))
+
+
+def _kept_positions(pos0, L, step):
+    """small deterministic drifts (a fraction of the mean spacing per step): what happens between two decompositions"""
+    n = len(pos0)
+    d = 0.0015 * step * np.sin(2 * np.pi * (pos0[:, [1, 2, 0]] * 3.1 + 0.17 * step)) + 0.0007 * step * np.cos(5.0 * pos0[:, [2, 0, 1]])
+    return np.mod(pos0 + L * d, L) if L > 0 else pos0 + d
+
+
+NKEPT = 4
+
+
+def _kept_worker(rank, world, port, out_dir, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import importlib
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = ge.load_package()
+    dd = importlib.import_module("ngravs_amd.distributed")
+    pos0, mass, typ, old0, cfg = _strict_case(pkg, case)
+    n, L = len(pos0), cfg.box_size if cfg.periodic else 0.0
+    eng = dd.DistributedEngine(cfg, leaf_max=300.0)
+    ids = np.arange(rank, n, world)
+    eng.set_particles(pos0[ids], mass[ids], typ[ids], old_acc=old0[ids], ids=ids)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    ids = eng.local_ids()
+    a, o, c = eng.get_accel()[:3]
+    out = {"ids": ids, "acc0": a, "cost0": c, "old0": o}
+    for step in range(1, NKEPT):
+        pos = _kept_positions(pos0, L, step)
+        eng.kept_step(pos[ids], mass[ids], typ[ids], old_acc=o)
+        eng.gravity_tree()
+        a, o, c = eng.get_accel()[:3]
+        assert np.array_equal(eng.local_ids(), ids)                     # nothing migrates on a kept step
+        out.update({"acc%d" % step: a, "cost%d" % step: c, "old%d" % step: o,
+                    "info%d" % step: np.array([eng.info.collectives, eng.info.n_halo, 1e3 * sum(eng.info.seconds[k] for k in (2, 4, 5, 6))])})
+    np.savez(os.path.join(out_dir, "kp%d.npz" % rank), **out)
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["c4", "plummer"])
+def test_three_rank_kept_decomposition(pkg, tmp_path, case):
+    """Steps that KEEP the decomposition (domain.c:76, All.TreeDomainUpdateFrequency > 0) on three tasks: after one full
+    decomposition the particles drift a little three times; every task hands its own rows over again (ngravs_update_particles),
+    ngravs_host_kept_step() refreshes the imported copies (one all-to-all-v with the requests of the decomposition), refits the
+    tree and renews the global moments and cell sides of the top nodes (one all-reduce).  The reference walk on these trees gives
+    the forces, OldAcc and interaction counts of the SINGLE task's refit tree (ngravs_update_particles + ngravs_force_update_tree:
+    force_update_len / force_update_pseudoparticles, forcetree.c:753, 1005-1122)."""
+    import torch.multiprocessing as mp
+    world = 3
+    port = 27300 + (os.getpid() % 2000)
+    mp.spawn(_kept_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    pos0, mass, typ, old0, cfg = _strict_case(pkg, case)
+    n, L = len(pos0), cfg.box_size if cfg.periodic else 0.0
+    res = [np.load(os.path.join(str(tmp_path), "kp%d.npz" % r)) for r in range(world)]
+    eng = pkg.Engine(cfg)
+    eng.set_particles(pos0, mass, typ, old_acc=old0)
+    eng.compute_accelerations(pm_step=bool(cfg.pmgrid))
+    a1, o1, c1 = eng.get_accel()[:3]
+    for step in range(NKEPT):
+        if step > 0:
+            eng.update_particles(_kept_positions(pos0, L, step), mass, typ, old_acc=o1)
+            eng.gravity_tree()
+            a1, o1, c1 = eng.get_accel()[:3]
+        acc, oa, cost, seen = np.zeros((n, 3)), np.zeros(n), np.zeros(n), np.zeros(n, dtype=np.int64)
+        for d in res:
+            ids = d["ids"]
+            acc[ids], oa[ids], cost[ids] = d["acc%d" % step], d["old%d" % step], d["cost%d" % step]
+            seen[ids] += 1
+        assert np.all(seen == 1)
+        err = np.linalg.norm(acc - a1, axis=1) / np.linalg.norm(a1, axis=1)
+        print("step %d (%s): counts equal for %.4f of the particles; |da|/|a| max %.1e; OldAcc %.1e%s" %
+              (step, "decomposition" if step == 0 else "kept", np.mean(cost == c1), err.max(), np.abs(oa - o1).max() / o1.max(),
+               "" if step == 0 else "; collectives %d, imported rows %d, kept-step host ms %.2f" % tuple(res[0]["info%d" % step])))
+        assert np.array_equal(cost, c1) and err.max() < 1e-10 and np.abs(oa - o1).max() < 1e-10 * o1.max()
+    eng.close()
