@@ -34,7 +34,7 @@ EXPORTS = [
     "ngravs_get_domain", "ngravs_get_keys", "ngravs_get_order", "ngravs_get_shard", "ngravs_last_error",
     "ngravs_peano_hilbert_key", "ngravs_peano_keys", "ngravs_shortrange_table", "ngravs_direct_sum", "ngravs_direct_sum_targets",
     "ngravs_dd_num_local", "ngravs_dd_local_extent", "ngravs_dd_set_extent", "ngravs_get_domain_extent", "ngravs_dd_set_toptree",
-    "ngravs_dd_get_toptree", "ngravs_dd_peano_order", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_pack", "ngravs_dd_get_dest",
+    "ngravs_dd_get_toptree", "ngravs_dd_peano_order", "ngravs_dd_leaf_sums", "ngravs_dd_target_bounds", "ngravs_dd_keep_margin", "ngravs_dd_pack", "ngravs_dd_get_dest",
     "ngravs_dd_pack_leaves", "ngravs_dd_set_top", "ngravs_dd_recv_buffer", "ngravs_dd_apply_migration", "ngravs_dd_set_halo",
     "ngravs_dd_leaf_sums_kept", "ngravs_dd_pack_leaves_kept", "ngravs_dd_refresh_halo", "ngravs_dd_update_top", "ngravs_dd_get_kept",
     "ngravs_dd_set_ids", "ngravs_dd_get_ids",
@@ -44,7 +44,7 @@ EXPORTS = [
 HOST_EXPORTS = ["ngravs_host_comm_selftest", "ngravs_host_kept_step", "ngravs_host_toptree_borrow", "ngravs_host_domain_decomposition", "ngravs_host_domain_owners", "ngravs_host_domain_halo",
                 "ngravs_host_plan_free", "ngravs_host_pmforce_periodic", "ngravs_host_compute_accelerations", "ngravs_host_split",
                 "ngravs_host_pm_seconds", "ngravs_host_toptree_init", "ngravs_host_toptree_from_children", "ngravs_host_toptree_adapt",
-                "ngravs_host_toptree_free", "ngravs_host_import_request"]
+                "ngravs_host_toptree_free", "ngravs_host_import_request", "ngravs_host_import_request_margin"]
 # include/ngravs_comm_rccl.h (libngravs_rccl.so: the communicator vtable over RCCL, plain C)
 RCCL_LIB_PATH = os.path.join(_HERE, "libngravs_rccl.so")
 RCCL_EXPORTS = ["ngravs_rccl_selftest", "ngravs_rccl_unique_id", "ngravs_rccl_create", "ngravs_rccl_fill", "ngravs_rccl_destroy", "ngravs_rccl_stats",

@@ -484,6 +484,8 @@ extern "C" int ngravs_set_tuning(ngravs_ctx *c, const char *name, double v)
     t.pm_tile8 = iv != 0;
   else if(k == "tree_levelwise")
     t.tree_levelwise = iv != 0;
+  else if(k == "dd_keep" && v >= 0 && v <= 0.25)
+    t.dd_keep = v;
   else if(k == "moments_octet")
     t.moments_octet = iv != 0;
   else
@@ -558,8 +560,16 @@ static double ev_ms(ngravs_ctx *c);
 
 static int set_particles_impl(ngravs_ctx *c, const ngravs_particles_t *p, bool keep_tree)
 {
-  if(!c || !p || p->n < 0 || (p->n > 0 && (!p->pos || !p->mass || !p->type)) || (p->n == 0 && keep_tree))
+  if(!c || !p || p->n < 0 || (p->n > 0 && (!p->pos || !p->mass || !p->type)))
     return NGRAVS_ERR_ARG;
+  if(p->n == 0 && keep_tree)
+    {
+      // a task without own particles on a kept step of several tasks: its working set is imported copies (or nothing)
+      if(!c->have_particles || c->n_local != 0)
+        return NGRAVS_ERR_STATE;
+      c->tree_stale = c->have_tree;
+      return NGRAVS_OK;
+    }
   if(p->n == 0)
     {
       // a task without particles (NumPart = 0): legal with several tasks -- it still owns mesh slabs, takes part in every
@@ -731,6 +741,11 @@ extern "C" int ngravs_force_update_tree(ngravs_ctx *c)
   if(!c || !c->have_order || !c->have_tree)
     return NGRAVS_ERR_STATE;
   (void)hipSetDevice(c->cfg.device);
+  if(c->n == 0)   // an empty working set (a task without particles): no nodes to refit
+    {
+      c->tree_stale = false;
+      return NGRAVS_OK;
+    }
   HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
   int rc = dom_regather(c);
   if(rc)
@@ -1139,33 +1154,52 @@ extern "C" int ngravs_get_stats(ngravs_ctx *c, ngravs_stats_t *out)
 }
 
 // ---- kept decomposition (include/ngravs_hip.h, ngravs_host_kept_step)
+static std::string kept_state(const ngravs_ctx *c, const char *who)
+{
+  char b[320];
+  snprintf(b, sizeof(b), "%s: no kept decomposition to work on (own rows %lld, rows at the cut %lld, working set %lld, tree %d, top %d, task %d of %d)", who,
+           (long long)c->n_local, (long long)c->top.own_leaf_n, (long long)c->n, (int)c->have_tree, (int)c->top.on, c->top.kept_rank, c->top.kept_world);
+  return std::string(b);
+}
 extern "C" int ngravs_dd_leaf_sums_kept(ngravs_ctx *c, void **dev_sums, int64_t *count)
 {
   if(!c || !dev_sums || !count)
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  return dd_leaf_sums_kept(c, dev_sums, count);
+  const int rc = dd_leaf_sums_kept(c, dev_sums, count);
+  if(rc == NGRAVS_ERR_STATE)
+    ngravs_report(c, rc, kept_state(c, "ngravs_dd_leaf_sums_kept"));
+  return rc;
 }
 extern "C" int ngravs_dd_pack_leaves_kept(ngravs_ctx *c, int64_t *counts, void **dev_records, int64_t *nrec)
 {
   if(!c || !counts || !dev_records || !nrec)
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  return dd_pack_leaves_kept(c, counts, dev_records, nrec);
+  const int rc = dd_pack_leaves_kept(c, counts, dev_records, nrec);
+  if(rc == NGRAVS_ERR_STATE)
+    ngravs_report(c, rc, kept_state(c, "ngravs_dd_pack_leaves_kept"));
+  return rc;
 }
 extern "C" int ngravs_dd_refresh_halo(ngravs_ctx *c, const void *dev_records, int64_t nrec)
 {
   if(!c || nrec < 0 || (nrec > 0 && !dev_records))
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  return dd_refresh_halo(c, dev_records, nrec);
+  const int rc = dd_refresh_halo(c, dev_records, nrec);
+  if(rc == NGRAVS_ERR_STATE)
+    ngravs_report(c, rc, kept_state(c, "ngravs_dd_refresh_halo"));
+  return rc;
 }
 extern "C" int ngravs_dd_update_top(ngravs_ctx *c, const double *node_sums, const double *leaf_len)
 {
   if(!c)
     return NGRAVS_ERR_ARG;
   (void)hipSetDevice(c->cfg.device);
-  return dd_update_top(c, node_sums, leaf_len);
+  const int rc = dd_update_top(c, node_sums, leaf_len);
+  if(rc == NGRAVS_ERR_STATE)
+    ngravs_report(c, rc, kept_state(c, "ngravs_dd_update_top"));
+  return rc;
 }
 extern "C" int ngravs_dd_get_kept(ngravs_ctx *c, int32_t *rank, int32_t *world, const int32_t **leaf_owner, const uint8_t **present,
                                   const double **node_sums)
@@ -1175,7 +1209,10 @@ extern "C" int ngravs_dd_get_kept(ngravs_ctx *c, int32_t *rank, int32_t *world, 
   const TopTree &t = c->top;
   if(!(t.on && t.h.nnode > 0 && t.own_leaf_n == c->n_local && t.kept_rank >= 0 && (int)t.h_leaf_owner.size() == t.h.nleaf &&
        (int)t.h_present.size() == t.h.nleaf))
-    return NGRAVS_ERR_STATE;
+    {
+      ngravs_report(c, NGRAVS_ERR_STATE, kept_state(c, "ngravs_dd_get_kept"));
+      return NGRAVS_ERR_STATE;
+    }
   if(rank)
     *rank = t.kept_rank;
   if(world)
@@ -1424,6 +1461,14 @@ extern "C" int ngravs_get_domain_extent(ngravs_ctx *c, double out[8])
   if(!c || !c->extent_override || !out)
     return NGRAVS_ERR_STATE;
   memcpy(out, c->dom, sizeof(double) * 8);
+  return NGRAVS_OK;
+}
+
+extern "C" int ngravs_dd_keep_margin(ngravs_ctx *c, double *margin)
+{
+  if(!c || !margin)
+    return NGRAVS_ERR_ARG;
+  *margin = c->tune.dd_keep * c->dom[6];
   return NGRAVS_OK;
 }
 

@@ -125,6 +125,7 @@ struct Tuning
   int sort_full = 0;        // Peano order by one radix sort on all 63 key bits (default: top 42 bits + fix-up of the rare ties)
   int tree_levelwise = 0;   // build the tree level by level (the multi-task path) also for single-task trees
   int moments_octet = 0;
+  double dd_keep = 0;       // > 0: the next decompositions will be KEPT for some steps -- import for ALL own particles (not only the active ones), own boxes grown by dd_keep x the domain's side
   int walk_ring = 1;        // TreePM evaluation through the ring-pool kernel (kernels_eval.hip); 0: k_walk_group2<...,2>
   int walk_ring_k = 0;      // ... with at most this many slots per wave (0: as many as fit, at most 8)    // moments pass with eight lanes per node (k_moments8; measured slower: 5.7 against 5.0 ms of build at C4)
 };

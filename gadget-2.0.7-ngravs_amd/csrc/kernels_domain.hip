@@ -868,11 +868,11 @@ int dd_pack(ngravs_ctx *c, int what, const int *leaf_owner, int nranks, int me, 
 // smallest ErrTolForceAcc * OldAcc and smallest softening length over the own ACTIVE particles: what the conservative
 // opening tests of a whole domain need (the group walk uses the same two minima per group)
 __global__ void k_dd_bounds(const double *__restrict__ oldacc, const int *__restrict__ type, const unsigned char *__restrict__ active,
-                            long long n, WalkParams wp, double *__restrict__ out)
+                            long long n, WalkParams wp, double *__restrict__ out, int all)
 {
   double a = 1e300, h = 1e300;
   for(long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    if(active[i] & 1)
+    if((active[i] & 1) || all)   // (all: a decomposition that will be kept -- every own particle is a target of one of its steps)
       {
         a = fmin(a, wp.errtol_acc * oldacc[i]);
         h = fmin(h, wp.fsoft[type[i]]);
@@ -904,7 +904,7 @@ int dd_target_bounds(ngravs_ctx *c, double out[2])
   make_walk_params(c, &wp);
   if(c->n_local > 0)
     hipLaunchKernelGGL(k_dd_bounds, dim3(2048), dim3(256), 0, c->stream, c->in_oldacc.p, c->in_type.p, c->in_active.p, (long long)c->n_local,
-                       wp, c->red_tmp.p);
+                       wp, c->red_tmp.p, c->tune.dd_keep > 0 ? 1 : 0);
   HIP_TRY(c, hipMemcpyAsync(out, c->red_tmp.p, sizeof(big), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NGRAVS_OK;
@@ -917,6 +917,8 @@ int dd_get_dest(ngravs_ctx *c, const int *leaf_owner, int *dest)
   const long long n = c->n_local;
   if(t.h.nnode < 1)
     return NGRAVS_ERR_STATE;
+  t.h_leaf_owner.assign(leaf_owner, leaf_owner + t.h.nleaf);   // (also on a task without particles: the cut is what a kept step goes by)
+  t.own_leaf_n = -1;
   if(n <= 0)
     return NGRAVS_OK;
   DevBuf<int> d;

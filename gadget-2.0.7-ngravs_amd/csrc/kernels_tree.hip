@@ -970,6 +970,8 @@ int tree_top_leaf_len(ngravs_ctx *c, double *dev_kept_sums, int stride)
   const TopTree &t = c->top;
   if(!c->have_tree || !t.on)
     return NGRAVS_ERR_STATE;
+  if(c->n == 0)   // (a task without particles and without imported copies: no tree nodes)
+    return NGRAVS_OK;
   for(int l = (t.h.depth < c->nlevels - 1 ? t.h.depth : c->nlevels - 1); l >= 0; l--)
     {
       const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;
@@ -1030,6 +1032,8 @@ int tree_top_refit(ngravs_ctx *c)
   const TopTree &t = c->top;
   if(!c->have_tree || !t.on)
     return NGRAVS_ERR_STATE;
+  if(c->n == 0)   // (a task without particles and without imported copies: no tree nodes)
+    return NGRAVS_OK;
   for(int l = (t.h.depth < c->nlevels - 1 ? t.h.depth : c->nlevels - 1); l >= 0; l--)
     {
       const long long l0 = c->level_start[l], lc = c->level_start[l + 1] - l0;

@@ -245,6 +245,7 @@ class DistributedEngine(Engine):
         L.ngravs_dd_num_local.argtypes = [C.c_void_p]
         L.ngravs_host_domain_decomposition.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.ngravs_host_pmforce_periodic.argtypes = [C.c_void_p, C.c_void_p]
+        L.ngravs_host_kept_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ngravs_pm_slab_bytes.argtypes = [C.c_void_p, C.c_void_p]
 
     def _host(self, rc, what):
@@ -289,7 +290,6 @@ class DistributedEngine(Engine):
         nodes get their global moments and sides again (ngravs_host_kept_step: two collectives).  Then gravity_tree() as usual."""
         self.n = self.num_local()
         self.update_particles(pos, mass, ptype, old_acc=old_acc, active=active)
-        self._L.ngravs_host_kept_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         self._host(self._L.ngravs_host_kept_step(self._h, C.byref(self.comm.c), C.byref(self.info)), "ngravs_host_kept_step")
 
     def pmforce_periodic(self):

@@ -378,7 +378,11 @@ static void exchange_particles(const int32_t *dest)
  * the export / import loop of gravtree.c:112-285).  The import is decided for the opening criterion and the OldAcc in force NOW:
  * DdUseTheta remembers which.  again != 0: P[] has already been handed over for this step and GravPM computed (the second
  * gravity_tree() of a first step, see there). */
+#ifndef NGRAVS_GLUE_KEEP_MARGIN
+#define NGRAVS_GLUE_KEEP_MARGIN 0.002	/* of the domain cube's side: the drift a kept decomposition allows for before it is cut again */
+#endif
 static int DdUseTheta = -1;
+static int KeptStep = 0;		/* this step walks the kept decomposition of several tasks (ngravs_host_kept_step) */
 static long long NumImported = 0;	/* copies of other tasks' particles in this task's tree (the last decomposition) */
 static void decompose_several_tasks(int again)
 {
@@ -390,6 +394,8 @@ static void decompose_several_tasks(int again)
       PushGravPM = 1;
       push_particles(0);
     }
+  /* a decomposition that will serve several steps (domain.c:76) imports for all own particles, with room to drift */
+  must(ngravs_set_tuning(Ctx, "dd_keep", All.TreeDomainUpdateFrequency > 0 ? NGRAVS_GLUE_KEEP_MARGIN : 0.0), 1076);
   must(ngravs_set_opening(Ctx, All.ErrTolTheta, All.ErrTolForceAcc), 1062);
   must(ngravs_host_domain_owners(Ctx, &Comm, 0, All.PartAllocFactor, &plan, &info), 1058);
   dest = malloc(sizeof(int32_t) * (NumPart > 0 ? NumPart : 1));
@@ -415,7 +421,11 @@ void domain_Decomposition(void)
   if(All.PM_Ti_endstep == All.Ti_Current)	/* domain.c:66-73: PM steps always re-decompose (particles get wrapped) */
     All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart * All.TreeDomainUpdateFrequency;
 #endif
-  if(NTask > 1 || All.NumForcesSinceLastDomainDecomp > All.TotNumPart * All.TreeDomainUpdateFrequency)	/* domain.c:76 */
+  KeptStep = 0;
+  /* domain.c:76.  Several tasks keep a decomposition the same way one task keeps its tree: same cut, same top tree, same imported
+   * leaves (DdUseTheta >= 0: there is one) -- the copies follow their originals and the top nodes get their moments and sides
+   * again, two collectives (ngravs_host_kept_step; force_update_pseudoparticles + force_update_node_len_toptree there). */
+  if((NTask > 1 && DdUseTheta < 0) || All.NumForcesSinceLastDomainDecomp > All.TotNumPart * All.TreeDomainUpdateFrequency)
     {
       t0 = second();
 #ifdef PERIODIC
@@ -451,8 +461,17 @@ void domain_Decomposition(void)
 	All.CPU_Domain += timediff(t0, t1) - st.t_peano;
       }
     }
-  else
+  else if(NTask == 1)
     push_particles(1);		/* drifted tree: gravity_tree() refits it (ngravs_force_update_tree) */
+  else
+    {
+      ngravs_dd_info info;
+      t0 = second();
+      push_particles(1);
+      must(ngravs_host_kept_step(Ctx, &Comm, &info), 1075);
+      KeptStep = 1;
+      All.CPU_Domain += timediff(t0, second());
+    }
 }
 
 /* proto.h:89, :96 -- the library recomputes node moments and cell sides from the particles (ngravs_force_update_tree);
@@ -645,6 +664,28 @@ void gravity_tree(void)
   if(NumPart > 0)
     must(ngravs_set_old_acc(Ctx, &P[0].OldAcc, sizeof(struct particle_data), 0), 1074);
   must(ngravs_gravity_tree(Ctx), 1063);
+  if(KeptStep)
+    {
+      /* the imported leaves were chosen at the decomposition; the particles have moved since.  A walk of ANY task that wanted a
+       * leaf it does not hold (the library walked it as a monopole and counted it) sends all tasks through a new decomposition
+       * and this walk again -- the reference's export follows whatever the walk opens, so it has no such case. */
+      int64_t want = 0;
+      long long mine, any = 0;
+      (void)ngravs_walk_unopened(Ctx, &want);
+      mine = (long long)want;
+      MPI_Allreduce(&mine, &any, 1, MPI_LONG_LONG, MPI_MAX, MPI_COMM_WORLD);
+      KeptStep = 0;
+      if(any > 0)
+	{
+	  if(ThisTask == 0)
+	    printf("ngravs-hip: a kept decomposition no longer holds the leaves the walk opens: decomposing again\n");
+	  decompose_several_tasks(1);
+	  All.NumForcesSinceLastDomainDecomp = 0;
+	  if(NumPart > 0)
+	    must(ngravs_set_old_acc(Ctx, &P[0].OldAcc, sizeof(struct particle_data), 0), 1074);
+	  must(ngravs_gravity_tree(Ctx), 1063);
+	}
+    }
   /* only particles with Ti_endstep == Ti_Current are written (gravtree.c:318-341); inactive rows of P[] keep their values */
   must(ngravs_get_accel(Ctx, &P[0].GravAccel[0], sizeof(struct particle_data), NULL, 0, &P[0].OldAcc,
 			sizeof(struct particle_data), &P[0].GravCost, sizeof(struct particle_data), 0, 1), 1064);

@@ -596,6 +596,12 @@ static void need_visit(const need_t *T, int32_t node)
 int ngravs_host_import_request(const ngravs_config_t *cfg, const double dom[8], const ngravs_toptree *t, const double *node_sums,
                                const int32_t *leaf_owner, int me, const double bounds[2], uint8_t *need)
 {
+  return ngravs_host_import_request_margin(cfg, dom, t, node_sums, leaf_owner, me, bounds, 0.0, need);
+}
+
+int ngravs_host_import_request_margin(const ngravs_config_t *cfg, const double dom[8], const ngravs_toptree *t, const double *node_sums,
+                                      const int32_t *leaf_owner, int me, const double bounds[2], double margin, uint8_t *need)
+{
   need_t T;
   double blo[64][3], bhi[64][3], (*bc)[3], (*bh)[3];
   uint8_t *mine;
@@ -643,7 +649,7 @@ int ngravs_host_import_request(const ngravs_config_t *cfg, const double dom[8], 
             for(j = 0; j < 3; j++)
               {
                 bc[T.nbox][j] = 0.5 * (blo[k][j] + bhi[k][j]);
-                bh[T.nbox][j] = 0.5 * (bhi[k][j] - blo[k][j]) + 1e-9 * dom[6];   /* rounding slack */
+                bh[T.nbox][j] = 0.5 * (bhi[k][j] - blo[k][j]) + 1e-9 * dom[6] + margin;   /* rounding slack; drift while the decomposition is kept */
               }
             T.nbox++;
           }
@@ -1064,7 +1070,7 @@ static int domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_p
 {
   ngravs_dd_info local;
   ngravs_config_t cfg;
-  double dom[8];
+  double dom[8], margin = 0;
   int64_t nleaf, i, sc[65], rcn[65], nrec = 0, nrecv = 0;
   uint8_t *need = NULL, *allneed = NULL, *present = NULL;
   uint64_t *reqmask = NULL;
@@ -1099,7 +1105,9 @@ static int domain_halo(ngravs_ctx *ctx, const ngravs_comm *cm, const ngravs_dd_p
     }
   info->seconds[3] = -wall_now();
   if(!rc)
-    rc = ngravs_host_import_request(&cfg, dom, &plan->tree, plan->node_sums, plan->leaf_owner, me, plan->bounds, need);
+    rc = ngravs_dd_keep_margin(ctx, &margin);
+  if(!rc)
+    rc = ngravs_host_import_request_margin(&cfg, dom, &plan->tree, plan->node_sums, plan->leaf_owner, me, plan->bounds, margin, need);
   info->seconds[3] += wall_now();
   info->seconds[4] = -wall_now();
   if(rc)

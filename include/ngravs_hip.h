@@ -193,6 +193,8 @@ int ngravs_get_config(ngravs_ctx *ctx, ngravs_config_t *out);
  *   "pm_notile" 1: per-particle CIC deposit     "pm_fused_gather" 1: one-pass gradient+gather    "pm_tile_gather" 1: LDS-tiled gather
  *   "pm_tile8" 1: deposit tiles of 8 instead of 16 mesh cells    "tree_levelwise" 1: level-by-level tree build for single-task trees too
  *   "sort_full" 1: Peano order by one radix sort on all key bits (default: top 28 to 42 bits + fix-up of the ties, the same order)
+ *   "dd_keep" f: decompositions are kept over several steps (ngravs_host_kept_step): leaves are imported for ALL own particles as
+ *       targets, whose cells may have grown by f x the domain's side (0 <= f <= 0.25; default 0: import for this step's active targets)
  *   "moments_octet" 1: node moments with eight lanes per node instead of one thread per node (another summation order; slower)
  * Returns NGRAVS_ERR_ARG for an unknown name or a value out of range. */
 int ngravs_set_tuning(ngravs_ctx *ctx, const char *name, double value);
@@ -335,8 +337,12 @@ int ngravs_dd_get_toptree(ngravs_ctx *ctx, int32_t *nnode, const int32_t **child
  * *count = nleaf * NGRAVS_TOP_CW doubles.  The host all-reduces it (in place on the device if it can) and reads it back. */
 #define NGRAVS_TOP_CW(ng) (7 + 4 * (ng))
 int ngravs_dd_leaf_sums(ngravs_ctx *ctx, void **dev_sums, int64_t *count);
-/* min over the own active particles of ErrTolForceAcc * OldAcc and of the softening length: out[2] */
+/* min over the own active particles of ErrTolForceAcc * OldAcc and of the softening length: out[2].  With the tuning "dd_keep" > 0
+ * (a decomposition that will be kept over steps with other active sets, All.TreeDomainUpdateFrequency > 0): over ALL own particles */
 int ngravs_dd_target_bounds(ngravs_ctx *ctx, double out[2]);
+/* "dd_keep" x the side of the domain cube: how far the import decision lets a target drift out of its top leaf's cell while the
+ * decomposition is kept (0: the decomposition serves this step only) */
+int ngravs_dd_keep_margin(ngravs_ctx *ctx, double *margin);
 /* what = 0: the records of the own particles whose leaf belongs to another task (leaf_owner[leaf], host array), grouped by
  * destination; counts[r] records go to task r */
 int ngravs_dd_pack(ngravs_ctx *ctx, int what, const int32_t *leaf_owner, int nranks, int my_rank, int64_t *counts, void **dev_records,
@@ -364,7 +370,7 @@ int ngravs_dd_set_halo(ngravs_ctx *ctx, const void *dev_records, int64_t nrec);
  * The reference drifts its nodes with their velocities, refreshes the other tasks' top-leaf moments (force_update_pseudoparticles,
  * forcetree.c:753) and the sides of the top nodes (force_update_node_len_toptree, :1096-1122), and goes on exporting targets.  Here
  * the cut, the top tree and the import requests of the last decomposition stay; the caller hands its own rows over again
- * (ngravs_update_particles: same rows, drifted positions) and ngravs_host_kept_step() (ngravs_host.h) does the rest with two
+ * (ngravs_update_particles: same rows, drifted positions) and ngravs_host_kept_step in ngravs_host.h does the rest with two
  * collectives: the owners ship the drifted particles of the leaves that were asked for at the decomposition -- the same records in
  * the same order (ngravs_dd_pack_leaves_kept -> all-to-all-v -> ngravs_dd_refresh_halo); the tree is refit
  * (ngravs_force_update_tree); the per-leaf sums BY THE MEMBERSHIP OF THE DECOMPOSITION plus the grown side of every leaf's cell in

@@ -158,6 +158,9 @@ int ngravs_host_split(const double *count, const double *work, int64_t nleaf, in
  * DomainFac; bounds: see ngravs_dd_plan. */
 int ngravs_host_import_request(const ngravs_config_t *cfg, const double dom[8], const ngravs_toptree *t, const double *node_sums,
                                const int32_t *leaf_owner, int me, const double bounds[2], uint8_t *need);
+/* ... with the boxes around the own leaves grown by `margin` on every side (a kept decomposition: ngravs_dd_keep_margin) */
+int ngravs_host_import_request_margin(const ngravs_config_t *cfg, const double dom[8], const ngravs_toptree *t, const double *node_sums,
+                               const int32_t *leaf_owner, int me, const double bounds[2], double margin, uint8_t *need);
 
 #ifdef __cplusplus
 }

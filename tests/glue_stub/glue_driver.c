@@ -19,6 +19,7 @@
 #include <math.h>
 #include <time.h>
 #include <unistd.h>
+#include <signal.h>
 #include <mpi.h>
 #include "allvars.h"
 #include "proto.h"
@@ -59,7 +60,14 @@ void endrun(int code)
 {
   printf("task %d: endrun(%d)\n", ThisTask, code);
   fflush(stdout);
-  _exit(code ? (code & 127) | 1 : 0);   /* (a task that ends the run leaves the others in their barrier: the test's timeout ends them) */
+  /* a task that ends the run would leave the others in their barrier for ever (and on the GPU): the run's tasks are one process
+   * group (mpi_start), which ends here as a whole -- MPI_Abort */
+  if(code && NTask > 1)
+    {
+      usleep(300000);   /* (the other tasks may be on their way to say why) */
+      kill(0, SIGTERM);
+    }
+  _exit(code ? (code & 127) | 1 : 0);
 }
 double get_random_number(int id)   /* a fixed pseudo-random number per particle ID (system.c:26-40 draws from a table of 1000) */
 {
@@ -89,6 +97,8 @@ void do_box_wrapping(void)   /* predict.c:107-133 */
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
+#include <sys/prctl.h>
+#include <signal.h>
 #include <unistd.h>
 #ifndef GLUE_NTASK
 #define GLUE_NTASK 1
@@ -120,6 +130,8 @@ static void mpi_start(void)
   pthread_barrierattr_t at;
   int r;
   NTask = GLUE_NTASK;
+  if(NTask > 1)
+    setpgid(0, 0);   /* the tasks of this run: one process group (endrun) */
   Sh = mmap(NULL, sizeof(*Sh), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
   Slots = mmap(NULL, SLOT * (size_t)NTask, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
   if(Sh == MAP_FAILED || Slots == MAP_FAILED)
@@ -132,6 +144,7 @@ static void mpi_start(void)
     if(fork() == 0)
       {
         ThisTask = r;
+        prctl(PR_SET_PDEATHSIG, SIGKILL);   /* task 0 killed (a test's timeout): no task is left behind on the GPU */
         break;
       }
 }
@@ -452,16 +465,16 @@ int main(int argc, char **argv)
   All.PM_Ti_endstep = 16;
   for(i = 0; i < NumPart; i++)
     P[i].Ti_endstep = ((P[i].ID - 1) % 5 == 2) ? 8 : 16;
-  All.NumForcesSinceLastDomainDecomp = 1 + All.TotNumPart;   /* TreeDomainUpdateFrequency = 0: every step re-decomposes */
+  All.TreeDomainUpdateFrequency = 1.0;
+  All.NumForcesSinceLastDomainDecomp = 1 + 2 * All.TotNumPart;   /* more forces than the frequency allows: this step re-decomposes */
   domain_Decomposition();
   gravity_tree();
   dump(f);
-  if(NTask == 1)
     {
-      /* step 3 (one task): TreeDomainUpdateFrequency > 0 and few forces since the last decomposition -- domain.c:76 keeps
-       * decomposition and tree, the particles have drifted (move_particles, predict.c:36-104: no box wrapping between
-       * decompositions): the glue hands the drifted positions over and the library refits the tree */
-      All.TreeDomainUpdateFrequency = 1.0;
+      /* step 3: TreeDomainUpdateFrequency > 0 and few forces since the last decomposition -- domain.c:76 keeps decomposition and
+       * tree, the particles have drifted (move_particles, predict.c:36-104: no box wrapping between decompositions): the glue
+       * hands the drifted positions over and the library refits the tree; with several tasks the imported copies follow their
+       * originals and the top of the tree is summed again (ngravs_host_kept_step) */
       All.NumForcesSinceLastDomainDecomp = 0;
       All.Ti_Current = 12;
       for(i = 0; i < NumPart; i++)
@@ -475,7 +488,7 @@ int main(int argc, char **argv)
       dump(f);
     }
   fclose(f);
-  printf("glue driver: task %d of %d holds %d particles, N_GRAVS %d, two steps done; TotNumOfForces %lld\n", ThisTask, NTask, NumPart, N_GRAVS,
+  printf("glue driver: task %d of %d holds %d particles, N_GRAVS %d, three steps done; TotNumOfForces %lld\n", ThisTask, NTask, NumPart, N_GRAVS,
          All.TotNumOfForces);
   return mpi_finish(0);
 }

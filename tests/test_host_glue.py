@@ -163,9 +163,9 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
            "-o", exe, "-L" + libdir, "-lngravs_hip"] + (["-lngravs_rccl"] if "-DNGRAVS_WITH_RCCL" in opts else []) + ["-lm", "-lpthread", "-Wl,-rpath," + libdir]
     b = subprocess.run(cmd, capture_output=True, text=True)
     assert b.returncode == 0, b.stderr[-3000:]
-    r = subprocess.run([exe, fin, fout, str(tmp_path) + "/"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, fin, fout, str(tmp_path) + "/"], capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
-    nstep = 3 if ntask == 1 else 2
+    nstep = 3
     out = np.zeros((nstep, n, 8))
     seen = np.zeros((nstep, n), dtype=np.int64)
     own = []
@@ -227,8 +227,9 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
     eng.compute_accelerations(pm_step=False)
     a3, o3, c3 = a2.copy(), o2.copy(), c2.copy()
     eng.get_accel(into=(a3, o3, c3))
-    if ntask == 1:
-        # step 3: the drifted tree (domain.c:76 keeps decomposition and tree; the glue hands drifted positions over, the library refits)
+    if True:
+        # step 3: the drifted tree (domain.c:76 keeps decomposition and tree; the glue hands drifted positions over, the library refits;
+        # several tasks: the kept decomposition, ngravs_host_kept_step)
         idn = np.arange(1, n + 1, dtype=np.float64)
         pos3 = pos + 1e-3 * (L if periodic else 1.0) * np.sin(0.37 * idn[:, None] + 1.3 * np.arange(3)[None, :])
         act3 = (np.arange(n) % 3 == 1).astype(np.uint8)
@@ -237,8 +238,14 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
         a4, o4, c4 = a3.copy(), o3.copy(), c3.copy()
         eng.get_accel(into=(a4, o4, c4))
         s3 = out[2]
-        assert same(s3[:, 0:3], a4) and same(s3[:, 6], o4) and np.mean(s3[:, 7] == c4.astype(np.float64)) > 0.999
         idle3 = act3 == 0
+        if ntask == 1:
+            assert same(s3[:, 0:3], a4) and same(s3[:, 6], o4) and np.mean(s3[:, 7] == c4.astype(np.float64)) > 0.999
+        elif strict:
+            assert same(s3[~idle3, 0:3], a4[~idle3], 1e-10) and np.array_equal(s3[~idle3, 7], c4[~idle3].astype(np.float64))
+        else:
+            assert walks_agree(s3[~idle3, 0:3], a4[~idle3], (a4 + p2)[~idle3], loose=4.0)
+        assert "decomposing again" not in r.stdout                     # the kept decomposition held what the walk opened
         assert np.array_equal(s3[idle3, 0:3], out[1][idle3, 0:3]) and np.array_equal(s3[:, 3:6], out[0][:, 3:6])
     eng.close()
     s2 = out[1]
@@ -258,7 +265,7 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
     import re
     blocks = open(str(tmp_path / "timings.txt")).read().split("\n\n")
     blocks = [b for b in blocks if b.strip()]
-    assert len(blocks) == (4 if ntask == 1 else 3)          # first step: two calls; then one per step
+    assert len(blocks) == 4                                 # first step: two calls; then one per step
     pat = [r"^Step= -?\d+  t= \S+  dt= \S+ $", r"^Nf= \d+\d{9}  total-Nf= \d+\d{9}  ex-frac= \S+  iter= \d+$",
            r"^work-load balance: \S+  max=\S+ avg=\S+ PE0=\S+$", r"^particle-load balance: \S+$", r"^max\. nodes: \d+, filled: \S+$",
            r"^part/sec=\S+ \| \S+  ia/part=\S+ \(\S+\)$"]
@@ -268,7 +275,7 @@ def test_glue_runs_on_the_gpu(pkg, have_lib, tmp_path, opts, ng, nsmall):
     nf = [int(b.split("\n")[1].split()[1]) for b in blocks]
     assert nf[0] == n and nf[1] == n                          # every particle is active on the first step
     ia = float(blocks[1].split("\n")[5].split("ia/part=")[1].split()[0])
-    assert abs(ia / s1[:, 7].mean() - 1) < 1e-6               # ia/part is the mean of P[].GravCost
+    assert abs(ia / s1[:, 7].mean() - 1) < 1e-5               # ia/part is the mean of P[].GravCost (printed with %g: six digits)
     exf = float(blocks[1].split("\n")[1].split("ex-frac=")[1].split()[0])
     assert exf == 0 if ntask == 1 else (exf > 0 or n <= 100)
     if "-DFORCETEST=0.02" in opts:

@@ -63,6 +63,31 @@ def main():
                            "alltoallv": list(1e3 * pm_s[2::3] / steps), "unpack": list(1e3 * pm_s[3::3] / steps)},
            "device_phases_ms_last_step": {"domain+peano": st.t_domain + st.t_peano, "pm": st.t_pm, "treebuild": st.t_treebuild,
                                           "treewalk": st.t_treewalk}}
+    # steps that KEEP the decomposition (TreeDomainUpdateFrequency > 0): the own rows drift, ngravs_host_kept_step does the rest
+    import ctypes as C
+    import time
+    ids = eng.local_ids()
+    pl, ml, tl = np.asarray(pos)[ids].copy(), np.asarray(mass)[ids].copy(), np.asarray(ptype)[ids].copy()
+    rng = np.random.default_rng(3)
+    kept = {"host_ms": [], "stage_ms": [], "walk_ms": []}
+    for _ in range(3):
+        pl += 2e-4 * L * rng.standard_normal(pl.shape)
+        eng.n = eng.num_local()
+        eng.update_particles(pl, ml, tl)
+        eng._check(pkg.lib().ngravs_set_old_acc(eng._h, tmp.data_ptr(), 8, 1), "ngravs_set_old_acc")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng._host(eng._L.ngravs_host_kept_step(eng._h, C.byref(eng.comm.c), C.byref(eng.info)), "ngravs_host_kept_step")
+        t1 = time.perf_counter()
+        eng.gravity_tree()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        kept["host_ms"].append(1e3 * (t1 - t0))
+        kept["walk_ms"].append(1e3 * (t2 - t1))
+        kept["stage_ms"].append({k: 1e3 * v for k, v in zip(names, list(eng.info.seconds))})
+    kept["collectives"] = int(eng.info.collectives)
+    kept["unopened"] = int(eng.walk_unopened())
+    out["kept_step"] = kept
     print(json.dumps(out))
     eng.close()
     dist.destroy_process_group()
