@@ -110,7 +110,7 @@ TRIP = [
     "s_add_u32 %[ntr], %[ntr], 1",
     "v_ffbl_b32_e32 {J}, %[m]                        ;; -1 for an empty mask: the NULL entry",
     "v_add_co_u32_e64 {I1}, s[90:91], %[m], -1       ;; carry <=> m != 0: the lanes with a real entry",
-    "v_lshl_add_u32 {A}, {J}, 5, %[q]",
+    "v_lshl_add_u32 {A}, {J}, 4, %[q]",
     "v_and_b32_e32 %[m], {I1}, %[m]",
     "v_cmp_eq_u32_e32 vcc, 0, %[m]",
     "s_and_saveexec_b64 s[92:93], vcc                ;; lanes whose block is used up follow the link",
@@ -118,8 +118,8 @@ TRIP = [
     "ds_read_b32 %[q], %[q] offset:256",
     "ds_read_b32 %[m], {I1}",
     "s_mov_b64 exec, s[92:93]",
-    "ds_read_b128 {E0}, {A} offset:336",
-    "ds_read_b128 {E1}, {A} offset:352",
+    "ds_read_b128 {E0}, {A} offset:320",
+    "ds_read_b128 {E1}, {A} offset:848",
     "s_waitcnt lgkmcnt(1)                            ;; (right whether or not the masked reads were counted)",
     "v_add_f64 {DX}, {DX}, -%[tpx]",
     "v_add_f64 {DY}, {DY}, -%[tpy]",
@@ -162,7 +162,7 @@ TRIP = [
     "s_branch L_er_top_%=",
     # ---- rare: a pair possibly inside the softening radius (forcetree.c:1415-1417, ngravs.c:420-434)
     "L_er_soft_%=:",
-    "v_mul_i32_i24_e32 {T1LO}, 0xffffffe1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 31 j + 272",
+    "v_mul_i32_i24_e32 {T1LO}, 0xfffffff1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 15 j + 272",
     "v_add_u32_e32 {T1LO}, {A}, {T1LO}",
     "ds_read_u8 {T1LO}, {T1LO} offset:272",
     "s_waitcnt lgkmcnt(0)",
@@ -254,9 +254,9 @@ def zipl(a, b):
 T2_FETCH = [
     "v_ffbl_b32_e32 {J}, %[m]                        ;; -1 for an empty mask: the NULL entry",
     "v_add_co_u32_e64 {I1}, {ACT}, %[m], -1          ;; carry <=> m != 0: the lanes with a real entry",
-    "v_lshl_add_u32 {A}, {J}, 5, %[q]",
-    "ds_read_b128 {E0}, {A} offset:336",
-    "ds_read_b128 {E1}, {A} offset:352",
+    "v_lshl_add_u32 {A}, {J}, 4, %[q]",
+    "ds_read_b128 {E0}, {A} offset:320",
+    "ds_read_b128 {E1}, {A} offset:848",
     "v_and_b32_e32 %[m], {I1}, %[m]",
     "v_cmp_eq_u32_e32 vcc, 0, %[m]",
     "s_and_saveexec_b64 s[92:93], vcc                ;; lanes whose block is used up follow the link",
@@ -339,7 +339,7 @@ T2_S5 = [
 ]
 T2_SOFT = [
     "L_er_soft{S}_%=:",
-    "v_mul_i32_i24_e32 {T1LO}, 0xffffffe1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 31 j + 272",
+    "v_mul_i32_i24_e32 {T1LO}, 0xfffffff1, {J}       ;; type byte of entry j: [slot] + ER_TYPE + j = A - 15 j + 272",
     "v_add_u32_e32 {T1LO}, {A}, {T1LO}",
     "ds_read_u8 {T1LO}, {T1LO} offset:272",
     "s_waitcnt lgkmcnt(0)",
@@ -462,10 +462,10 @@ CULL = [
     "v_mov_b32_e32 {SQ2}, %[q2]",
     "v_cndmask_b32_e32 {SQ}, {SQ2}, {SQ}, vcc",
     "v_and_b32_e32 {EA}, 31, {L}",
-    "v_lshl_add_u32 {EA}, {EA}, 5, {SQ}",
-    "ds_write_b128 {EA}, {EXY} offset:336",
-    "ds_write_b64 {EA}, {EZ} offset:352",
-    "ds_write_b64 {EA}, %[rw] offset:360",
+    "v_lshl_add_u32 {EA}, {EA}, 4, {SQ}",
+    "ds_write_b128 {EA}, {EXY} offset:320",
+    "ds_write_b64 {EA}, {EZ} offset:848",
+    "ds_write_b64 {EA}, %[rw] offset:856",
     "s_mov_b64 exec, s[92:93]",
 ]
 

@@ -3,7 +3,7 @@
 kernels that compete for it): 2^23 particles and PMGRID 256 -- the particle count and the number of mesh cells ONE of 8 tasks
 holds at C4 (2^26 particles, PMGRID 512) -- through the production backend (torch.distributed "nccl" = RCCL, world size 1).
 Imports and exchange payloads are absent (no other task), everything else of the choreography runs.
-  python tools/probe_one_task.py [log2n] [pmgrid]"""
+  python tools/probe_one_task.py [log2n] [pmgrid] [nokept]"""
 import importlib
 import json
 import os
@@ -66,6 +66,11 @@ def main():
     # steps that KEEP the decomposition (TreeDomainUpdateFrequency > 0): the own rows drift, ngravs_host_kept_step does the rest
     import ctypes as C
     import time
+    if len(sys.argv) > 3 and sys.argv[3] == "nokept":   # (tools/trace_one_task.sh: the trace ends with a step that decomposes)
+        print(json.dumps(out))
+        eng.close()
+        dist.destroy_process_group()
+        return
     ids = eng.local_ids()
     pl, ml, tl = np.asarray(pos)[ids].copy(), np.asarray(mass)[ids].copy(), np.asarray(ptype)[ids].copy()
     rng = np.random.default_rng(3)

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/trace_one_task
 mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 $R/tools/probe_one_task.py ${1:-23} ${2:-256} > $O/log.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/t -o t -- python3 $R/tools/probe_one_task.py ${1:-23} ${2:-256} nokept > $O/log.txt 2>&1
 F=$(find $O/t -name "*kernel_trace.csv" | head -1)
 python3 - "$F" > $O/dispatches.txt <<'PY'
 import csv,sys
