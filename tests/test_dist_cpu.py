@@ -129,6 +129,15 @@ def _worker(rank, world, port, out_dir, name):
     rc = L.ngravs_host_import_request(C.byref(cfg), dom_c.ctypes.data, C.byref(t), node_sums.ctypes.data, owner.ctypes.data, rank,
                                       bounds.ctypes.data, need.ctypes.data)
     assert rc == 0
+    # a decomposition that will be kept (ngravs_host_import_request_margin: own boxes grown by the drift allowance) asks for at least
+    # as much, and margin 0 is the plain decision
+    L.ngravs_host_import_request_margin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double,
+                                                    C.c_void_p]
+    need0, needm = np.zeros(nl, dtype=np.uint8), np.zeros(nl, dtype=np.uint8)
+    for mg, out in ((0.0, need0), (0.01 * dom[6], needm)):
+        assert L.ngravs_host_import_request_margin(C.byref(cfg), dom_c.ctypes.data, C.byref(t), node_sums.ctypes.data, owner.ctypes.data, rank,
+                                                   bounds.ctypes.data, mg, out.ctypes.data) == 0
+    assert np.array_equal(need0, need) and np.all(needm >= need) and needm.sum() >= need.sum()
     # ---- what the reference walk of these targets really enters
     reach = T.walk_reach(targets, old_acc=old, table=tab)
     leaf_len = dom[6] / (1 << level[node_of_leaf]).astype(np.float64)
