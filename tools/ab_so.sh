@@ -2,7 +2,7 @@
 # A/B of two builds of libngravs_hip.so on ONE GPU box (the boxes of the pool differ by +-1 ms in the evaluation kernel):
 #   tools/ab_so.sh TAG A.so B.so [rounds]   -> gpurun_out/TAG_ab.txt  (C4 bench, alternating; then the SQ counter pass of each)
 # The two files are copied over gadget-2.0.7-ngravs_amd/libngravs_hip.so in turn; the last copy is B.
-TAG=$1; A=$2; B=$3; N=${4:-2}
+TAG=$1; A=$(realpath $2); B=$(realpath $3); N=${4:-2}
 R=$GRAFT_REPO_ROOT
 L=$R/gadget-2.0.7-ngravs_amd/libngravs_hip.so
 O=$R/gpurun_out/${TAG}_ab.txt

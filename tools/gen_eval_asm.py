@@ -420,6 +420,119 @@ def trip2(yuk):
     return out
 
 
+
+# ---- trip loop with the NEXT entry in flight (ER_TRIP3_*_ASM) ------------------------------------------------------------------------
+# ER_TRIP_ASM starts every trip with an LDS round trip nobody hides: cursor -> ds_read_b128 x 2 -> s_waitcnt -> first use.  Here the
+# loop is unrolled twice over two register sets (x: v104-v111 + v126/v127, y: v96-v103 + v94/v95): as soon as the entry of trip t has
+# arrived (and with it, in order, the link words of the lanes that changed slots), the cursor step of trip t+1 is taken and ITS entry
+# requested, then trip t is evaluated.  The exit test of trip t+1 comes before that step -- a trip that will not run takes no bit.
+def role_regs(s):
+    r = dict(REGS)
+    if s == "y":
+        r.update({"E0": "v[96:99]", "E1": "v[100:103]", "DX": pair(96), "DY": pair(98), "DZ": pair(100), "MW": pair(102), "MWLO": "v102",
+                  "MWHI": "v103", "J": "v94", "A": "v95"})
+    r["ACT"] = "s[90:91]" if s == "x" else "s[88:89]"
+    r["S"] = s
+    return r
+
+
+P_CURSOR = [
+    "v_ffbl_b32_e32 {J}, %[m]                        ;; -1 for an empty mask: the NULL entry",
+    "v_add_co_u32_e64 {T3LO}, {ACT}, %[m], -1        ;; carry <=> m != 0: the lanes with a real entry",
+    "v_lshl_add_u32 {A}, {J}, 4, %[q]",
+    "v_and_b32_e32 %[m], {T3LO}, %[m]",
+    "v_cmp_eq_u32_e32 vcc, 0, %[m]",
+    "s_and_saveexec_b64 s[92:93], vcc                ;; lanes whose block is used up follow the link",
+    "v_add_u32_e32 {T3LO}, %[q], %[lane4]",
+    "ds_read_b32 %[q], %[q] offset:256",
+    "ds_read_b32 %[m], {T3LO}",
+    "s_mov_b64 exec, s[92:93]",
+    "ds_read_b128 {E0}, {A} offset:320",
+    "ds_read_b128 {E1}, {A} offset:848",
+]
+P_HEAD = [
+    "v_add_f64 {DX}, {DX}, -%[tpx]",
+    "v_add_f64 {DY}, {DY}, -%[tpy]",
+    "v_mul_f64 {R2}, {DY}, {DY}",
+    "v_add_f64 {DZ}, {DZ}, -%[tpz]",
+    "v_fmac_f64_e32 {R2}, {DX}, {DX}",
+    "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
+    "v_cmp_ngt_f64_e32 vcc, %[reach2], {R2}          ;; !(r2 < reach2)",
+    "s_and_b64 s[94:95], vcc, {ACT}",
+    "s_cmp_eq_u64 s[94:95], 0",
+    "s_cbranch_scc1 L_er_incut{S}_%=",
+    "v_cndmask_b32_e64 {MWHI}, {MWHI}, 0, s[94:95]   ;; rare: beyond the exact cut -- no mass, not counted",
+    "v_cndmask_b32_e64 {MWLO}, {MWLO}, 0, s[94:95]",
+    "v_cndmask_b32_e64 {T1LO}, 0, 1, s[94:95]",
+    "v_sub_u32_e32 %[nint], %[nint], {T1LO}",
+    "L_er_incut{S}_%=:",
+    "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
+    "v_rsq_f64_e32 {RI}, {RR}",
+    "v_cmp_lt_f64_e64 s[94:95], {R2}, %[h2max]       ;; closer than the largest softening length?",
+    "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
+    "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
+    "v_mul_f64 {T2}, {RI}, 0.5",
+    "v_fma_f64 {RI}, {T2}, {T1}, {RI}                ;; 1/r",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; r",
+    "v_mul_f64 {T1}, {RR}, %[asmthfac]",
+    "v_cvt_i32_f64_e32 {I1}, {T1}                    ;; table bin (saturating conversion, then clamped); r2 is no longer needed",
+    "v_min_i32_e32 {I1}, 0x7ff, {I1}",
+]
+P_TAIL = [
+    "s_waitcnt lgkmcnt(0)",
+    "v_fma_f64 {T3}, -%[utor2wpi], {TT}, {T3}        ;; - long-range part",
+    "v_mul_f64 {T3}, {MW}, {T3}",
+    "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
+    "s_cmp_lg_u64 s[94:95], 0",
+    "s_cbranch_scc1 L_er_soft{S}_%=",
+    "L_er_acc{S}_%=:",
+    "v_fmac_f64_e32 %[ax], {DX}, {T3}",
+    "v_fmac_f64_e32 %[ay], {DY}, {T3}",
+    "v_fmac_f64_e32 %[az], {DZ}, {T3}",
+]
+
+
+def trip3(yuk):
+    i0 = TRIP.index("L_er_soft_%=:")
+    soft = TRIP[i0 + 1:TRIP.index("L_er_done_%=:")]      # the softened-pair path of ER_TRIP_ASM, relabelled per register set below
+    rx, ry = role_regs("x"), role_regs("y")
+    seg = YUK_ET if yuk else NOYUK
+    seq = ["s_mov_b32 %[ntr], 0",
+           "s_mov_b32 s87, 0                                ;; 1: the trip being evaluated is the last one",
+           "v_cmp_eq_u32_e32 vcc, %[tail], %[q]",
+           "s_cbranch_vccz L_er_done_%="]
+    seq += fill(P_CURSOR, rx)
+    for cur, nxt in ((rx, ry), (ry, rx)):
+        S = cur["S"]
+        seq += ["L_er_top%s_%%=:" % S,
+                "s_waitcnt lgkmcnt(0)                            ;; this trip's entry (requested a trip ago) and, before it, the link words",
+                "s_add_u32 %[ntr], %[ntr], 1",
+                "v_cmp_eq_u32_e32 vcc, %[tail], %[q]             ;; will there be another trip?",
+                "s_cbranch_vccnz L_er_pf%s_%%=" % S,
+                "s_mov_b32 s87, 1",
+                "s_branch L_er_cmp%s_%%=" % S,
+                "L_er_pf%s_%%=:" % S]
+        seq += fill(P_CURSOR, nxt)
+        seq += ["L_er_cmp%s_%%=:" % S]
+        seq += fill(P_HEAD, cur) + fill(seg, cur) + fill(P_TAIL, cur)
+        seq += ["s_cmp_lg_u32 s87, 0",
+                "s_cbranch_scc1 L_er_done_%="]
+    seq += ["s_branch L_er_topx_%="]
+    for r in (rx, ry):
+        S = r["S"]
+        seq += ["L_er_soft%s_%%=:" % S]
+        for l in soft:
+            if l.startswith("@"):
+                # the FST splice of ER_TRIP_ASM names REGS' registers: TE and T1LO are shared temporaries, the same in both sets
+                seq.append(l)
+            else:
+                l = l.replace("L_er_acc_%=", "L_er_acc%s_%%=" % S)
+                if S == "y":   # the path's scratch pair is the set's own (by now dead) mask of real entries: s[90:91] holds set x's NEXT one
+                    l = l.replace("s[90:91]", "s[88:89]").replace("s_mov_b32 s90,", "s_mov_b32 s88,").replace("s_mov_b32 s91,", "s_mov_b32 s89,")
+                seq.append(fill([l], r)[0])
+    seq += ["L_er_done_%=:"]
+    return seq
+
 # ---- cull --------------------------------------------------------------------------------------------------------------------
 CULL_WRAP = [
     "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
@@ -482,6 +595,9 @@ def main():
     out.append(macro("ER_TRIP2_YUK_ASM", trip2(True), "(FSTOFF)"))
     out.append(macro("ER_TRIP2_NOYUK_ASM", trip2(False), "(FSTOFF)"))
     out.append(clobbers("ER_TRIP2_CLOBBERS", range(80, 128), range(86, 96)))
+    out.append(macro("ER_TRIP3_YUK_ASM", trip3(True), "(FSTOFF)"))
+    out.append(macro("ER_TRIP3_NOYUK_ASM", trip3(False), "(FSTOFF)"))
+    out.append(clobbers("ER_TRIP3_CLOBBERS", range(94, 128), range(86, 96)))
     out.append(macro("ER_CULL_WRAP", CULL_WRAP))
     out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
     out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
