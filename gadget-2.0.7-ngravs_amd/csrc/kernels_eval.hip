@@ -40,7 +40,9 @@
 #define ER_TYPE 272u         // type bytes (the NULL entry's at -1)
 #define ER_XY 320u           // (x, y) of entry 0; the NULL entry's 16 bytes in front
 #define ER_ZM 848u           // (z, mass) of entry 0; the NULL entry's 16 bytes in front
-#define ER_MAXWAVES 16
+#ifndef ER_MAXWAVES
+#define ER_MAXWAVES 16   // waves per workgroup the kernel is compiled for (128 VGPRs at 16; -DER_MAXWAVES=12: 168)
+#endif
 
 extern __shared__ __attribute__((aligned(16))) unsigned char er_smem[];
 
