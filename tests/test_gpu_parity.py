@@ -1157,7 +1157,13 @@ def test_ring_pool_kernel_is_the_synchronous_kernel(pkg, wiring, ng, pmgrid, sof
     eps = L / (40 * n ** (1 / 3))
     softening = [eps] * 6 if soft == "one" else [eps, eps, 2.5 * eps, eps, 1.7 * eps, eps]
     out = {}
-    for name, tune in (("sync", {"walk_ring": 0}), ("ring", {}), ("ring4", {"walk_ring_k": 4})):
+    variants = [("sync", {"walk_ring": 0}), ("ring", {}), ("ring4", {"walk_ring_k": 4})]
+    if (wiring, ng, pmgrid, soft) == ("c4", 2, 256, "two"):
+        # two / four lanes per target (walk_spread: what the library chooses for strongly clustered sets): the S lanes of a target share the
+        # entries of every block, each against the synchronous kernel with the same spread
+        variants += [("sync_s2", {"walk_ring": 0, "walk_spread": 2}), ("ring_s2", {"walk_spread": 2}),
+                     ("sync_s4", {"walk_ring": 0, "walk_spread": 4}), ("ring_s4", {"walk_spread": 4})]
+    for name, tune in variants:
         cfg = pkg.make_config(n_gravs=ng, periodic=1, pmgrid=pmgrid, box_size=L, G=1.0, theta=0.5, softening=softening,
                               type_to_grav=pkg.ic.default_type_to_grav(ng), wiring=wiring, walk_mode=pkg.WALK_GROUP)
         eng = _engine(pkg, cfg, pos, mass, typ, tuning=tune)
@@ -1169,9 +1175,8 @@ def test_ring_pool_kernel_is_the_synchronous_kernel(pkg, wiring, ng, pmgrid, sof
         a2, _, c2 = eng.get_accel()
         out[name] = (a1, c1, a2, c2, eng.stats().reserved[3])
         eng.close()
-    s = out["sync"]
-    for name in ("ring", "ring4"):
-        r = out[name]
+    for name, ref in [("ring", "sync"), ("ring4", "sync")] + [(v[0], "sync" + v[0][4:]) for v in variants if v[0].startswith("ring_s")]:
+        r, s = out[name], out[ref]
         for k in (0, 2):
             na = np.linalg.norm(s[k], axis=1)       # (a particle with nothing inside the cut has no short-range force at all)
             e = np.linalg.norm(r[k] - s[k], axis=1) / np.maximum(na, 1e-6 * np.median(na))
