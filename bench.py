@@ -453,6 +453,9 @@ def main():
                        "world_size_reported_by_backend": (eng.comm.world_reported if domain else (dist.get_world_size() if world > 1 else 1)),
                        "parallelism": ("work-weighted Peano-Hilbert domain decomposition over %d tasks: migration + halo all-to-all-v, x-slab decomposed PM (4 plane exchanges)" % world)
                        if domain else ("walk sharded over %d Peano segment(s); decomposition, build, PM replicated" % world),
+                       "untimed_prologue": ("every rank generates the whole seeded IC on its host (%d particles: the ranks must agree on it without a file), "
+                                            "uploads it and keeps every %d-th particle; the first step migrates" % (n, world)) if domain else
+                                           "the IC is generated on the host and uploaded once",
                        "phases_ms": {"domain+peano": ph[0] * 1e3, "pm": ph[1] * 1e3, "treebuild": ph[2] * 1e3,
                                      "treewalk": ph[3] * 1e3},
                        "ia_per_particle": st.interactions / max(1, st.n_active), "tree_nodes": st.n_nodes,
