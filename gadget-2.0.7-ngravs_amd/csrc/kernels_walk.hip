@@ -30,6 +30,7 @@
 // neg_newtonian, yukawa, coloyuk) and kernels are compiled per N_GRAVS and per "has Yukawa".
 #include "engine.hpp"
 #include "walk_device.hpp"
+#include "eval_asm.inc"   // ER_DIRECT_ASM: the tree-only force loop (the other blocks belong to kernels_eval.hip)
 #include <hipcub/hipcub.hpp>
 #include <type_traits>
 
@@ -1425,7 +1426,29 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                 // ---- force loop: every lane walks its own bits, ES per trip
                 unsigned long long m = (((unsigned long long)mhi << 32) | mlo) & lane_pat;
                 nint += direct ? (valid ? nc : 0) : __popcll(m);   // evalN takes the (rare) slots beyond the exact cut off again
-                if(direct)
+                bool direct_done = false;
+                if constexpr(!PM && !LATT && ES == 1)
+                  if(direct && !lanewrap && !(BAMCAP && wp.bam))
+                    {
+                      // the common tree-only case in assembly (eval_asm.inc ER_DIRECT_ASM: unrolled twice, the next entry in flight,
+                      // accumulators in place); a lane without a target takes part with zero coefficients
+                      typedef __attribute__((address_space(3))) unsigned char *lds_p;
+                      unsigned ptr = (unsigned)(unsigned long)(lds_p)(unsigned char *)pp;
+                      const unsigned tya = (unsigned)(unsigned long)(lds_p)lty;
+                      const unsigned fsa = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(lds_p)(unsigned char *)fsT);
+                      const double cNv = valid ? cNg : 0.0, cSv = valid ? cSg : 0.0;
+                      const int ncs = __builtin_amdgcn_readfirstlane(nc);
+                      const double h2u = wave_uniform(h2max);
+                      asm volatile(ER_DIRECT_ASM
+                                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ptr] "+v"(ptr)
+                                   : [n] "s"(ncs), [tpx] "v"(tpx), [tpy] "v"(tpy), [tpz] "v"(tpz), [cN] "v"(cNv), [cS] "v"(cSv), [hT] "v"(hT),
+                                     [tyb] "v"(tya), [fst] "s"(fsa), [tiny] "s"(1e-290), [h2max] "s"(h2u)
+                                   : ER_DIRECT_CLOBBERS);
+                      st_iters += nc;
+                      direct_done = true;
+                      m = 0;
+                    }
+                if(direct && !direct_done)
                   {
                     // tree-only: every pool entry interacts with every target -- no masks to decode, all lanes read the
                     // same entries (LDS broadcast)

@@ -533,6 +533,82 @@ def trip3(yuk):
     seq += ["L_er_done_%=:"]
     return seq
 
+
+# ---- tree-only force loop (ER_DIRECT_ASM; k_walk_group2 with PM = false, one lane per target) ---------------------------------------
+# Every pool entry interacts with every target: no masks, all lanes read the same entry (LDS broadcast).  The compiler's version of
+# this loop carried its three accumulators through six register copies per entry and left the entry's LDS round trip exposed
+# (33 issue slots per entry, 204 cycles per entry and SIMD measured on the 4 M Plummer sphere).  Here: unrolled twice over two
+# register sets, the next entry requested before the current one is evaluated, 21 VALU per entry.  Pool entries are 32-byte
+# records (x, y | z, m) from %[ptr] on; s89 counts the entries; a lane without a target is handed cN = cS = 0.
+D_COMPUTE = [
+    "v_add_f64 {DX}, {DX}, -%[tpx]",
+    "v_add_f64 {DY}, {DY}, -%[tpy]",
+    "v_mul_f64 {R2}, {DY}, {DY}",
+    "v_add_f64 {DZ}, {DZ}, -%[tpz]",
+    "v_fmac_f64_e32 {R2}, {DX}, {DX}",
+    "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
+    "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
+    "v_rsq_f64_e32 {RI}, {RR}",
+    "v_cmp_lt_f64_e64 s[94:95], {R2}, %[h2max]       ;; closer than the largest softening length?",
+    "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
+    "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
+    "v_mul_f64 {T2}, {RI}, 0.5",
+    "v_fma_f64 {RI}, {T2}, {T1}, {RI}                ;; 1/r",
+    "v_mul_f64 {T2}, {RI}, {RI}",
+    "v_mul_f64 {T3}, %[cN], {T2}                     ;; cN / r^2",
+    "v_mul_f64 {T3}, {MW}, {T3}",
+    "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
+    "s_cmp_lg_u64 s[94:95], 0",
+    "s_cbranch_scc1 L_ed_soft{S}_%=",
+    "L_ed_acc{S}_%=:",
+    "v_fmac_f64_e32 %[ax], {DX}, {T3}",
+    "v_fmac_f64_e32 %[ay], {DY}, {T3}",
+    "v_fmac_f64_e32 %[az], {DZ}, {T3}",
+]
+D_SOFT_HEAD = [
+    "L_ed_soft{S}_%=:",
+    "v_mul_f64 {RR}, {RR}, {RI}                      ;; r",
+    "v_add_u32_e32 {T1LO}, s89, %[tyb]               ;; type byte of the entry",
+    "ds_read_u8 {T1LO}, {T1LO}",
+    "s_waitcnt lgkmcnt(0)",
+    "v_lshl_add_u32 {T1LO}, {T1LO}, 3, %[fst]",
+    "ds_read_b64 {TE}, {T1LO}                        ;; softening length of the source's type",
+]
+
+
+def direct():
+    i0 = TRIP.index("L_er_soft_%=:")
+    soft = TRIP[i0 + 7:TRIP.index("L_er_done_%=:")]      # from the wait for the softening length on: shared with ER_TRIP_ASM
+    rx, ry = role_regs("x"), role_regs("y")
+    seq = ["s_mov_b32 s89, 0",
+           "ds_read_b128 %s, %%[ptr]" % rx["E0"],
+           "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"],
+           "L_ed_topx_%=:",
+           "s_waitcnt lgkmcnt(0)",
+           "ds_read_b128 %s, %%[ptr] offset:32             ;; the next entry (one past the end on the last trip: inside the pool, not used)" % ry["E0"],
+           "ds_read_b128 %s, %%[ptr] offset:48" % ry["E1"]]
+    seq += fill(D_COMPUTE, rx)
+    seq += ["s_add_u32 s89, s89, 1",
+            "s_cmp_lt_u32 s89, %[n]",
+            "s_cbranch_scc0 L_ed_done_%=",
+            "s_waitcnt lgkmcnt(0)",
+            "v_add_u32_e32 %[ptr], 64, %[ptr]",
+            "ds_read_b128 %s, %%[ptr]" % rx["E0"],
+            "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"]]
+    seq += fill(D_COMPUTE, ry)
+    seq += ["s_add_u32 s89, s89, 1",
+            "s_cmp_lt_u32 s89, %[n]",
+            "s_cbranch_scc1 L_ed_topx_%=",
+            "s_branch L_ed_done_%="]
+    for r in (rx, ry):
+        S = r["S"]
+        seq += fill(D_SOFT_HEAD, r)
+        for l in soft:
+            l = l.replace("L_er_acc_%=", "L_ed_acc%s_%%=" % S)
+            seq.append(fill([l], r)[0])
+    seq += ["L_ed_done_%=:"]
+    return seq
+
 # ---- cull --------------------------------------------------------------------------------------------------------------------
 CULL_WRAP = [
     "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
@@ -598,6 +674,8 @@ def main():
     out.append(macro("ER_TRIP3_YUK_ASM", trip3(True), "(FSTOFF)"))
     out.append(macro("ER_TRIP3_NOYUK_ASM", trip3(False), "(FSTOFF)"))
     out.append(clobbers("ER_TRIP3_CLOBBERS", range(94, 128), range(86, 96)))
+    out.append(macro("ER_DIRECT_ASM", direct()))
+    out.append(clobbers("ER_DIRECT_CLOBBERS", range(96, 128), range(89, 96)))
     out.append(macro("ER_CULL_WRAP", CULL_WRAP))
     out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
     out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
