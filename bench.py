@@ -472,10 +472,14 @@ def main():
         if args.walk == "group" and split:
             # the kernel's own bound: fp64 VALU issue.  Every evaluated pair costs one trip of the force loop's common path (static
             # count from this build's assembly, profiles/r04_eval_isa_mix.txt, ER_TRIP_ASM: 45 VALU + 3 extra issue slots for the quarter-rate
-            # v_rsq_f64; tree-only walks run k_walk_group2's loop: 49 + 3), one wave-instruction issues in 4 cycles on a SIMD for 64
+            # v_rsq_f64), one wave-instruction issues in 4 cycles on a SIMD for 64
             # lanes, 4 SIMDs per CU
             pairs = st.interactions / max(1, split["launches_per_step"])
-            slots, clock_hz, simds = (48 if ring else 52), 2.4e9, 4 * torch.cuda.get_device_properties(dev).multi_processor_count
+            # (tree-only walks with one lane per target -- force-loop trips per group = pairs per particle -- run ER_DIRECT_ASM: 21 + 3;
+            # with several lanes per target or per-pair images k_walk_group2's C++ loop: 49 + 3)
+            ia_pp = st.interactions / max(1, st.n_active)
+            direct_asm = treeonly and ia_pp > 0 and abs(st.reserved[3] / ia_pp - 1.0) < 0.01
+            slots, clock_hz, simds = (48 if ring else (24 if direct_asm else 52)), 2.4e9, 4 * torch.cuda.get_device_properties(dev).multi_processor_count
             floor_ms = pairs * slots * 4.0 / 64.0 / (simds * clock_hz) * 1e3
             out["roofline"]["secondary"] = {"bound": "fp64 VALU issue", "floor_ms": floor_ms, "achieved_ms": k_ms, "frac": floor_ms / k_ms,
                                             "issue_slots_per_pair": slots, "pairs_per_launch": pairs, "simds": simds, "clock_ghz": clock_hz / 1e9,
