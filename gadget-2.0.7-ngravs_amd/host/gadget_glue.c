@@ -674,11 +674,17 @@ void gravity_tree(void)
       (void)ngravs_walk_unopened(Ctx, &want);
       mine = (long long)want;
       MPI_Allreduce(&mine, &any, 1, MPI_LONG_LONG, MPI_MAX, MPI_COMM_WORLD);
+#ifdef NGRAVS_GLUE_TEST_KEPT_FALLBACK
+      any = 1;			/* tests: take the way out below although nothing was missing */
+#endif
       KeptStep = 0;
       if(any > 0)
 	{
 	  if(ThisTask == 0)
 	    printf("ngravs-hip: a kept decomposition no longer holds the leaves the walk opens: decomposing again\n");
+#ifdef PERIODIC
+	  do_box_wrapping();	/* as every domain_Decomposition() starts (domain.c:81): the particles have drifted since the last one */
+#endif
 	  decompose_several_tasks(1);
 	  All.NumForcesSinceLastDomainDecomp = 0;
 	  if(NumPart > 0)
