@@ -611,6 +611,10 @@ __global__ __launch_bounds__(256) void k_walk_strict(TreeView tv, const double4 
 #define GW3_LIST_MAX 65536
 #define GW3_STK_MIN 4096      // split walk: pending-node LIFO ints per group (scap; grown likewise)
 #define GW3_STK_MAX 65536
+#ifndef GW_DIRECT
+#define GW_DIRECT 1   // the tree-only force loop in assembly: 1 = ER_DIRECT_ASM (one entry per trip, the next one in flight), 2 = ER_DIRECT2_ASM (two
+                      // interleaved entries per trip)
+#endif
 #ifndef GW2_ES
 #define GW2_ES 1   // measured at C4 (round 2, after the table-bin exp and the expanded-form masks): 1 -> 91.5 ms, 2 -> 96.8 ms
 #endif
@@ -1439,11 +1443,19 @@ __global__ __launch_bounds__(MODE == 1 ? GW3_TBLOCK : (MODE == 2 ? GW2_MAXWAVES 
                       const double cNv = valid ? cNg : 0.0, cSv = valid ? cSg : 0.0;
                       const int ncs = __builtin_amdgcn_readfirstlane(nc);
                       const double h2u = wave_uniform(h2max);
+#if GW_DIRECT == 2
+                      asm volatile(ER_DIRECT2_ASM
+                                   : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ptr] "+v"(ptr)
+                                   : [n] "s"(ncs), [tpx] "v"(tpx), [tpy] "v"(tpy), [tpz] "v"(tpz), [cN] "v"(cNv), [cS] "v"(cSv), [hT] "v"(hT),
+                                     [tyb] "v"(tya), [fst] "s"(fsa), [tiny] "s"(1e-290), [h2max] "s"(h2u)
+                                   : ER_DIRECT2_CLOBBERS);
+#else
                       asm volatile(ER_DIRECT_ASM
                                    : [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az), [ptr] "+v"(ptr)
                                    : [n] "s"(ncs), [tpx] "v"(tpx), [tpy] "v"(tpy), [tpz] "v"(tpz), [cN] "v"(cNv), [cS] "v"(cSv), [hT] "v"(hT),
                                      [tyb] "v"(tya), [fst] "s"(fsa), [tiny] "s"(1e-290), [h2max] "s"(h2u)
                                    : ER_DIRECT_CLOBBERS);
+#endif
                       st_iters += nc;
                       direct_done = true;
                       m = 0;

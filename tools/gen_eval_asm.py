@@ -609,6 +609,74 @@ def direct():
     seq += ["L_ed_done_%=:"]
     return seq
 
+
+# ---- tree-only force loop, two entries per trip as two interleaved instruction streams (ER_DIRECT2_ASM; -DGW_DIRECT=2) ---------------
+def d2_regs(sfx):
+    r = role_regs("x" if sfx in ("x", "s") else "y")
+    if sfx == "y":
+        base = 82
+        names = {"R2": 0, "TT": 0, "RI": 2, "RR": 4, "T1": 6, "T2": 8, "T3": 10, "TE": 12}
+        for k, o in names.items():
+            r[k] = pair(base + o)
+            r[k + "LO"] = "v%d" % (base + o)
+            r[k + "HI"] = "v%d" % (base + o + 1)
+    r["SOFT"] = "s[88:89]" if sfx == "y" else "s[94:95]"
+    r["S"] = sfx + "2"
+    return r
+
+
+D2_NOBR = [l.replace("s[94:95]", "{SOFT}") for l in D_COMPUTE[:D_COMPUTE.index("s_cmp_lg_u64 s[94:95], 0")]]
+D2_ACC = ["s_cmp_lg_u64 {SOFT}, 0",
+          "s_cbranch_scc1 L_ed_soft{S}_%=",
+          "L_ed_acc{S}_%=:",
+          "v_fmac_f64_e32 %[ax], {DX}, {T3}",
+          "v_fmac_f64_e32 %[ay], {DY}, {T3}",
+          "v_fmac_f64_e32 %[az], {DZ}, {T3}"]
+
+
+def direct2():
+    i0 = TRIP.index("L_er_soft_%=:")
+    soft = TRIP[i0 + 7:TRIP.index("L_er_done_%=:")]
+    rs, rx, ry = d2_regs("s"), d2_regs("x"), d2_regs("y")
+    seq = ["s_mov_b32 s86, 0",
+           "s_bitcmp1_b32 %[n], 0                           ;; an odd count: one entry alone first",
+           "s_cbranch_scc0 L_ed_pairs_%=",
+           "ds_read_b128 %s, %%[ptr]" % rs["E0"],
+           "ds_read_b128 %s, %%[ptr] offset:16" % rs["E1"],
+           "v_add_u32_e32 %[ptr], 32, %[ptr]",
+           "s_waitcnt lgkmcnt(0)"]
+    seq += fill(D2_NOBR, rs) + fill(D2_ACC, rs)
+    seq += ["s_mov_b32 s86, 1",
+            "L_ed_pairs_%=:",
+            "s_cmp_lt_u32 s86, %[n]",
+            "s_cbranch_scc0 L_ed_done_%=",
+            "L_ed_top_%=:",
+            "ds_read_b128 %s, %%[ptr]" % rx["E0"],
+            "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"],
+            "ds_read_b128 %s, %%[ptr] offset:32" % ry["E0"],
+            "ds_read_b128 %s, %%[ptr] offset:48" % ry["E1"],
+            "v_add_u32_e32 %[ptr], 64, %[ptr]",
+            "s_waitcnt lgkmcnt(0)"]
+    seq += zipl(fill(D2_NOBR, rx), fill(D2_NOBR, ry))
+    seq += fill(D2_ACC, rx) + fill(D2_ACC, ry)
+    seq += ["s_add_u32 s86, s86, 2",
+            "s_cmp_lt_u32 s86, %[n]",
+            "s_cbranch_scc1 L_ed_top_%=",
+            "s_branch L_ed_done_%="]
+    for r in (rs, rx, ry):
+        S = r["S"]
+        head = list(D_SOFT_HEAD)
+        if S == "y2":   # the second entry of the pair
+            head = [head[0], head[1], "s_add_u32 s87, s86, 1", head[2].replace("s89", "s87")] + head[3:]
+        else:
+            head = [h.replace("s89", "s86") for h in head]   # (s[88:89] is the second stream's softening flag: the counter lives in s86)
+        seq += fill(head, r)
+        for l in soft:
+            l = l.replace("L_er_acc_%=", "L_ed_acc%s_%%=" % S)
+            seq.append(fill([l], r)[0])
+    seq += ["L_ed_done_%=:"]
+    return seq
+
 # ---- cull --------------------------------------------------------------------------------------------------------------------
 CULL_WRAP = [
     "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
@@ -676,6 +744,8 @@ def main():
     out.append(clobbers("ER_TRIP3_CLOBBERS", range(94, 128), range(86, 96)))
     out.append(macro("ER_DIRECT_ASM", direct()))
     out.append(clobbers("ER_DIRECT_CLOBBERS", range(96, 128), range(89, 96)))
+    out.append(macro("ER_DIRECT2_ASM", direct2()))
+    out.append(clobbers("ER_DIRECT2_CLOBBERS", range(82, 128), range(86, 96)))
     out.append(macro("ER_CULL_WRAP", CULL_WRAP))
     out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
     out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
