@@ -78,7 +78,9 @@ __device__ __forceinline__ double4 er_entry(unsigned q, int j)
 // and around every stage.  The blocks use v104 .. v127 and s90 .. s95 as temporaries (clobbers).
 #include "eval_asm.inc"
 #ifndef ER_ES
-#define ER_ES 1   // the assembly trip loop: 1: ER_TRIP_ASM (one entry per trip; the default).  Built, measured, correct and slower (-DER_ES=...):
+#define ER_ES 4   // the assembly trip loop: 4 (the default): ER_TRIP4_ASM, one entry per trip, unrolled twice, the rare "beyond the exact cut" block out
+                  // of line -- one taken branch per two trips where 1: ER_TRIP_ASM takes four (68.7-68.8 against 69.1-69.2 ms on one box).
+                  // Built, measured, correct and slower (-DER_ES=...):
                   // 2: ER_TRIP2_*_ASM, two entries per trip as two interleaved streams -- its 48 temporaries push the records in flight into
                   //    scratch: 72.9 against 69.6 ms at C4;  3: ER_TRIP3_*_ASM, the NEXT trip's entry requested a trip ahead (unrolled twice over
                   //    two register sets, 34 temporaries, 32 spills) -- SQ_WAIT_INST_ANY -3.6 %, SQ_INSTS_VALU +2 %, 72.4 against 69.2 ms on one
@@ -422,6 +424,11 @@ __global__ __launch_bounds__(ER_MAXWAVES * 64) void k_eval_ring(
                         ER_TRIP_CALL(ER_TRIP3_YUK_ASM(ER_FST_OFF_ET), ER_TRIP3_CLOBBERS);
                       else
                         ER_TRIP_CALL(ER_TRIP3_NOYUK_ASM(ER_FST_OFF_NOET), ER_TRIP3_CLOBBERS);
+#elif ER_ES == 4
+                      if constexpr(YUK)
+                        ER_TRIP_CALL(ER_TRIP4_ASM(ER_YUK_ET, ER_FST_OFF_ET), ER_TRIP_CLOBBERS);
+                      else
+                        ER_TRIP_CALL(ER_TRIP4_ASM(ER_NOYUK, ER_FST_OFF_NOET), ER_TRIP_CLOBBERS);
 #else
                       if constexpr(YUK)
                         ER_TRIP_CALL(ER_TRIP_ASM(ER_YUK_ET, ER_FST_OFF_ET), ER_TRIP_CLOBBERS);

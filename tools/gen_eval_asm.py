@@ -677,6 +677,34 @@ def direct2():
     seq += ["L_ed_done_%=:"]
     return seq
 
+
+# ---- trip loop, taken branches off the common path (ER_TRIP4_ASM; -DER_ES=4) ---------------------------------------------------------
+# ER_TRIP_ASM takes two branches on every trip: the jump over the four instructions of "beyond the exact cut" and the jump back to the
+# top.  Here the rare block is out of line (the common case falls through) and the loop is unrolled twice (one jump back per two trips).
+def trip4():
+    top = TRIP.index("L_er_top_%=:")
+    cut = TRIP.index("s_cmp_eq_u64 s[94:95], 0")
+    incut = TRIP.index("L_er_incut_%=:")
+    back = TRIP.index("s_branch L_er_top_%=")
+    soft0 = TRIP.index("L_er_soft_%=:")
+    done = TRIP.index("L_er_done_%=:")
+    rare = TRIP[cut + 2:incut]
+    seq = [TRIP[0]]
+
+    def relabel(l, k):
+        for name in ("top", "incut", "acc", "soft", "rare"):
+            l = l.replace("L_er_%s_%%=" % name, "L_er_%s%s_%%=" % (name, k))
+        return l
+    for k in ("a", "b"):
+        body = TRIP[top:cut] + ["s_cmp_lg_u64 s[94:95], 0", "s_cbranch_scc1 L_er_rare_%=", "L_er_incut_%=:"] + TRIP[incut + 1:back]
+        seq += [relabel(l, k) for l in body]
+    seq += ["s_branch L_er_topa_%="]
+    for k in ("a", "b"):
+        seq += ["L_er_rare%s_%%=:" % k] + rare + ["s_branch L_er_incut%s_%%=" % k]
+        seq += [relabel(l, k) for l in TRIP[soft0:done]]
+    seq += ["L_er_done_%=:"]
+    return seq
+
 # ---- cull --------------------------------------------------------------------------------------------------------------------
 CULL_WRAP = [
     "v_mul_f64 {B0}, {EX}, %[invbox]                 ;; nearest image: x - box rint(x / box)",
@@ -746,6 +774,7 @@ def main():
     out.append(clobbers("ER_DIRECT_CLOBBERS", range(96, 128), range(89, 96)))
     out.append(macro("ER_DIRECT2_ASM", direct2()))
     out.append(clobbers("ER_DIRECT2_CLOBBERS", range(82, 128), range(86, 96)))
+    out.append(macro("ER_TRIP4_ASM", trip4(), "(YUKSEG, FSTOFF)"))
     out.append(macro("ER_CULL_WRAP", CULL_WRAP))
     out.append(macro("ER_CULL_ASM", CULL, "(WRAPSEG)"))
     out.append(clobbers("ER_CULL_CLOBBERS", range(104, 120), range(90, 94)))
