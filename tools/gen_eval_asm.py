@@ -120,18 +120,16 @@ TRIP = [
     "s_mov_b64 exec, s[92:93]",
     "ds_read_b128 {E0}, {A} offset:320",
     "ds_read_b128 {E1}, {A} offset:848",
-    "s_waitcnt lgkmcnt(1)                            ;; (right whether or not the masked reads were counted)",
+    "s_waitcnt lgkmcnt(0)",
     "v_add_f64 {DX}, {DX}, -%[tpx]",
     "v_add_f64 {DY}, {DY}, -%[tpy]",
     "v_mul_f64 {R2}, {DY}, {DY}",
-    "s_waitcnt lgkmcnt(0)",
     "v_add_f64 {DZ}, {DZ}, -%[tpz]",
     "v_fmac_f64_e32 {R2}, {DX}, {DX}",
     "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
     "v_cmp_ngt_f64_e32 vcc, %[reach2], {R2}          ;; !(r2 < reach2)",
-    "s_and_b64 s[94:95], vcc, s[90:91]",
-    "s_cmp_eq_u64 s[94:95], 0",
-    "s_cbranch_scc1 L_er_incut_%=",
+    "s_and_b64 s[94:95], vcc, s[90:91]              ;; (SCC = the result is not zero)",
+    "s_cbranch_scc0 L_er_incut_%=",
     "v_cndmask_b32_e64 {MWHI}, {MWHI}, 0, s[94:95]   ;; rare: beyond the exact cut -- no mass, not counted",
     "v_cndmask_b32_e64 {MWLO}, {MWLO}, 0, s[94:95]",
     "v_cndmask_b32_e64 {T1LO}, 0, 1, s[94:95]",
@@ -139,7 +137,7 @@ TRIP = [
     "L_er_incut_%=:",
     "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
     "v_rsq_f64_e32 {RI}, {RR}",
-    "v_cmp_lt_f64_e64 s[94:95], {R2}, %[h2max]       ;; closer than the largest softening length?",
+    "v_cmp_gt_f64_e32 vcc, %[h2max], {R2}            ;; closer than the largest softening length?  (vcc lives until the branch below)",
     "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
     "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
     "v_mul_f64 {T2}, {RI}, 0.5",
@@ -153,8 +151,7 @@ TRIP = [
     "v_fma_f64 {T3}, -%[utor2wpi], {TT}, {T3}        ;; - long-range part",
     "v_mul_f64 {T3}, {MW}, {T3}",
     "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
-    "s_cmp_lg_u64 s[94:95], 0",
-    "s_cbranch_scc1 L_er_soft_%=",
+    "s_cbranch_vccnz L_er_soft_%=",
     "L_er_acc_%=:",
     "v_fmac_f64_e32 %[ax], {DX}, {T3}",
     "v_fmac_f64_e32 %[ay], {DY}, {T3}",
@@ -683,12 +680,12 @@ def direct2():
 # top.  Here the rare block is out of line (the common case falls through) and the loop is unrolled twice (one jump back per two trips).
 def trip4():
     top = TRIP.index("L_er_top_%=:")
-    cut = TRIP.index("s_cmp_eq_u64 s[94:95], 0")
+    cut = TRIP.index("s_cbranch_scc0 L_er_incut_%=")
     incut = TRIP.index("L_er_incut_%=:")
     back = TRIP.index("s_branch L_er_top_%=")
     soft0 = TRIP.index("L_er_soft_%=:")
     done = TRIP.index("L_er_done_%=:")
-    rare = TRIP[cut + 2:incut]
+    rare = TRIP[cut + 1:incut]
     seq = [TRIP[0]]
 
     def relabel(l, k):
@@ -696,13 +693,16 @@ def trip4():
             l = l.replace("L_er_%s_%%=" % name, "L_er_%s%s_%%=" % (name, k))
         return l
     for k in ("a", "b"):
-        body = TRIP[top:cut] + ["s_cmp_lg_u64 s[94:95], 0", "s_cbranch_scc1 L_er_rare_%=", "L_er_incut_%=:"] + TRIP[incut + 1:back]
+        body = TRIP[top:cut] + ["s_cbranch_scc1 L_er_rare_%=", "L_er_incut_%=:"] + TRIP[incut + 1:back]
+        body = [l for l in body if not l.startswith("s_add_u32 %[ntr]")]      # trips are counted per pair (and once on the way out of copy b)
+        if k == "b":
+            body = [l.replace("s_cbranch_vccz L_er_done_%=", "s_cbranch_vccz L_er_doneb_%=") for l in body]
         seq += [relabel(l, k) for l in body]
-    seq += ["s_branch L_er_topa_%="]
+    seq += ["s_add_u32 %[ntr], %[ntr], 2", "s_branch L_er_topa_%="]
     for k in ("a", "b"):
         seq += ["L_er_rare%s_%%=:" % k] + rare + ["s_branch L_er_incut%s_%%=" % k]
         seq += [relabel(l, k) for l in TRIP[soft0:done]]
-    seq += ["L_er_done_%=:"]
+    seq += ["L_er_doneb_%=:", "s_add_u32 %[ntr], %[ntr], 1", "L_er_done_%=:"]
     return seq
 
 # ---- cull --------------------------------------------------------------------------------------------------------------------
