@@ -694,15 +694,17 @@ def trip4():
         return l
     for k in ("a", "b"):
         body = TRIP[top:cut] + ["s_cbranch_scc1 L_er_rare_%=", "L_er_incut_%=:"] + TRIP[incut + 1:back]
-        body = [l for l in body if not l.startswith("s_add_u32 %[ntr]")]      # trips are counted per pair (and once on the way out of copy b)
+        body = [l for l in body if not l.startswith("s_add_u32 %[ntr]")]      # trips are counted per pair
         if k == "b":
-            body = [l.replace("s_cbranch_vccz L_er_done_%=", "s_cbranch_vccz L_er_doneb_%=") for l in body]
+            # the exit test ("no lane is on the oldest slot") once per pair of trips: a trip taken after the slot has emptied is an ordinary
+            # trip of the lanes on the newer slots (one idle trip at the end of a list, where all lanes are parked)
+            body = [l for l in body if not l.startswith("v_cmp_eq_u32_e32 vcc, %[tail], %[q]") and not l.startswith("s_cbranch_vccz L_er_done_%=")]
         seq += [relabel(l, k) for l in body]
     seq += ["s_add_u32 %[ntr], %[ntr], 2", "s_branch L_er_topa_%="]
     for k in ("a", "b"):
         seq += ["L_er_rare%s_%%=:" % k] + rare + ["s_branch L_er_incut%s_%%=" % k]
         seq += [relabel(l, k) for l in TRIP[soft0:done]]
-    seq += ["L_er_doneb_%=:", "s_add_u32 %[ntr], %[ntr], 1", "L_er_done_%=:"]
+    seq += ["L_er_done_%=:"]
     return seq
 
 # ---- cull --------------------------------------------------------------------------------------------------------------------
