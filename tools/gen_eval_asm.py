@@ -546,7 +546,7 @@ D_COMPUTE = [
     "v_fmac_f64_e32 {R2}, {DZ}, {DZ}",
     "v_add_f64 {RR}, {R2}, %[tiny]                   ;; self / coincident pairs stay finite",
     "v_rsq_f64_e32 {RI}, {RR}",
-    "v_cmp_lt_f64_e64 s[94:95], {R2}, %[h2max]       ;; closer than the largest softening length?",
+    "v_cmp_gt_f64_e32 vcc, %[h2max], {R2}            ;; closer than the largest softening length?  (vcc lives until the branch below)",
     "v_mul_f64 {T1}, {RR}, {RI}                      ;; one Newton step: y += y/2 (1 - x y^2)",
     "v_fma_f64 {T1}, -{T1}, {RI}, 1.0",
     "v_mul_f64 {T2}, {RI}, 0.5",
@@ -555,8 +555,7 @@ D_COMPUTE = [
     "v_mul_f64 {T3}, %[cN], {T2}                     ;; cN / r^2",
     "v_mul_f64 {T3}, {MW}, {T3}",
     "v_mul_f64 {T3}, {RI}, {T3}                      ;; fac = f m / r",
-    "s_cmp_lg_u64 s[94:95], 0",
-    "s_cbranch_scc1 L_ed_soft{S}_%=",
+    "s_cbranch_vccnz L_ed_soft{S}_%=",
     "L_ed_acc{S}_%=:",
     "v_fmac_f64_e32 %[ax], {DX}, {T3}",
     "v_fmac_f64_e32 %[ay], {DY}, {T3}",
@@ -577,35 +576,48 @@ def direct():
     i0 = TRIP.index("L_er_soft_%=:")
     soft = TRIP[i0 + 7:TRIP.index("L_er_done_%=:")]      # from the wait for the softening length on: shared with ER_TRIP_ASM
     rx, ry = role_regs("x"), role_regs("y")
+    rs = role_regs("x")
+    rs["S"] = "s"
     seq = ["s_mov_b32 s89, 0",
            "ds_read_b128 %s, %%[ptr]" % rx["E0"],
            "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"],
-           "L_ed_topx_%=:",
-           "s_waitcnt lgkmcnt(0)",
-           "ds_read_b128 %s, %%[ptr] offset:32             ;; the next entry (one past the end on the last trip: inside the pool, not used)" % ry["E0"],
-           "ds_read_b128 %s, %%[ptr] offset:48" % ry["E1"]]
-    seq += fill(D_COMPUTE, rx)
-    seq += ["s_add_u32 s89, s89, 1",
+           "s_bitcmp1_b32 %[n], 0                           ;; an odd count: one entry alone first, then pairs (one loop test per pair)",
+           "s_cbranch_scc0 L_ed_pairs_%=",
+           "s_waitcnt lgkmcnt(0)"]
+    seq += fill(D_COMPUTE, rs)
+    seq += ["s_mov_b32 s89, 1",
+            "v_add_u32_e32 %[ptr], 32, %[ptr]",
+            "ds_read_b128 %s, %%[ptr]                        ;; (with n = 1: one entry past the end, inside the pool, not used)" % rx["E0"],
+            "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"],
+            "L_ed_pairs_%=:",
             "s_cmp_lt_u32 s89, %[n]",
             "s_cbranch_scc0 L_ed_done_%=",
+            "L_ed_topx_%=:",
             "s_waitcnt lgkmcnt(0)",
+            "ds_read_b128 %s, %%[ptr] offset:32" % ry["E0"],
+            "ds_read_b128 %s, %%[ptr] offset:48" % ry["E1"]]
+    seq += fill(D_COMPUTE, rx)
+    seq += ["s_waitcnt lgkmcnt(0)",
             "v_add_u32_e32 %[ptr], 64, %[ptr]",
-            "ds_read_b128 %s, %%[ptr]" % rx["E0"],
+            "ds_read_b128 %s, %%[ptr]                        ;; the next pair's first entry (past the end after the last pair: not used)" % rx["E0"],
             "ds_read_b128 %s, %%[ptr] offset:16" % rx["E1"]]
     seq += fill(D_COMPUTE, ry)
-    seq += ["s_add_u32 s89, s89, 1",
+    seq += ["s_add_u32 s89, s89, 2",
             "s_cmp_lt_u32 s89, %[n]",
             "s_cbranch_scc1 L_ed_topx_%=",
             "s_branch L_ed_done_%="]
-    for r in (rx, ry):
+    for r in (rs, rx, ry):
         S = r["S"]
-        seq += fill(D_SOFT_HEAD, r)
+        head = list(D_SOFT_HEAD)
+        if S == "y":   # the second entry of the pair
+            head = [head[0], head[1], "s_add_u32 s88, s89, 1", head[2].replace("s89", "s88")] + head[3:]
+        seq += fill(head, r)
         for l in soft:
             l = l.replace("L_er_acc_%=", "L_ed_acc%s_%%=" % S)
             seq.append(fill([l], r)[0])
-    seq += ["L_ed_done_%=:"]
+    seq += ["L_ed_done_%=:",
+            "s_waitcnt lgkmcnt(0)                            ;; the request that ran ahead must have landed before its registers are anybody else's"]
     return seq
-
 
 # ---- tree-only force loop, two entries per trip as two interleaved instruction streams (ER_DIRECT2_ASM; -DGW_DIRECT=2) ---------------
 def d2_regs(sfx):
@@ -622,7 +634,7 @@ def d2_regs(sfx):
     return r
 
 
-D2_NOBR = [l.replace("s[94:95]", "{SOFT}") for l in D_COMPUTE[:D_COMPUTE.index("s_cmp_lg_u64 s[94:95], 0")]]
+D2_NOBR = [l.replace("v_cmp_gt_f64_e32 vcc, %[h2max], {R2}", "v_cmp_gt_f64_e64 {SOFT}, %[h2max], {R2}") for l in D_COMPUTE[:D_COMPUTE.index("s_cbranch_vccnz L_ed_soft{S}_%=")]]
 D2_ACC = ["s_cmp_lg_u64 {SOFT}, 0",
           "s_cbranch_scc1 L_ed_soft{S}_%=",
           "L_ed_acc{S}_%=:",
@@ -773,7 +785,7 @@ def main():
     out.append(macro("ER_TRIP3_NOYUK_ASM", trip3(False), "(FSTOFF)"))
     out.append(clobbers("ER_TRIP3_CLOBBERS", range(94, 128), range(86, 96)))
     out.append(macro("ER_DIRECT_ASM", direct()))
-    out.append(clobbers("ER_DIRECT_CLOBBERS", range(96, 128), range(89, 96)))
+    out.append(clobbers("ER_DIRECT_CLOBBERS", range(96, 128), range(88, 96)))
     out.append(macro("ER_DIRECT2_ASM", direct2()))
     out.append(clobbers("ER_DIRECT2_CLOBBERS", range(82, 128), range(86, 96)))
     out.append(macro("ER_TRIP4_ASM", trip4(), "(YUKSEG, FSTOFF)"))
