@@ -471,7 +471,7 @@ def main():
         out["roofline"]["traffic"], out["roofline"]["traffic_provenance"] = walk_traffic(args, n, world, split["launches_per_step"] if split else 1)
         if args.walk == "group" and split:
             # the kernel's own bound: fp64 VALU issue.  Every evaluated pair costs one trip of the force loop's common path (static
-            # count from this build's assembly, profiles/r04_eval_isa_mix.txt, ER_TRIP_ASM: 45 VALU + 3 extra issue slots for the quarter-rate
+            # count from this build's assembly, profiles/r04_eval_isa_mix.txt, ER_TRIP4_ASM: 44.5 VALU (counted as 45) + 3 extra issue slots for the quarter-rate
             # v_rsq_f64), one wave-instruction issues in 4 cycles on a SIMD for 64
             # lanes, 4 SIMDs per CU
             pairs = st.interactions / max(1, split["launches_per_step"])
