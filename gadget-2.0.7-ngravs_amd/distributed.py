@@ -219,6 +219,7 @@ class DistributedEngine(Engine):
         if comm is None:
             comm = "rccl" if dist.get_backend(group) == "nccl" else "torch"
         self.comm = RcclComm(dev, group) if comm == "rccl" else TorchComm(dev, group)
+        self.group, self._dev = group, dev
         self.comm_note = ""
         if comm == "rccl":
             # the C communicator proves itself once; if it does not on ANY task, all tasks fall back together to the process group
@@ -291,6 +292,17 @@ class DistributedEngine(Engine):
         self.n = self.num_local()
         self.update_particles(pos, mass, ptype, old_acc=old_acc, active=active)
         self._host(self._L.ngravs_host_kept_step(self._h, C.byref(self.comm.c), C.byref(self.info)), "ngravs_host_kept_step")
+
+    def kept_walk_missed(self):
+        """After gravity_tree() on a kept step: did the walk of ANY task want a top leaf that was never imported (ngravs_walk_unopened,
+        all-reduced)?  The production walk used such a leaf as a monopole and counted it; the reference walk refuses instead.  True means:
+        decompose (domain_Decomposition) and walk again -- what gadget_glue.c does."""
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([int(self.walk_unopened())], dtype=torch.int64,
+                         device=(self._dev if dist.get_backend(self.group) == "nccl" else "cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item()) > 0
 
     def pmforce_periodic(self):
         self._host(self._L.ngravs_host_pmforce_periodic(self._h, C.byref(self.comm.c)), "ngravs_host_pmforce_periodic")

@@ -793,6 +793,7 @@ def _kept_worker(rank, world, port, out_dir, case):
         pos = _kept_positions(pos0, L, step)
         eng.kept_step(pos[ids], mass[ids], typ[ids], old_acc=o)
         eng.gravity_tree()
+        assert not eng.kept_walk_missed()                               # (collective) no task's walk wanted a leaf that was never imported
         a, o, c = eng.get_accel()[:3]
         assert np.array_equal(eng.local_ids(), ids)                     # nothing migrates on a kept step
         out.update({"acc%d" % step: a, "cost%d" % step: c, "old%d" % step: o,
